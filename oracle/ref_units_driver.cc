@@ -1,0 +1,158 @@
+/*
+ * oracle/ref_units_driver.cc -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A small command interpreter, written for this repo, that is linked against
+ * the upstream reference's own lib/profiles_lib objects (compiled from
+ * /root/reference where they lie; see oracle/Makefile target `ref`).  It lets
+ * the tests probe the reference's unit-level functions
+ * one call at a time.  oracle_cli.cc (-DORACLE_CLI_UNITS) is the twin that runs
+ * the same command language on this repo's restatement; the two outputs are
+ * diffed byte for byte (tests/test_oracle_vs_ref.py, tests/golden/units_*.txt).
+ *
+ * Command language (one command per line, integers are decimal longs):
+ *   profile <start> <end> <p_length> <ngaps> {<gs> <ge>}*   set current profile
+ *   p2s <seq_idx>          profile_idx_of_seq_idx      (m_profile.cc:91-112)
+ *   s2p <profile_idx>      seq_idx_of_profile_idx      (m_profile.cc:114-149)
+ *   sub <s> <e>            subset_profile              (m_profile.cc:160-206)
+ *   subseq <s> <e>         subset_seq                  (m_profile.cc:208-212)
+ *   delta <rs> <re> <qs> <qe> <nr> {<gs> <ge>}* <nq> {<gs> <ge>}*   set current delta entry
+ *   drev                   M_delta_entry::reverse      (m_delta.cc:94-146)
+ *   d2o                    deltas_of_gaps              (m_delta_stream_writer.hh:14-53)
+ * Every command prints exactly one line.
+ */
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <m_option.hh>
+#include <m_range.hh>
+#include <m_profile.hh>
+#include <m_delta.hh>
+#include <m_delta_stream_writer.hh>
+
+using namespace Para_mugsy;
+
+typedef std::vector<M_range<M_profile_idx> > gaps_t;
+
+static void print_profile(M_profile const &p) {
+  std::cout << "PROFILE " << p.p_range.get_start() << ' ' << p.p_range.get_end() << ' ' << p.p_length << ' ' << p.p_gaps.size();
+  for(gaps_t::const_iterator i = p.p_gaps.begin(); i != p.p_gaps.end(); ++i) {
+    std::cout << ' ' << i->get_start() << ' ' << i->get_end();
+  }
+  std::cout << '\n';
+}
+
+static gaps_t read_gaps(std::istringstream &iss) {
+  gaps_t g;
+  long n = 0;
+  iss >> n;
+  for(long k = 0; k < n; ++k) {
+    long s, e;
+    iss >> s >> e;
+    g.push_back(M_range<M_profile_idx>(s, e));
+  }
+  return g;
+}
+
+int main() {
+  std::ios_base::sync_with_stdio(false);
+  M_profile cur("", "", "", M_range<M_seq_idx>(1, 1), 1, 0, gaps_t(), "");
+  M_delta_entry cur_d(std::make_pair(std::string(), std::string()), std::make_pair(0L, 0L),
+                      M_range<M_seq_idx>(1, 1), M_range<M_seq_idx>(1, 1), gaps_t(), gaps_t());
+  std::string line;
+  while(std::getline(std::cin, line)) {
+    std::istringstream iss(line);
+    std::string cmd;
+    if(!(iss >> cmd)) {
+      continue;
+    }
+    try {
+      if(cmd == "profile") {
+        long s, e, len;
+        iss >> s >> e >> len;
+        gaps_t g = read_gaps(iss);
+        cur = M_profile("", "", "", M_range<M_seq_idx>(s, e), len, 0, g, "");
+        std::cout << "OK\n";
+      }
+      else if(cmd == "p2s") {
+        long si;
+        iss >> si;
+        std::cout << "IDX " << profile_idx_of_seq_idx(cur, si) << '\n';
+      }
+      else if(cmd == "s2p") {
+        long pi;
+        iss >> pi;
+        M_option<M_seq_idx> o = seq_idx_of_profile_idx(cur, pi);
+        if(o) {
+          std::cout << "IDX " << o.value() << '\n';
+        }
+        else {
+          std::cout << "NONE\n";
+        }
+      }
+      else if(cmd == "sub") {
+        long s, e;
+        iss >> s >> e;
+        M_option<M_profile> o = subset_profile(cur, s, e);
+        if(o) {
+          print_profile(o.value());
+        }
+        else {
+          std::cout << "NONE\n";
+        }
+      }
+      else if(cmd == "subseq") {
+        long s, e;
+        iss >> s >> e;
+        print_profile(subset_seq(cur, s, e));
+      }
+      else if(cmd == "delta") {
+        long rs, re, qs, qe;
+        iss >> rs >> re >> qs >> qe;
+        gaps_t rg = read_gaps(iss);
+        gaps_t qg = read_gaps(iss);
+        cur_d = M_delta_entry(std::make_pair(std::string(), std::string()), std::make_pair(0L, 0L),
+                              M_range<M_seq_idx>(rs, re), M_range<M_seq_idx>(qs, qe), rg, qg);
+        std::cout << "OK\n";
+      }
+      else if(cmd == "drev") {
+        M_delta_entry r = cur_d.reverse();
+        std::cout << "DELTA " << r.ref_range.get_start() << ' ' << r.ref_range.get_end() << ' '
+                  << r.query_range.get_start() << ' ' << r.query_range.get_end() << ' ' << r.ref_gaps.size();
+        for(gaps_t::const_iterator i = r.ref_gaps.begin(); i != r.ref_gaps.end(); ++i) {
+          std::cout << ' ' << i->get_start() << ' ' << i->get_end();
+        }
+        std::cout << ' ' << r.query_gaps.size();
+        for(gaps_t::const_iterator i = r.query_gaps.begin(); i != r.query_gaps.end(); ++i) {
+          std::cout << ' ' << i->get_start() << ' ' << i->get_end();
+        }
+        std::cout << '\n';
+      }
+      else if(cmd == "d2o") {
+        std::vector<long> o = deltas_of_gaps(cur_d);
+        std::cout << "OFFSETS";
+        for(std::vector<long>::const_iterator i = o.begin(); i != o.end(); ++i) {
+          std::cout << ' ' << *i;
+        }
+        std::cout << '\n';
+      }
+      else {
+        std::cout << "BADCMD\n";
+      }
+    }
+    catch(Seq_idx_out_of_range const &) {
+      std::cout << "EXC Seq_idx_out_of_range\n";
+    }
+    catch(Profile_idx_out_of_range const &) {
+      std::cout << "EXC Profile_idx_out_of_range\n";
+    }
+    catch(Is_none_error const &) {
+      std::cout << "EXC Is_none_error\n";
+    }
+    catch(std::exception const &) {
+      std::cout << "EXC exception\n";
+    }
+  }
+  return 0;
+}
