@@ -1,0 +1,32 @@
+# Top-level build: libparamugsy_amd.so (HIP, gfx950) + bin/m_translate (drop-in CLI).
+# `make oracle` builds the test-only CPU oracle (and, where /root/reference exists, oracle/_ref).
+HIPCC    ?= hipcc
+ARCH     ?= gfx950
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+CSRC      = paramugsy_amd/csrc
+LIB       = paramugsy_amd/libparamugsy_amd.so
+LIB_SRCS  = $(CSRC)/pm_common.hip $(CSRC)/translate_job.hip $(CSRC)/translate_host.cc $(wildcard $(CSRC)/dp_*.hip)
+LIB_HDRS  = $(wildcard $(CSRC)/*.hpp) include/paramugsy_amd.h
+
+.PHONY: all lib cli oracle clean
+
+all: lib cli
+
+lib: $(LIB)
+
+$(LIB): $(LIB_SRCS) $(LIB_HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_SRCS)
+
+cli: bin/m_translate
+
+bin/m_translate: $(CSRC)/m_translate_main.cc $(LIB)
+	mkdir -p bin
+	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/m_translate_main.cc -Lparamugsy_amd -lparamugsy_amd -Wl,-rpath,'$$ORIGIN/../paramugsy_amd'
+
+oracle:
+	$(MAKE) -C oracle oracle
+	if [ -d /root/reference/lib ]; then $(MAKE) -C oracle ref; fi
+
+clean:
+	rm -f $(LIB) bin/m_translate
+	$(MAKE) -C oracle clean

@@ -1,0 +1,156 @@
+/*
+ * paramugsy_amd.h -- C ABI of libparamugsy_amd.so (MI355X / gfx950).
+ *
+ * What this boundary replaces.  In the reference the "profiles" translate stage is reached only as a
+ * child process: `m_translate <left_dir> <right_dir> <nucmer_list> <out_delta>`
+ * (lib/m_translate/m_translate_main.cc:10-13,19-46), whose one library entry point is
+ *     void Para_mugsy::translate(left_dir, right_dir, nucmer_list, out_stream)   lib/m_translate/m_translate.hh:9-14
+ * There is no OCaml `external`, ctypes stub or extern "C" anywhere in the reference, so this header is NEW
+ * surface: it is what a ctypes/cgo/JNI binding of that entry point would bind.  The byte-compatible
+ * drop-in is the executable bin/m_translate built on top of it (same argv, same output bytes).
+ * INTEGRATION.md shows the OCaml ctypes stub and the one-line change to the task script.
+ *
+ * Three levels, all plain C (pointers, sizes, no C++ or torch types):
+ *   1. pm_translate_files()     == Para_mugsy::translate + the two header lines of m_translate_main.cc:35-39
+ *   2. pm_job_*()               a batch of (delta entry x left row x right row) work units kept resident in
+ *                               HBM; one pm_job_run() is one pass of the hot path
+ *                               (_translate_delta_with_profiles, lib/m_translate/m_translate.cc:625-647, over
+ *                               every unit of the batch)
+ *   3. pm_rows_*_batch()        batched coordinate conversions of lib/profiles_lib/m_profile.cc:91-149
+ *
+ * Every function returns PM_OK (0) or a negative PM_E_* code; pm_last_error() gives a message.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point fails with PM_E_NO_DEVICE.
+ */
+#ifndef PARAMUGSY_AMD_H
+#define PARAMUGSY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library-level return codes (negative) ---- */
+#define PM_OK 0
+#define PM_E_INVALID (-1)   /* bad argument (null pointer, negative size, index out of range) */
+#define PM_E_NO_DEVICE (-2) /* no HIP device / HIP runtime error at init */
+#define PM_E_HIP (-3)       /* a HIP call failed; see pm_last_error() */
+#define PM_E_IO (-4)        /* file could not be opened / written */
+#define PM_E_PARSE (-5)     /* Profile_read_error (m_profile.hh:13) / Delta_stream_parse_error (m_delta.hh:13) */
+#define PM_E_UNIT (-6)      /* at least one work unit ended in a PM_ST_* failure (the reference aborts there) */
+#define PM_E_MALFORMED (-7) /* a gap list is not ascending and disjoint: outside the domain of this library */
+
+/* ---- per-unit status: 0 or the failure class the reference would have died with ---- */
+#define PM_ST_OK 0
+#define PM_ST_SEQ_IDX_OUT_OF_RANGE 1     /* Seq_idx_out_of_range, m_profile.cc:110 */
+#define PM_ST_PROFILE_IDX_OUT_OF_RANGE 2 /* Profile_idx_out_of_range, m_profile.cc:147,162 */
+#define PM_ST_IS_NONE 3                  /* Is_none_error from .value(), m_option.hh:28 */
+#define PM_ST_ASSERT_GAP_BEHIND 4        /* assert(r_diff >= 0), m_translate.cc:42-43 */
+#define PM_ST_ASSERT_SUB_LENGTHS 5       /* assert(...length() == ...), m_translate.cc:550-551 */
+#define PM_ST_ALREADY_UNNEXT 6           /* Already_unnext_gap, m_translate.cc:74 */
+#define PM_ST_STEP_LIMIT 7               /* merge did not terminate within its step budget */
+#define PM_ST_OFFSET_ORDER 8             /* builder gaps not in writer order: result would differ, so refuse */
+#define PM_ST_MALFORMED_INPUT 9          /* unit touches a row / entry whose gap list is not ascending+disjoint */
+
+/* ---- batch description (host pointers; copied to the device by pm_job_create) ---- */
+
+/* Row profiles of one side.  One row == one M_profile (m_profile.hh:26-100) minus its names and text. */
+typedef struct pm_rows {
+  int64_t n;
+  const int64_t *start;     /* [n]   p_range start (1-based, may be > end: reverse strand) */
+  const int64_t *end;       /* [n]   p_range end */
+  const int64_t *length;    /* [n]   p_length (columns) */
+  const int64_t *gap_off;   /* [n+1] CSR offsets into gap_start/gap_end */
+  const int64_t *gap_start; /* [gap_off[n]] gap runs in column coordinates, ascending and disjoint per row */
+  const int64_t *gap_end;
+} pm_rows_t;
+
+/* Parsed delta entries.  One == one M_delta_entry (m_delta.hh:17-62) minus its header strings. */
+typedef struct pm_deltas {
+  int64_t n;
+  const int64_t *ref_start; /* [n] */
+  const int64_t *ref_end;
+  const int64_t *qry_start;
+  const int64_t *qry_end;
+  const int64_t *ref_gap_off; /* [n+1] */
+  const int64_t *ref_gap_start;
+  const int64_t *ref_gap_end;
+  const int64_t *qry_gap_off; /* [n+1] */
+  const int64_t *qry_gap_start;
+  const int64_t *qry_gap_end;
+} pm_deltas_t;
+
+/* Work units: the (entry, left row, right row) triples the loops of m_translate.cc:698-706 visit. */
+typedef struct pm_units {
+  int64_t n;
+  const int32_t *delta; /* [n] index into pm_deltas */
+  const int32_t *left;  /* [n] index into the left pm_rows */
+  const int32_t *right; /* [n] index into the right pm_rows */
+} pm_units_t;
+
+/* One emitted delta entry (what M_delta_builder::to_delta returns, m_delta_builder.cc:7-22), with its gap
+ * lists already merged into the signed-offset form M_delta_stream_writer prints
+ * (deltas_of_gaps, m_delta_stream_writer.hh:14-53; the terminating 0 is included). */
+typedef struct pm_entry {
+  int64_t ref_start;
+  int64_t ref_end;
+  int64_t qry_start;
+  int64_t qry_end;
+  int64_t offset_begin; /* index of this entry's first value in the offsets array */
+  int64_t n_offsets;    /* values including the terminating 0 */
+} pm_entry_t;
+
+typedef struct pm_job pm_job_t; /* opaque; owns device memory */
+
+const char *pm_last_error(void);
+int pm_device_count(void);
+/* name/CU count of device `dev`; name buffer of `cap` bytes */
+int pm_device_info(int dev, char *name, int cap, int *compute_units, int64_t *hbm_bytes);
+
+/* Upload a batch, build the per-gap prefix tables and validate the gap lists on the device. */
+int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+                  int device, pm_job_t **out);
+/* One pass of the hot path over every unit: count, scan, emit.  Asynchronous on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).  Inputs and outputs stay in HBM. */
+int pm_job_run(pm_job_t *job, void *hip_stream);
+/* Wait for the last run and report the output sizes. */
+int pm_job_sizes(pm_job_t *job, int64_t *n_entries, int64_t *n_offsets);
+/* Copy results to host arrays sized from pm_job_sizes.  unit_entry_off has units.n + 1 elements: unit u owns
+ * entries [unit_entry_off[u], unit_entry_off[u+1]).  Any pointer may be NULL to skip that array.
+ * Returns PM_OK, or PM_E_UNIT when some unit_status is non-zero (arrays are still filled). */
+int pm_job_fetch(pm_job_t *job, int32_t *unit_status, int64_t *unit_entry_off, pm_entry_t *entries, int64_t *offsets);
+/* Algorithmic bytes one pm_job_run moves (inputs read + outputs written), for roofline accounting. */
+int pm_job_algorithmic_bytes(pm_job_t *job, int64_t *bytes);
+void pm_job_destroy(pm_job_t *job);
+
+/* Batched coordinate conversions on one side's rows (a3/a4).  `row` selects the row per query; results and
+ * per-query status (PM_ST_*; IS_NONE = column is a gap) are written to host arrays. */
+int pm_rows_profile_idx_of_seq_idx_batch(const pm_rows_t *rows, int64_t n, const int32_t *row, const int64_t *seq_idx,
+                                         int64_t *profile_idx, int32_t *status, int device);
+int pm_rows_seq_idx_of_profile_idx_batch(const pm_rows_t *rows, int64_t n, const int32_t *row, const int64_t *profile_idx,
+                                         int64_t *seq_idx, int32_t *status, int device);
+
+/* Host-only loading of a job's files (no device needed): both `profiles` files (read_profile_file,
+ * m_profile.cc:15-85), every delta file (M_delta_stream, m_delta.cc:72-92,148-220), the per-sequence sorted
+ * row index (_profile_map_of_dir, m_translate.cc:188-207) and the unit list of the loops at
+ * m_translate.cc:666-707.  pm_workload_tables() fills views into memory owned by the workload.
+ * pm_workload_load returns PM_E_PARSE with a VALID handle when a delta file is malformed part-way: the
+ * entries before the failure are loaded, as the reference translates them before it throws. */
+typedef struct pm_workload pm_workload_t;
+int pm_workload_load(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
+                     pm_workload_t **out);
+int pm_workload_tables(pm_workload_t *w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units);
+/* side 0 = left, 1 = right; pointers stay valid until pm_workload_destroy */
+int pm_workload_row_name(pm_workload_t *w, int side, int64_t row, const char **major_name, const char **seq_name);
+void pm_workload_destroy(pm_workload_t *w);
+
+/* File level: the whole of Para_mugsy::translate plus m_translate_main.cc's two header lines.
+ * delta_paths: n_paths NUL-terminated strings.  Output bytes equal the reference's. */
+int pm_translate_files(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
+                       const char *out_path, int device);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

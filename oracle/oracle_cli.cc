@@ -140,6 +140,25 @@ int main() {
         cur_d.query_gaps = read_gaps(iss);
         std::cout << "OK\n";
       }
+      else if(cmd == "dparse") {
+        long rs, re, qs, qe, v;
+        iss >> rs >> re >> qs >> qe;
+        std::ostringstream text;
+        text << "a b\nNUCMER\n>r q 1 1\n" << rs << ' ' << re << ' ' << qs << ' ' << qe << " 0 0 0\n";
+        while(iss >> v) {
+          text << v << '\n';
+        }
+        text << "0\n";
+        std::istringstream in(text.str());
+        pmo::DeltaReader reader(in);
+        if(!reader.next(&cur_d)) {
+          throw pmo::Failure(pmo::IS_NONE);
+        }
+        std::cout << "DELTA " << cur_d.ref.s << ' ' << cur_d.ref.e << ' ' << cur_d.query.s << ' ' << cur_d.query.e;
+        print_gaps(cur_d.ref_gaps);
+        print_gaps(cur_d.query_gaps);
+        std::cout << '\n';
+      }
       else if(cmd == "drev") {
         pmo::DeltaEntry r = pmo::reverse_entry(cur_d);
         std::cout << "DELTA " << r.ref.s << ' ' << r.ref.e << ' ' << r.query.s << ' ' << r.query.e;

@@ -1,0 +1,97 @@
+"""ctypes loader of the CPU oracle (oracle/_build/libpm_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by paramugsy_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from paramugsy_amd import capi  # struct layouts only  # noqa: E402
+
+LIB_PATH = os.path.join(_HERE, "_build", "libpm_oracle.so")
+REF_DIR = os.path.join(_HERE, "_ref")
+BUILD_DIR = os.path.join(_HERE, "_build")
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s missing: run `make -C oracle oracle`" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        l.pmo_translate_units.restype = C.c_void_p
+        l.pmo_translate_units.argtypes = [C.POINTER(capi.PmRows), C.POINTER(capi.PmRows), C.POINTER(capi.PmDeltas), C.POINTER(capi.PmUnits)]
+        l.pmo_result_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        l.pmo_result_sizes.restype = None
+        l.pmo_result_fetch.argtypes = [C.c_void_p] * 5
+        l.pmo_result_fetch.restype = None
+        l.pmo_result_free.argtypes = [C.c_void_p]
+        l.pmo_result_free.restype = None
+        for n in ("pmo_profile_idx_of_seq_idx_batch", "pmo_seq_idx_of_profile_idx_batch"):
+            getattr(l, n).argtypes = [C.POINTER(capi.PmRows), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            getattr(l, n).restype = None
+        l.pmo_enumerate_units.restype = C.c_int64
+        l.pmo_enumerate_units.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.pmo_translate_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_char_p]
+        _lib = l
+    return _lib
+
+
+def translate_units(left, right, deltas, units):
+    """Oracle run over the same flat tables the product takes -> dict(status, unit_entry_off, entries, offsets)."""
+    l = lib()
+    ls, k1 = capi.rows_struct(left)
+    rs, k2 = capi.rows_struct(right)
+    ds, k3 = capi.deltas_struct(deltas)
+    us, k4 = capi.units_struct(units)
+    h = l.pmo_translate_units(C.byref(ls), C.byref(rs), C.byref(ds), C.byref(us))
+    ne, no = C.c_int64(), C.c_int64()
+    l.pmo_result_sizes(h, C.byref(ne), C.byref(no))
+    n = int(us.n)
+    status = np.zeros(n, dtype=np.int32)
+    ent_off = np.zeros(n + 1, dtype=np.int64)
+    entries = np.zeros(ne.value, dtype=capi.ENTRY_DTYPE)
+    offsets = np.zeros(no.value, dtype=np.int64)
+    l.pmo_result_fetch(h, status.ctypes.data, ent_off.ctypes.data, entries.ctypes.data, offsets.ctypes.data)
+    l.pmo_result_free(h)
+    return {"status": status, "unit_entry_off": ent_off, "entries": entries, "offsets": offsets}
+
+
+def profile_idx_of_seq_idx(rows, row, seq_idx):
+    rs, keep = capi.rows_struct(rows)
+    row = np.ascontiguousarray(row, dtype=np.int32)
+    q = np.ascontiguousarray(seq_idx, dtype=np.int64)
+    out = np.zeros(len(q), dtype=np.int64)
+    st = np.zeros(len(q), dtype=np.int32)
+    lib().pmo_profile_idx_of_seq_idx_batch(C.byref(rs), len(q), row.ctypes.data, q.ctypes.data, out.ctypes.data, st.ctypes.data)
+    return out, st
+
+
+def seq_idx_of_profile_idx(rows, row, profile_idx):
+    rs, keep = capi.rows_struct(rows)
+    row = np.ascontiguousarray(row, dtype=np.int32)
+    q = np.ascontiguousarray(profile_idx, dtype=np.int64)
+    out = np.zeros(len(q), dtype=np.int64)
+    st = np.zeros(len(q), dtype=np.int32)
+    lib().pmo_seq_idx_of_profile_idx_batch(C.byref(rs), len(q), row.ctypes.data, q.ctypes.data, out.ctypes.data, st.ctypes.data)
+    return out, st
+
+
+def enumerate_units(left_dir, right_dir, delta_paths):
+    arr = (C.c_char_p * len(delta_paths))(*[p.encode() for p in delta_paths])
+    n = lib().pmo_enumerate_units(left_dir.encode(), right_dir.encode(), arr, len(delta_paths), 0, None, None, None)
+    d = np.zeros(n, dtype=np.int32)
+    a = np.zeros(n, dtype=np.int32)
+    b = np.zeros(n, dtype=np.int32)
+    lib().pmo_enumerate_units(left_dir.encode(), right_dir.encode(), arr, len(delta_paths), n, d.ctypes.data, a.ctypes.data, b.ctypes.data)
+    return {"delta": d, "left": a, "right": b}
+
+
+def translate_files(left_dir, right_dir, delta_paths, out_path) -> int:
+    arr = (C.c_char_p * len(delta_paths))(*[p.encode() for p in delta_paths])
+    return lib().pmo_translate_files(left_dir.encode(), right_dir.encode(), arr, len(delta_paths), out_path.encode())

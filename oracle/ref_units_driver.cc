@@ -18,6 +18,8 @@
  *   delta <rs> <re> <qs> <qe> <nr> {<gs> <ge>}* <nq> {<gs> <ge>}*   set current delta entry
  *   drev                   M_delta_entry::reverse      (m_delta.cc:94-146)
  *   d2o                    deltas_of_gaps              (m_delta_stream_writer.hh:14-53)
+ *   dparse <rs> <re> <qs> <qe> {<offset>}*   M_delta_stream::next + _split_gaps (m_delta.cc:148-220,14-68)
+ *                          on a one-entry delta text built from the arguments; sets the current delta entry
  * Every command prints exactly one line.
  */
 #include <iostream>
@@ -115,6 +117,30 @@ int main() {
         cur_d = M_delta_entry(std::make_pair(std::string(), std::string()), std::make_pair(0L, 0L),
                               M_range<M_seq_idx>(rs, re), M_range<M_seq_idx>(qs, qe), rg, qg);
         std::cout << "OK\n";
+      }
+      else if(cmd == "dparse") {
+        long rs, re, qs, qe, v;
+        iss >> rs >> re >> qs >> qe;
+        std::ostringstream text;
+        text << "a b\nNUCMER\n>r q 1 1\n" << rs << ' ' << re << ' ' << qs << ' ' << qe << " 0 0 0\n";
+        while(iss >> v) {
+          text << v << '\n';
+        }
+        text << "0\n";
+        std::istringstream in(text.str());
+        M_delta_stream ds(in);
+        cur_d = ds.next().value();
+        M_delta_entry const &r = cur_d;
+        std::cout << "DELTA " << r.ref_range.get_start() << ' ' << r.ref_range.get_end() << ' '
+                  << r.query_range.get_start() << ' ' << r.query_range.get_end() << ' ' << r.ref_gaps.size();
+        for(gaps_t::const_iterator i = r.ref_gaps.begin(); i != r.ref_gaps.end(); ++i) {
+          std::cout << ' ' << i->get_start() << ' ' << i->get_end();
+        }
+        std::cout << ' ' << r.query_gaps.size();
+        for(gaps_t::const_iterator i = r.query_gaps.begin(); i != r.query_gaps.end(); ++i) {
+          std::cout << ' ' << i->get_start() << ' ' << i->get_end();
+        }
+        std::cout << '\n';
       }
       else if(cmd == "drev") {
         M_delta_entry r = cur_d.reverse();

@@ -1,0 +1,38 @@
+// m_translate_main.cc -- the drop-in executable.  Same argv, same exit behaviour and same output bytes as
+// the reference's lib/m_translate/m_translate_main.cc:19-46; the work runs on the GPU through the C ABI.
+// Optional: PARAMUGSY_DEVICE=<n> selects the HIP device (default 0).
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/paramugsy_amd.h"
+
+int main(int argc, char **argv) {
+  if(argc < 5) {
+    fprintf(stderr, "Usage: m_translate <left_profile_dir> <right_profile_dir> <nucmer_file_list> <output_delta_path>\n");
+    return 1;
+  }
+  std::vector<std::string> paths;
+  {
+    std::ifstream list(argv[3]);
+    std::string line;
+    while(std::getline(list, line)) {
+      paths.push_back(line);
+    }
+  }
+  std::vector<const char *> cpaths;
+  for(size_t k = 0; k < paths.size(); ++k) {
+    cpaths.push_back(paths[k].c_str());
+  }
+  const char *dev_env = getenv("PARAMUGSY_DEVICE");
+  int device = dev_env ? atoi(dev_env) : 0;
+  int rc = pm_translate_files(argv[1], argv[2], cpaths.data(), (int)cpaths.size(), argv[4], device);
+  if(rc != PM_OK) {
+    fprintf(stderr, "m_translate: error %d: %s\n", rc, pm_last_error());
+    // the reference ends in SIGABRT (uncaught exception / assert) on every failure past argument checking
+    return 134;
+  }
+  return 0;
+}

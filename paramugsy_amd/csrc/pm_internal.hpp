@@ -1,0 +1,79 @@
+// pm_internal.hpp -- shared host-side plumbing of libparamugsy_amd.so (error slot, device buffers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <string>
+
+#include "../../include/paramugsy_amd.h"
+
+namespace pm {
+
+// Records the message returned by pm_last_error() and hands `code` back.
+int fail(int code, const std::string &msg);
+// hipSetDevice with a loud failure when there is no usable device (no CPU fallback exists).
+int use_device(int device);
+
+#define PM_HIP(call)                                                                                       \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if(e_ != hipSuccess) {                                                                                 \
+      return ::pm::fail(PM_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                      \
+    }                                                                                                      \
+  } while(0)
+
+#define PM_TRY(call)  \
+  do {                \
+    int rc_ = (call); \
+    if(rc_) {         \
+      return rc_;     \
+    }                 \
+  } while(0)
+
+// Owning device allocation.
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if(p) {
+      (void)hipFree(p);
+      p = nullptr;
+      bytes = 0;
+    }
+  }
+  int alloc(size_t n) {
+    release();
+    if(n == 0) {
+      n = 16; // keep pointers non-null so kernels can take them unconditionally
+    }
+    hipError_t e = hipMalloc(&p, n);
+    if(e != hipSuccess) {
+      p = nullptr;
+      return fail(PM_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    bytes = n;
+    return PM_OK;
+  }
+  int upload(const void *src, size_t n, hipStream_t stream) {
+    int rc = alloc(n);
+    if(rc) {
+      return rc;
+    }
+    if(n > 0) {
+      // blocking copy: the caller's (pageable) host buffer may be reused as soon as this returns
+      (void)stream;
+      hipError_t e = hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+      if(e != hipSuccess) {
+        return fail(PM_E_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
+      }
+    }
+    return PM_OK;
+  }
+};
+
+} // namespace pm

@@ -1,0 +1,613 @@
+// translate_device.hpp -- device-side arithmetic of the translate path (gfx950).
+//
+// One lane owns one (delta entry x left row x right row) work unit and walks the reference's algorithm
+// without allocating: every "sub profile" of the reference (a copied gap vector) is a view
+// {parent gap array, index range, clip window, optional mirror}; every linear scan over a gap list
+// (lib/profiles_lib/m_profile.cc:91-149,160-206) is a binary search over a per-gap prefix table built
+// once per batch (translate_prepare_*).  The searches equal the scans on gap lists that are ascending and
+// disjoint, which is what both producers of gap lists emit (lib/profiles/m_profile.ml:29-47,
+// lib/profiles_lib/m_delta.cc:50-68); lists that are not are flagged at prepare time and every unit
+// touching one ends in PM_ST_MALFORMED_INPUT instead of a different answer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/paramugsy_amd.h"
+
+namespace pm {
+
+typedef long long i64;
+
+struct __attribute__((aligned(16))) R2 {
+  i64 s;
+  i64 e;
+};
+
+// Rows of one side, device resident.
+struct RowsD {
+  i64 n;
+  const R2 *range;    // [n]
+  const i64 *length;  // [n]
+  const i64 *gap_off; // [n+1]
+  const R2 *gaps;     // [gap_off[n]]
+  const i64 *pre;     // [gap_off[n] + n]: row r owns pre[gap_off[r] + r .. + n_r], pre[k] = gap columns before gap k, last = total
+  const int *bad;     // [n] 1 when the row's gap list is not ascending+disjoint
+};
+
+// Delta entries, device resident, in both orientations (o = 0 as read, 1 = M_delta_entry::reverse, m_delta.cc:94-146).
+struct DeltasD {
+  i64 n;
+  const R2 *ref;      // [n] as read
+  const R2 *qry;      // [n]
+  const i64 *ref_off; // [n+1]
+  const i64 *qry_off; // [n+1]
+  const R2 *ref_gaps[2];
+  const i64 *ref_pre[2]; // same indexing rule as RowsD::pre
+  const R2 *qry_gaps[2];
+  const i64 *qry_pre[2];
+  const int *bad;
+};
+
+__device__ __forceinline__ i64 rlen(R2 r) { return (r.s <= r.e ? r.e - r.s : r.s - r.e) + 1; } // m_range.hh:34
+__device__ __forceinline__ bool fwd(R2 r) { return r.s <= r.e; }                               // m_range.hh:36
+__device__ __forceinline__ R2 fwd_of(R2 r) { return fwd(r) ? r : R2{r.e, r.s}; }
+__device__ __forceinline__ i64 imax(i64 a, i64 b) { return a > b ? a : b; }
+__device__ __forceinline__ i64 imin(i64 a, i64 b) { return a < b ? a : b; }
+
+// m_range.hh:80-94
+__device__ __forceinline__ bool overlap(R2 a, R2 b, R2 &o) {
+  R2 fa = fwd_of(a), fb = fwd_of(b);
+  o.s = imax(fa.s, fb.s);
+  o.e = imin(fa.e, fb.e);
+  return o.e - o.s >= 0;
+}
+
+// A profile as the conversions see it: range, p_length, gap list + prefix table.
+struct PV {
+  R2 range;
+  i64 len;
+  const R2 *g;
+  const i64 *pre; // n+1 entries
+  int n;
+};
+
+// a3, m_profile.cc:91-112.  The scan adds gap k while gap[k].s <= offset + pre[k] and stops at the first
+// failure; gap[k].s - pre[k] is non-decreasing on ascending disjoint lists, so that first failure is a
+// lower bound.
+__device__ inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out) {
+  R2 f = fwd_of(p.range);
+  if(!(f.s <= si && si <= f.e)) {
+    return PM_ST_SEQ_IDX_OUT_OF_RANGE;
+  }
+  i64 d = p.range.s - si;
+  i64 offset = (d < 0 ? -d : d) + 1;
+  int lo = 0, hi = p.n;
+  while(lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if(p.g[mid].s - p.pre[mid] <= offset) {
+      lo = mid + 1;
+    }
+    else {
+      hi = mid;
+    }
+  }
+  out = p.pre[lo] + offset;
+  return PM_ST_OK;
+}
+
+// a4, m_profile.cc:114-149.  First gap whose end is >= pi decides: inside it -> none, else the gaps
+// before it are skipped.
+__device__ inline int seq_idx_of_profile_idx(const PV &p, i64 pi, i64 &out, bool &none) {
+  none = false;
+  if(!(pi < p.len + 1)) {
+    return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
+  }
+  int lo = 0, hi = p.n;
+  while(lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if(p.g[mid].e < pi) {
+      lo = mid + 1;
+    }
+    else {
+      hi = mid;
+    }
+  }
+  if(lo < p.n && p.g[lo].s <= pi) {
+    none = true;
+    return PM_ST_OK;
+  }
+  i64 offset = pi - p.pre[lo] - 1;
+  out = fwd(p.range) ? p.range.s + offset : p.range.s - offset;
+  return PM_ST_OK;
+}
+
+// The kept gaps of subset_profile as a view on the parent list.
+struct GapView {
+  const R2 *g; // parent list
+  int lo;      // first kept gap
+  int n;       // kept gaps
+  i64 ws, we;  // clip window (the subset's s..e after ordering)
+  bool mirror; // walk backwards and map column c -> L - c + 1 (m_translate.cc:559-570)
+  i64 L;
+};
+
+__device__ __forceinline__ R2 view_get(const GapView &v, int i) {
+  if(!v.mirror) {
+    R2 r = v.g[v.lo + i];
+    return R2{imax(r.s, v.ws), imin(r.e, v.we)};
+  }
+  R2 r = v.g[v.lo + (v.n - 1 - i)];
+  r = R2{imax(r.s, v.ws), imin(r.e, v.we)};
+  return R2{v.L - r.e + 1, v.L - r.s + 1};
+}
+
+// a5, m_profile.cc:160-206.  On an ascending disjoint list the gaps overlapping [s,e] are one index range.
+// Returns status; `none` mirrors the reference's empty option; seq = the sub profile's p_range.
+__device__ inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, bool &none) {
+  none = false;
+  if(s <= 0 || p.len < s || e <= 0 || p.len < e) {
+    return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
+  }
+  if(s > e) {
+    i64 t = s;
+    s = e;
+    e = t;
+  }
+  int lo = 0, hi = p.n;
+  while(lo < hi) { // first gap with end >= s
+    int mid = (lo + hi) >> 1;
+    if(p.g[mid].e < s) {
+      lo = mid + 1;
+    }
+    else {
+      hi = mid;
+    }
+  }
+  int first = lo;
+  hi = p.n;
+  while(lo < hi) { // first gap with start > e
+    int mid = (lo + hi) >> 1;
+    if(p.g[mid].s <= e) {
+      lo = mid + 1;
+    }
+    else {
+      hi = mid;
+    }
+  }
+  v.g = p.g;
+  v.lo = first;
+  v.n = lo - first;
+  v.ws = s;
+  v.we = e;
+  v.mirror = false;
+  v.L = 0;
+  if(v.n > 0) {
+    R2 a = view_get(v, 0);
+    R2 b = view_get(v, v.n - 1);
+    if(v.n == 1 && a.s == s && a.e == e) {
+      none = true;
+      return PM_ST_OK;
+    }
+    if(a.s == s) {
+      s = a.e + 1;
+    }
+    if(b.e == e) {
+      e = b.s - 1;
+    }
+  }
+  bool n1, n2;
+  i64 ss = 0, se = 0;
+  int st = seq_idx_of_profile_idx(p, s, ss, n1);
+  if(st) {
+    return st;
+  }
+  st = seq_idx_of_profile_idx(p, e, se, n2);
+  if(st) {
+    return st;
+  }
+  if(n1 || n2) {
+    return PM_ST_IS_NONE;
+  }
+  seq = R2{ss, se};
+  return PM_ST_OK;
+}
+
+// m_profile.cc:208-212
+__device__ inline int subset_seq(const PV &p, i64 s, i64 e, GapView &v, R2 &seq) {
+  i64 ps, pe;
+  int st = profile_idx_of_seq_idx(p, s, ps);
+  if(st) {
+    return st;
+  }
+  st = profile_idx_of_seq_idx(p, e, pe);
+  if(st) {
+    return st;
+  }
+  bool none;
+  st = subset_profile(p, ps, pe, v, seq, none);
+  if(st) {
+    return st;
+  }
+  return none ? PM_ST_IS_NONE : PM_ST_OK;
+}
+
+// a11, m_translate.cc:24-139: two gap lists, one push-back slot each.  Row 0 = reference, 1 = query.
+// Kept as scalars (no runtime-indexed arrays: those would go to scratch).
+struct PairCursor {
+  GapView v0, v1;
+  int at0, at1;
+  bool held0, held1;
+  R2 hold0, hold1;
+
+  __device__ __forceinline__ bool has(int r) const { return r ? (held1 || at1 < v1.n) : (held0 || at0 < v0.n); }
+  __device__ __forceinline__ R2 front(int r) const {
+    if(r) {
+      return held1 ? hold1 : view_get(v1, at1);
+    }
+    return held0 ? hold0 : view_get(v0, at0);
+  }
+  __device__ __forceinline__ bool done() const { return !has(0) && !has(1); }
+  __device__ __forceinline__ void pop(int r) {
+    if(r) {
+      if(held1) {
+        held1 = false;
+      }
+      else {
+        ++at1;
+      }
+    }
+    else {
+      if(held0) {
+        held0 = false;
+      }
+      else {
+        ++at0;
+      }
+    }
+  }
+  __device__ __forceinline__ int push_back(int r, R2 g) {
+    if(r ? held1 : held0) {
+      return PM_ST_ALREADY_UNNEXT;
+    }
+    if(r) {
+      hold1 = g;
+      held1 = true;
+    }
+    else {
+      hold0 = g;
+      held0 = true;
+    }
+    return PM_ST_OK;
+  }
+  // m_translate.cc:34-62
+  __device__ __forceinline__ int pick(i64 pos0, i64 pos1, bool &have, int &row, R2 &gap) const {
+    bool h0 = has(0), h1 = has(1);
+    have = h0 || h1;
+    if(h0 && h1) {
+      R2 g0 = front(0), g1 = front(1);
+      i64 d0 = g0.s - pos0, d1 = g1.s - pos1;
+      if(d0 < 0 || d1 < 0) {
+        return PM_ST_ASSERT_GAP_BEHIND;
+      }
+      row = d0 <= d1 ? 0 : 1;
+      gap = row ? g1 : g0;
+    }
+    else if(h0) {
+      row = 0;
+      gap = front(0);
+    }
+    else if(h1) {
+      row = 1;
+      gap = front(1);
+    }
+    return PM_ST_OK;
+  }
+};
+
+// Output side of one unit.  COUNT pass: sizes only.  EMIT pass: writes into the unit's exact slot.
+// The builder's two gap lists are never stored: each gap is turned into its signed offsets the moment it is
+// added, which equals deltas_of_gaps (m_delta_stream_writer.hh:14-53) as long as gaps arrive in that merge's
+// order; the order is checked per gap and a violation ends the unit in PM_ST_OFFSET_ORDER.
+template <bool EMIT>
+struct Sink {
+  i64 n_ent;     // committed entries
+  i64 n_off;     // committed offsets
+  i64 pend;      // offsets of the open segment
+  i64 wpos;      // deltas_of_gaps' running column
+  i64 last_start;
+  int last_row;
+  pm_entry_t *ent; // EMIT: this unit's first entry slot
+  i64 *off;        // EMIT: whole offsets array
+  i64 off_base;    // EMIT: this unit's first offset index
+  i64 off_cap;     // EMIT: this unit's offset count (exact, from the COUNT pass)
+  i64 ent_cap;
+
+  __device__ __forceinline__ void put(i64 v) {
+    if(EMIT) {
+      i64 at = n_off + pend;
+      if(at < off_cap) { // offsets of a segment that is later dropped may run past the exact slot
+        off[off_base + at] = v;
+      }
+    }
+    ++pend;
+  }
+  __device__ __forceinline__ int gap(int row, R2 g) {
+    int st = PM_ST_OK;
+    if(pend > 0 && (g.s < last_start || (g.s == last_start && last_row == 0 && row == 1))) {
+      st = PM_ST_OFFSET_ORDER;
+    }
+    i64 sign = row ? 1 : -1;
+    put(sign * (g.s - wpos));
+    for(i64 k = rlen(g) - 1; k > 0; --k) {
+      put(sign);
+    }
+    wpos = g.e;
+    last_start = g.s;
+    last_row = row;
+    return st;
+  }
+  __device__ __forceinline__ void drop() {
+    pend = 0;
+    wpos = 0;
+  }
+  __device__ __forceinline__ void commit(R2 ref, R2 qry) {
+    put(0);
+    if(EMIT) {
+      if(n_ent < ent_cap) {
+        pm_entry_t e;
+        e.ref_start = ref.s;
+        e.ref_end = ref.e;
+        e.qry_start = qry.s;
+        e.qry_end = qry.e;
+        e.offset_begin = off_base + n_off;
+        e.n_offsets = pend;
+        ent[n_ent] = e;
+      }
+    }
+    ++n_ent;
+    n_off += pend;
+    drop();
+  }
+};
+
+// a9 + a12: builder and merge state of one unit, all in registers.
+template <bool EMIT>
+struct Merge {
+  PairCursor rows;  // gaps of the two row profiles
+  PairCursor delta; // gaps of the entry's own rows
+  i64 ref_pos, query_pos, column, last_column;
+  // builder (m_delta_builder.hh:9-87)
+  i64 b_ref_start, b_ref_pos, b_query_start, b_query_pos, b_sum0, b_sum1;
+  bool mirrored;
+  i64 query_columns;
+  Sink<EMIT> sink;
+
+  __device__ __forceinline__ void b_restart(i64 r, i64 q) {
+    b_ref_start = b_ref_pos = r;
+    b_query_start = b_query_pos = q;
+    b_sum0 = b_sum1 = 0;
+    sink.drop();
+  }
+  __device__ __forceinline__ int b_add_gap(int row, R2 d) { // m_delta_builder.hh:32-63
+    i64 walked = row ? (b_query_pos - b_query_start) + b_sum1 : (b_ref_pos - b_ref_start) + b_sum0;
+    R2 g{d.s + walked + 1, d.e + walked + 1};
+    if(row) {
+      b_sum1 += rlen(g);
+      b_ref_pos += d.e + 1;
+      b_query_pos += d.s;
+    }
+    else {
+      b_sum0 += rlen(g);
+      b_ref_pos += d.s;
+      b_query_pos += d.e + 1;
+    }
+    return sink.gap(row, g);
+  }
+  __device__ __forceinline__ i64 qcol(i64 pi) const { return mirrored ? query_columns - pi + 1 : pi; }
+  __device__ __forceinline__ void b_finish() { // m_delta_builder.cc:7-22
+    if(b_ref_start != b_ref_pos && b_query_start != b_query_pos) {
+      sink.commit(R2{b_ref_start, b_ref_pos - 1}, R2{qcol(b_query_start), qcol(b_query_pos - 1)});
+    }
+  }
+  __device__ __forceinline__ void consume_delta_piece(int row, R2 d) { // m_translate.cc:220-231
+    if(row) {
+      ref_pos += d.e + 1;
+      query_pos += d.s;
+    }
+    else {
+      ref_pos += d.s;
+      query_pos += d.e + 1;
+    }
+    column += d.e + 1;
+  }
+  __device__ __forceinline__ void close_segment(int row, R2 g) { // m_translate.cc:309-316,436-443
+    b_ref_pos += g.s;
+    b_query_pos += g.s;
+    if(row) { // m_translate.cc:233-244
+      ref_pos += g.s;
+      query_pos += g.e + 1;
+    }
+    else {
+      ref_pos += g.e + 1;
+      query_pos += g.s;
+    }
+    column += g.s;
+    rows.pop(row);
+    b_finish();
+    b_restart(ref_pos, query_pos);
+  }
+  __device__ __forceinline__ R2 rel(int row, R2 g) const {
+    i64 base = row ? query_pos : ref_pos;
+    return R2{g.s - base, g.e - base};
+  }
+  __device__ inline int step() { // m_translate.cc:279-472
+    bool have_p, have_d;
+    int prow = 0, drow = 0;
+    R2 pgap{0, 0}, dgap{0, 0};
+    int st = rows.pick(ref_pos, query_pos, have_p, prow, pgap);
+    if(st) {
+      return st;
+    }
+    st = delta.pick(column, column, have_d, drow, dgap);
+    if(st) {
+      return st;
+    }
+    if(have_p && have_d) {
+      R2 g = rel(prow, pgap);
+      R2 d{dgap.s - column, dgap.e - column};
+      int other = prow ^ 1;
+      bool other_within = rows.has(other) && rel(other, rows.front(other)).s <= d.e; // :246-268
+      if(g.s <= d.s) {
+        close_segment(prow, g);
+      }
+      else if(d.e < g.s || (prow == drow && !other_within)) {
+        st = b_add_gap(drow, d);
+        consume_delta_piece(drow, d);
+        delta.pop(drow);
+      }
+      else {
+        // split the entry's gap in front of the row gap it runs into (:368-386 same row, :395-401 other row)
+        i64 keep = prow == drow ? rel(other, rows.front(other)).s - d.s : g.s - d.s;
+        R2 piece{d.s, d.s + keep - 1};
+        R2 rest{dgap.s + keep, dgap.e};
+        st = b_add_gap(drow, piece);
+        consume_delta_piece(drow, piece);
+        delta.pop(drow);
+        int st2 = delta.push_back(drow, rest);
+        if(!st) {
+          st = st2;
+        }
+      }
+    }
+    else if(have_p) {
+      close_segment(prow, rel(prow, pgap));
+    }
+    else if(have_d) {
+      R2 d{dgap.s - column, dgap.e - column};
+      st = b_add_gap(drow, d);
+      consume_delta_piece(drow, d);
+      delta.pop(drow);
+    }
+    else if(column <= last_column) { // :464-470
+      i64 n = last_column - column + 1;
+      b_ref_pos += n;
+      b_query_pos += n;
+      b_finish();
+    }
+    return st;
+  }
+};
+
+__device__ __forceinline__ PV row_view(const RowsD &rows, int r) {
+  PV p;
+  p.range = rows.range[r];
+  p.len = rows.length[r];
+  i64 o = rows.gap_off[r];
+  p.n = (int)(rows.gap_off[r + 1] - o);
+  p.g = rows.gaps + o;
+  p.pre = rows.pre + o + r;
+  return p;
+}
+
+// One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
+template <bool EMIT>
+__device__ inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r,
+                               Sink<EMIT> &sink) {
+  if(left.bad[l] | right.bad[r] | ds.bad[d]) {
+    return PM_ST_MALFORMED_INPUT;
+  }
+  PV lp = row_view(left, l);
+  PV rp = row_view(right, r);
+  R2 de_ref = ds.ref[d], de_qry = ds.qry[d];
+  R2 ref_seq, query_seq;
+  if(!overlap(de_ref, lp.range, ref_seq) || !overlap(de_qry, rp.range, query_seq)) {
+    return PM_ST_OK; // :636-639
+  }
+  int o = fwd(de_ref) != fwd(lp.range) ? 1 : 0; // :210-217
+  if(o) {
+    de_ref = R2{de_ref.e, de_ref.s};
+    de_qry = R2{de_qry.e, de_qry.s};
+  }
+  // the entry's two rows as profiles over its own columns (:496-506)
+  PV dr, dq;
+  i64 ro = ds.ref_off[d], qo = ds.qry_off[d];
+  dr.range = de_ref;
+  dr.n = (int)(ds.ref_off[d + 1] - ro);
+  dr.g = ds.ref_gaps[o] + ro;
+  dr.pre = ds.ref_pre[o] + ro + d;
+  dr.len = rlen(de_ref) + dr.pre[dr.n];
+  dq.range = de_qry;
+  dq.n = (int)(ds.qry_off[d + 1] - qo);
+  dq.g = ds.qry_gaps[o] + qo;
+  dq.pre = ds.qry_pre[o] + qo + d;
+  dq.len = rlen(de_qry) + dq.pre[dq.n];
+
+  int st;
+  R2 d_ref_cols, d_query_cols, cols;
+  if((st = profile_idx_of_seq_idx(dr, ref_seq.s, d_ref_cols.s))) return st; // :508-511
+  if((st = profile_idx_of_seq_idx(dr, ref_seq.e, d_ref_cols.e))) return st;
+  if((st = profile_idx_of_seq_idx(dq, query_seq.s, d_query_cols.s))) return st;
+  if((st = profile_idx_of_seq_idx(dq, query_seq.e, d_query_cols.e))) return st;
+  if(!overlap(d_ref_cols, d_query_cols, cols)) {
+    return PM_ST_OK; // :513
+  }
+  Merge<EMIT> m;
+  m.sink = sink;
+  R2 d_ref_seq, d_query_seq, l_seq, r_seq;
+  bool none_r, none_q;
+  if((st = subset_profile(dr, cols.s, cols.e, m.delta.v0, d_ref_seq, none_r))) return st;   // :527-529
+  if((st = subset_profile(dq, cols.s, cols.e, m.delta.v1, d_query_seq, none_q))) return st; // :531-533
+  if(none_r || none_q) {
+    return PM_ST_OK; // :535
+  }
+  if((st = subset_seq(lp, d_ref_seq.s, d_ref_seq.e, m.rows.v0, l_seq))) return st;     // :539-541
+  if((st = subset_seq(rp, d_query_seq.s, d_query_seq.e, m.rows.v1, r_seq))) return st; // :543-545
+  if(rlen(d_ref_seq) != rlen(l_seq) || rlen(d_query_seq) != rlen(r_seq)) {
+    return PM_ST_ASSERT_SUB_LENGTHS; // :550-551
+  }
+  bool mirrored = fwd(rp.range) != fwd(dq.range); // :557
+  m.rows.v1.mirror = mirrored;
+  m.rows.v1.L = rp.len;
+  i64 ref_start, query_start;
+  if((st = profile_idx_of_seq_idx(lp, l_seq.s, ref_start))) return st; // :572
+  if(mirrored) {                                                        // :575-581
+    i64 t;
+    if((st = profile_idx_of_seq_idx(rp, r_seq.e, t))) return st;
+    query_start = rp.len - t + 1;
+  }
+  else {
+    if((st = profile_idx_of_seq_idx(rp, r_seq.s, query_start))) return st;
+  }
+  m.rows.at0 = m.rows.at1 = m.delta.at0 = m.delta.at1 = 0;
+  m.rows.held0 = m.rows.held1 = m.delta.held0 = m.delta.held1 = false;
+  m.rows.hold0 = m.rows.hold1 = m.delta.hold0 = m.delta.hold1 = R2{0, 0};
+  m.ref_pos = ref_start;
+  m.query_pos = query_start;
+  m.column = cols.s;
+  m.last_column = cols.e;
+  m.mirrored = mirrored;
+  m.query_columns = rp.len;
+  m.b_restart(ref_start, query_start);
+
+  // :612-618.  Same budget as oracle/pm_oracle.cc: far above any terminating run; every lane reaches it.
+  i64 budget = 4 * (i64)(m.rows.v0.n + m.rows.v1.n + m.delta.v0.n + m.delta.v1.n) + 2 * (cols.e - cols.s + 1) + 64;
+  st = PM_ST_OK;
+  while(!m.rows.done() || !m.delta.done()) {
+    if(budget-- <= 0) {
+      st = PM_ST_STEP_LIMIT;
+      break;
+    }
+    st = m.step();
+    if(st) {
+      break;
+    }
+  }
+  if(!st) {
+    st = m.step();
+  }
+  sink = m.sink;
+  return st;
+}
+
+} // namespace pm

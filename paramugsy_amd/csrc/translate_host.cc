@@ -1,0 +1,619 @@
+// translate_host.cc -- host side of the translate path above the C ABI: file formats in, units out,
+// delta text out.  Mirrors the reference's own host logic for this path:
+//   read_profile_file            lib/profiles_lib/m_profile.cc:15-85      -> parse_profiles
+//   M_delta_stream ctor / next   lib/profiles_lib/m_delta.cc:72-92,148-220 -> parse_delta_file
+//   _split_gaps                  lib/profiles_lib/m_delta.cc:14-68        -> split_offsets
+//   _profile_map_of_dir          lib/m_translate/m_translate.cc:188-207   -> build_side_index
+//   _translate_delta (loops)     lib/m_translate/m_translate.cc:650-709   -> enumerate_units
+//   M_delta_stream_writer::write lib/profiles_lib/m_delta_stream_writer.hh:55-82 -> TextSink
+//   translate + main's 2 lines   lib/m_translate/m_translate.cc:713-730, m_translate_main.cc:35-39 -> pm_translate_files
+// The arithmetic of every work unit runs on the GPU (translate_job.hip); nothing here computes a translation.
+//
+// Parsing is strict where the reference's iostream extraction is lax: a token that is not wholly a decimal
+// integer is a PM_E_PARSE error here (the reference would read its numeric prefix).  The producers of these
+// files (lib/profiles/m_profile.ml:122-135 printf "%d"; MUMmer) never emit such tokens.
+#include <algorithm>
+#include <cerrno>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pm_internal.hpp"
+#include "translate_host.hpp"
+
+namespace pm {
+
+// ------------------------------------------------------------------ small text tools
+
+static bool read_whole_file(const std::string &path, std::string &out) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if(!f) {
+    return false;
+  }
+  std::string buf;
+  char chunk[1 << 16];
+  size_t n;
+  while((n = fread(chunk, 1, sizeof chunk, f)) > 0) {
+    buf.append(chunk, n);
+  }
+  fclose(f);
+  out.swap(buf);
+  return true;
+}
+
+// A cursor over a text buffer that hands out '\n'-terminated lines the way std::getline does
+// (a final unterminated line counts; an empty trailing remainder does not).
+struct Lines {
+  const char *p;
+  const char *end;
+  explicit Lines(const std::string &s) : p(s.data()), end(s.data() + s.size()) {}
+  bool next(const char *&b, const char *&e) {
+    if(p >= end) {
+      return false;
+    }
+    b = p;
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    if(nl) {
+      e = nl;
+      p = nl + 1;
+    }
+    else {
+      e = end;
+      p = end;
+    }
+    return true;
+  }
+};
+
+static inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
+
+static bool next_token(const char *&p, const char *e, const char *&tb, const char *&te) {
+  while(p < e && is_space(*p)) {
+    ++p;
+  }
+  if(p >= e) {
+    return false;
+  }
+  tb = p;
+  while(p < e && !is_space(*p)) {
+    ++p;
+  }
+  te = p;
+  return true;
+}
+
+static bool token_to_i64(const char *b, const char *e, long long &v) {
+  if(b >= e) {
+    return false;
+  }
+  bool neg = false;
+  if(*b == '-' || *b == '+') {
+    neg = *b == '-';
+    ++b;
+  }
+  if(b >= e || e - b > 18) {
+    return false;
+  }
+  long long acc = 0;
+  for(; b < e; ++b) {
+    if(*b < '0' || *b > '9') {
+      return false;
+    }
+    acc = acc * 10 + (*b - '0');
+  }
+  v = neg ? -acc : acc;
+  return true;
+}
+
+static bool next_i64(const char *&p, const char *e, long long &v) {
+  const char *tb, *te;
+  return next_token(p, e, tb, te) && token_to_i64(tb, te, v);
+}
+
+// ------------------------------------------------------------------ profiles
+
+int parse_profiles(const std::string &path, Side &side) {
+  std::string text;
+  side = Side();
+  side.gap_off.push_back(0);
+  if(!read_whole_file(path, text)) {
+    return PM_OK; // the reference's ifstream on a missing file is an empty stream: zero profiles (m_translate.cc:189-195)
+  }
+  Lines lines(text);
+  const char *b, *e;
+  while(lines.next(b, e)) {
+    const char *p = b, *tb, *te;
+    std::string major, minor, seq;
+    long long start, end, length, src_size;
+    if(!next_token(p, e, tb, te)) {
+      return fail(PM_E_PARSE, path + ": empty profile header line");
+    }
+    major.assign(tb, te);
+    if(!next_token(p, e, tb, te)) {
+      return fail(PM_E_PARSE, path + ": short profile header");
+    }
+    minor.assign(tb, te);
+    if(!next_token(p, e, tb, te)) {
+      return fail(PM_E_PARSE, path + ": short profile header");
+    }
+    seq.assign(tb, te);
+    if(!next_i64(p, e, start) || !next_i64(p, e, end) || !next_i64(p, e, length) || !next_i64(p, e, src_size)) {
+      return fail(PM_E_PARSE, path + ": bad profile header numbers");
+    }
+    if(length < 0 || length > 0xffffffffLL || src_size < 0 || src_size > 0xffffffffLL) {
+      return fail(PM_E_PARSE, path + ": p_length/p_src_size outside unsigned int (m_profile.cc:27-28)");
+    }
+    side.major.push_back(major);
+    side.seq_name.push_back(seq);
+    side.start.push_back(start);
+    side.end.push_back(end);
+    side.length.push_back(length);
+    for(;;) {
+      if(!lines.next(b, e)) {
+        break; // m_profile.cc:45: the loop also ends at end of file
+      }
+      if(e - b == 1 && *b == '0') {
+        break;
+      }
+      p = b;
+      long long gs, ge;
+      if(!next_i64(p, e, gs) || !next_i64(p, e, ge)) {
+        return fail(PM_E_PARSE, path + ": bad gap line");
+      }
+      side.gap_start.push_back(gs);
+      side.gap_end.push_back(ge);
+    }
+    side.gap_off.push_back((long long)side.gap_start.size());
+    lines.next(b, e); // the text line, never needed here (lite = true, m_translate.cc:192)
+  }
+  return PM_OK;
+}
+
+// m_translate.cc:188-207: rows grouped by sequence name, each group sorted by forward start.
+void build_side_index(Side &side) {
+  side.by_seq.clear();
+  for(size_t r = 0; r < side.start.size(); ++r) {
+    side.by_seq[side.seq_name[r]].push_back((int)r);
+  }
+  const std::vector<long long> &s = side.start, &e = side.end;
+  for(std::map<std::string, std::vector<int> >::iterator it = side.by_seq.begin(); it != side.by_seq.end(); ++it) {
+    std::sort(it->second.begin(), it->second.end(),
+              [&](int a, int b) { return std::min(s[a], e[a]) < std::min(s[b], e[b]); });
+  }
+}
+
+// ------------------------------------------------------------------ deltas
+
+// m_delta.cc:14-68
+static void split_offsets(const std::vector<long long> &offsets, DeltaTable &t) {
+  size_t k = 0;
+  long long column = 0;
+  while(k < offsets.size()) {
+    long long v = offsets[k];
+    bool in_query = v > 0;
+    long long first = column + (in_query ? v : -v);
+    ++k;
+    long long extra = 0;
+    while(k < offsets.size() && (offsets[k] == 1 || offsets[k] == -1) && ((offsets[k] > 0) == in_query)) {
+      ++extra;
+      ++k;
+    }
+    column = first + extra;
+    if(in_query) {
+      t.qry_gap_start.push_back(first);
+      t.qry_gap_end.push_back(column);
+    }
+    else {
+      t.ref_gap_start.push_back(first);
+      t.ref_gap_end.push_back(column);
+    }
+  }
+}
+
+int parse_delta_file(const std::string &path, DeltaTable &t) {
+  std::string text;
+  if(!read_whole_file(path, text)) {
+    return fail(PM_E_PARSE, path + ": cannot read delta file (the reference throws Delta_stream_parse_error, m_delta.cc:72-92)");
+  }
+  if(t.ref_gap_off.empty()) {
+    t.ref_gap_off.push_back(0);
+    t.qry_gap_off.push_back(0);
+  }
+  Lines lines(text);
+  const char *b, *e, *tb, *te;
+  if(!lines.next(b, e)) {
+    return fail(PM_E_PARSE, path + ": empty delta file");
+  }
+  const char *p = b;
+  if(!next_token(p, e, tb, te) || !next_token(p, e, tb, te)) {
+    return fail(PM_E_PARSE, path + ": first line needs two tokens");
+  }
+  if(!lines.next(b, e)) {
+    return fail(PM_E_PARSE, path + ": missing stream type line");
+  }
+  std::string ref_name, qry_name;
+  std::vector<long long> offsets;
+  while(lines.next(b, e)) {
+    if(b < e && *b == '>') {
+      p = b + 1;
+      long long l1, l2;
+      if(!next_token(p, e, tb, te)) {
+        return fail(PM_E_PARSE, path + ": bad alignment header");
+      }
+      ref_name.assign(tb, te);
+      if(!next_token(p, e, tb, te)) {
+        return fail(PM_E_PARSE, path + ": bad alignment header");
+      }
+      qry_name.assign(tb, te);
+      if(!next_i64(p, e, l1) || !next_i64(p, e, l2)) {
+        return fail(PM_E_PARSE, path + ": bad alignment header lengths");
+      }
+      if(!lines.next(b, e)) {
+        return fail(PM_E_PARSE, path + ": header without alignment line");
+      }
+    }
+    p = b;
+    long long v[7];
+    for(int k = 0; k < 7; ++k) {
+      if(!next_i64(p, e, v[k])) {
+        return fail(PM_E_PARSE, path + ": alignment line needs 7 integers");
+      }
+    }
+    offsets.clear();
+    for(;;) {
+      if(!lines.next(b, e)) {
+        break;
+      }
+      if(e - b == 1 && *b == '0') {
+        break;
+      }
+      p = b;
+      long long o;
+      if(!next_i64(p, e, o) || o < INT_MIN || o > INT_MAX) { // `int gap`, m_delta.cc:189
+        return fail(PM_E_PARSE, path + ": bad offset line");
+      }
+      offsets.push_back(o);
+    }
+    t.ref_name.push_back(ref_name);
+    t.qry_name.push_back(qry_name);
+    t.ref_start.push_back(v[0]);
+    t.ref_end.push_back(v[1]);
+    t.qry_start.push_back(v[2]);
+    t.qry_end.push_back(v[3]);
+    split_offsets(offsets, t);
+    t.ref_gap_off.push_back((long long)t.ref_gap_start.size());
+    t.qry_gap_off.push_back((long long)t.qry_gap_start.size());
+  }
+  return PM_OK;
+}
+
+// ------------------------------------------------------------------ units
+
+// std::lower_bound with "row ends before the entry starts" (m_translate.cc:175-178,682-695)
+static size_t first_candidate(const Side &side, const std::vector<int> &rows, long long rs, long long re) {
+  long long key = std::min(rs, re);
+  std::vector<int>::const_iterator it =
+      std::lower_bound(rows.begin(), rows.end(), key, [&](int r, long long v) { return std::max(side.start[r], side.end[r]) < v; });
+  return (size_t)(it - rows.begin());
+}
+
+static inline bool ranges_overlap(long long as, long long ae, long long bs, long long be) { // m_range.hh:80-94
+  long long s = std::max(std::min(as, ae), std::min(bs, be));
+  long long e = std::min(std::max(as, ae), std::max(bs, be));
+  return e - s >= 0;
+}
+
+// m_translate.cc:666-707, for entries [first, t.size())
+void enumerate_units(const Side &left, const Side &right, const DeltaTable &t, size_t first, UnitList &units) {
+  for(size_t d = first; d < t.ref_start.size(); ++d) {
+    std::map<std::string, std::vector<int> >::const_iterator li = left.by_seq.find(t.ref_name[d]);
+    std::map<std::string, std::vector<int> >::const_iterator ri = right.by_seq.find(t.qry_name[d]);
+    if(li == left.by_seq.end() || ri == right.by_seq.end()) {
+      continue;
+    }
+    const std::vector<int> &lr = li->second, &rr = ri->second;
+    size_t l0 = first_candidate(left, lr, t.ref_start[d], t.ref_end[d]);
+    size_t r0 = first_candidate(right, rr, t.qry_start[d], t.qry_end[d]);
+    for(size_t l = l0; l < lr.size() && ranges_overlap(left.start[lr[l]], left.end[lr[l]], t.ref_start[d], t.ref_end[d]); ++l) {
+      for(size_t r = r0; r < rr.size() && ranges_overlap(right.start[rr[r]], right.end[rr[r]], t.qry_start[d], t.qry_end[d]); ++r) {
+        units.delta.push_back((int)d);
+        units.left.push_back(lr[l]);
+        units.right.push_back(rr[r]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ text out
+
+struct TextSink {
+  FILE *f;
+  std::string buf;
+  std::string last_left, last_right; // M_delta_stream_writer::header_names starts as ("", "")
+  explicit TextSink(FILE *f_) : f(f_) { buf.reserve(1 << 20); }
+  void put_i64(long long v) {
+    char tmp[24];
+    int n = 0;
+    unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+    do {
+      tmp[n++] = (char)('0' + u % 10);
+      u /= 10;
+    } while(u);
+    if(v < 0) {
+      tmp[n++] = '-';
+    }
+    while(n) {
+      buf.push_back(tmp[--n]);
+    }
+  }
+  bool flush() {
+    if(!buf.empty()) {
+      if(fwrite(buf.data(), 1, buf.size(), f) != buf.size()) {
+        return false;
+      }
+      buf.clear();
+    }
+    return true;
+  }
+  bool maybe_flush() { return buf.size() < (1 << 20) - 4096 ? true : flush(); }
+};
+
+int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const std::vector<int32_t> &status,
+                  const std::vector<int64_t> &unit_entry_off, const std::vector<pm_entry_t> &entries, const std::vector<int64_t> &offsets,
+                  std::string &last_left, std::string &last_right) {
+  TextSink out(f);
+  out.last_left = last_left;
+  out.last_right = last_right;
+  for(size_t u = 0; u < units.delta.size(); ++u) {
+    int l = units.left[u], r = units.right[u];
+    for(int64_t k = unit_entry_off[u]; k < unit_entry_off[u + 1]; ++k) {
+      const pm_entry_t &en = entries[(size_t)k];
+      if(left.major[l] != out.last_left || right.major[r] != out.last_right) { // m_delta_stream_writer.hh:62-67
+        out.buf.push_back('>');
+        out.buf += left.major[l];
+        out.buf.push_back(' ');
+        out.buf += right.major[r];
+        out.buf.push_back(' ');
+        out.put_i64(left.length[l]);
+        out.buf.push_back(' ');
+        out.put_i64(right.length[r]);
+        out.buf.push_back('\n');
+        out.last_left = left.major[l];
+        out.last_right = right.major[r];
+      }
+      out.put_i64(en.ref_start);
+      out.buf.push_back(' ');
+      out.put_i64(en.ref_end);
+      out.buf.push_back(' ');
+      out.put_i64(en.qry_start);
+      out.buf.push_back(' ');
+      out.put_i64(en.qry_end);
+      out.buf += " 1 2 3\n"; // m_delta_stream_writer.hh:71
+      for(int64_t o = 0; o < en.n_offsets; ++o) {
+        out.put_i64(offsets[(size_t)(en.offset_begin + o)]);
+        out.buf.push_back('\n');
+        if(!out.maybe_flush()) {
+          return fail(PM_E_IO, "write failed");
+        }
+      }
+    }
+    if(status[u] != PM_ST_OK) {
+      // the reference dies inside this unit: what it had emitted so far is on the stream, nothing after it
+      out.flush();
+      char msg[160];
+      snprintf(msg, sizeof msg, "work unit %zu (delta entry %d, left row %d, right row %d) failed with status %d", u, units.delta[u], l, r,
+               (int)status[u]);
+      return fail(status[u] == PM_ST_MALFORMED_INPUT ? PM_E_MALFORMED : PM_E_UNIT, msg);
+    }
+  }
+  if(!out.flush()) {
+    return fail(PM_E_IO, "write failed");
+  }
+  last_left = out.last_left;
+  last_right = out.last_right;
+  return PM_OK;
+}
+
+static pm_rows_t rows_view(const Side &s) {
+  pm_rows_t r;
+  r.n = (int64_t)s.start.size();
+  r.start = (const int64_t *)s.start.data();
+  r.end = (const int64_t *)s.end.data();
+  r.length = (const int64_t *)s.length.data();
+  r.gap_off = (const int64_t *)s.gap_off.data();
+  r.gap_start = (const int64_t *)s.gap_start.data();
+  r.gap_end = (const int64_t *)s.gap_end.data();
+  return r;
+}
+
+static pm_deltas_t deltas_view(const DeltaTable &t) {
+  pm_deltas_t d;
+  d.n = (int64_t)t.ref_start.size();
+  d.ref_start = (const int64_t *)t.ref_start.data();
+  d.ref_end = (const int64_t *)t.ref_end.data();
+  d.qry_start = (const int64_t *)t.qry_start.data();
+  d.qry_end = (const int64_t *)t.qry_end.data();
+  d.ref_gap_off = (const int64_t *)t.ref_gap_off.data();
+  d.ref_gap_start = (const int64_t *)t.ref_gap_start.data();
+  d.ref_gap_end = (const int64_t *)t.ref_gap_end.data();
+  d.qry_gap_off = (const int64_t *)t.qry_gap_off.data();
+  d.qry_gap_start = (const int64_t *)t.qry_gap_start.data();
+  d.qry_gap_end = (const int64_t *)t.qry_gap_end.data();
+  return d;
+}
+
+// Parse both sides and every delta file of a job and list its work units (host only, no device needed).
+// `parse_rc`/`parse_msg` keep a delta-file parse failure: the entries read before it are still in the table,
+// as the reference would have translated them before throwing (m_translate.cc:722-728).
+int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w) {
+  PM_TRY(parse_profiles(left_dir + "/profiles", w.left));
+  PM_TRY(parse_profiles(right_dir + "/profiles", w.right));
+  build_side_index(w.left);
+  build_side_index(w.right);
+  w.table = DeltaTable();
+  w.table.ref_gap_off.push_back(0);
+  w.table.qry_gap_off.push_back(0);
+  w.units = UnitList();
+  w.parse_rc = PM_OK;
+  w.parse_msg.clear();
+  for(size_t k = 0; k < delta_paths.size(); ++k) {
+    size_t first = w.table.ref_start.size();
+    int rc = parse_delta_file(delta_paths[k], w.table);
+    enumerate_units(w.left, w.right, w.table, first, w.units);
+    if(rc) {
+      w.parse_rc = rc;
+      w.parse_msg = pm_last_error();
+      break;
+    }
+  }
+  return PM_OK;
+}
+
+void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units) {
+  if(left) {
+    *left = rows_view(w.left);
+  }
+  if(right) {
+    *right = rows_view(w.right);
+  }
+  if(deltas) {
+    *deltas = deltas_view(w.table);
+  }
+  if(units) {
+    units->n = (int64_t)w.units.delta.size();
+    units->delta = w.units.delta.data();
+    units->left = w.units.left.data();
+    units->right = w.units.right.data();
+  }
+}
+
+int translate_to_file(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
+                      int device) {
+  Workload w;
+  PM_TRY(load_workload(left_dir, right_dir, delta_paths, w));
+  std::string last_left, last_right;
+  if(!w.units.delta.empty()) {
+    pm_rows_t lv, rv;
+    pm_deltas_t dv;
+    pm_units_t uv;
+    workload_views(w, &lv, &rv, &dv, &uv);
+    pm_job_t *job = nullptr;
+    PM_TRY(pm_job_create(&lv, &rv, &dv, &uv, device, &job));
+    int rc = pm_job_run(job, nullptr);
+    int64_t ne = 0, no = 0;
+    if(!rc) {
+      rc = pm_job_sizes(job, &ne, &no);
+    }
+    std::vector<int32_t> status((size_t)uv.n);
+    std::vector<int64_t> ent_off((size_t)uv.n + 1);
+    std::vector<pm_entry_t> entries((size_t)ne);
+    std::vector<int64_t> offsets((size_t)no);
+    if(!rc) {
+      rc = pm_job_fetch(job, status.data(), ent_off.data(), entries.data(), offsets.data());
+      if(rc == PM_E_UNIT) {
+        rc = PM_OK; // write_results reports the first failing unit after the output that precedes it
+      }
+    }
+    pm_job_destroy(job);
+    if(rc) {
+      return rc;
+    }
+    PM_TRY(write_results(out, w.left, w.right, w.units, status, ent_off, entries, offsets, last_left, last_right));
+  }
+  if(w.parse_rc) {
+    return fail(w.parse_rc, w.parse_msg);
+  }
+  return PM_OK;
+}
+
+} // namespace pm
+
+extern "C" int pm_translate_files(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
+                                  const char *out_path, int device) {
+  if(!left_dir || !right_dir || !out_path || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
+    return pm::fail(PM_E_INVALID, "pm_translate_files: null argument");
+  }
+  int rc = pm::use_device(device);
+  if(rc) {
+    return rc;
+  }
+  std::vector<std::string> paths;
+  for(int k = 0; k < n_paths; ++k) {
+    if(!delta_paths[k]) {
+      return pm::fail(PM_E_INVALID, "pm_translate_files: null path");
+    }
+    paths.push_back(delta_paths[k]);
+  }
+  FILE *f = fopen(out_path, "wb");
+  if(!f) {
+    return pm::fail(PM_E_IO, std::string("cannot open ") + out_path);
+  }
+  // m_translate_main.cc:35-39
+  fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_dir, right_dir);
+  rc = pm::translate_to_file(left_dir, right_dir, paths, f, device);
+  if(fclose(f) != 0 && !rc) {
+    rc = pm::fail(PM_E_IO, "close failed");
+  }
+  return rc;
+}
+
+struct pm_workload {
+  pm::Workload w;
+};
+
+extern "C" int pm_workload_load(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
+                                pm_workload_t **out) {
+  if(!left_dir || !right_dir || !out || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
+    return pm::fail(PM_E_INVALID, "pm_workload_load: null argument");
+  }
+  *out = nullptr;
+  std::vector<std::string> paths;
+  for(int k = 0; k < n_paths; ++k) {
+    if(!delta_paths[k]) {
+      return pm::fail(PM_E_INVALID, "pm_workload_load: null path");
+    }
+    paths.push_back(delta_paths[k]);
+  }
+  pm_workload *h = new pm_workload();
+  int rc = pm::load_workload(left_dir, right_dir, paths, h->w);
+  if(rc) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  if(h->w.parse_rc) {
+    return pm::fail(h->w.parse_rc, h->w.parse_msg); // handle stays valid: the entries read before the failure are in it
+  }
+  return PM_OK;
+}
+
+extern "C" int pm_workload_tables(pm_workload_t *h, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units) {
+  if(!h) {
+    return pm::fail(PM_E_INVALID, "pm_workload_tables: null workload");
+  }
+  pm::workload_views(h->w, left, right, deltas, units);
+  return PM_OK;
+}
+
+extern "C" int pm_workload_row_name(pm_workload_t *h, int side, int64_t row, const char **major_name, const char **seq_name) {
+  if(!h || (side != 0 && side != 1)) {
+    return pm::fail(PM_E_INVALID, "pm_workload_row_name: bad argument");
+  }
+  const pm::Side &s = side ? h->w.right : h->w.left;
+  if(row < 0 || row >= (int64_t)s.major.size()) {
+    return pm::fail(PM_E_INVALID, "pm_workload_row_name: row out of range");
+  }
+  if(major_name) {
+    *major_name = s.major[(size_t)row].c_str();
+  }
+  if(seq_name) {
+    *seq_name = s.seq_name[(size_t)row].c_str();
+  }
+  return PM_OK;
+}
+
+extern "C" void pm_workload_destroy(pm_workload_t *h) { delete h; }

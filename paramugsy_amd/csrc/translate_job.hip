@@ -1,0 +1,615 @@
+// translate_job.hip -- kernels, device-resident batch ("job") and C ABI of the translate path.
+//
+// Data layout in HBM (all int64 unless noted; R2 = {start,end} 16-byte pairs so a gap is one dwordx4 load):
+//   rows   : range[R2 n], length[n], gap_off[n+1], gaps[R2 G], pre[G+n], bad[int n]          (per side)
+//   deltas : ref[R2 n], qry[R2 n], ref_off[n+1], qry_off[n+1],
+//            {ref,qry}_gaps[2][R2 G], {ref,qry}_pre[2][G+n]   (orientation 0 as read, 1 reversed), bad[int n]
+//   units  : delta[int U], left[int U], right[int U]
+//   out    : status[int U], cnt_ent[U+1], cnt_off[U+1] -> exclusive scans ent_off[U+1], off_off[U+1],
+//            entries[pm_entry_t E], offsets[O]
+// Kernels: prepare_rows / prepare_deltas (once per job), translate_count, 2x rocprim exclusive_scan,
+// translate_emit.  One lane per unit (the merge is a sequential state machine; the batch supplies the
+// parallelism), 64-lane workgroups so a 100 k-unit batch spreads over all 256 CUs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pm_internal.hpp"
+#include "translate_device.hpp"
+
+namespace pm {
+
+// ------------------------------------------------------------------ kernels
+
+// One thread per row: interleave the gap list, build the prefix table, validate ordering.
+__global__ void prepare_rows_kernel(i64 n, const i64 *start, const i64 *end, const i64 *gap_off, const i64 *gs, const i64 *ge,
+                                    R2 *range, R2 *gaps, i64 *pre, int *bad) {
+  i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(r >= n) {
+    return;
+  }
+  range[r] = R2{start[r], end[r]};
+  i64 o = gap_off[r], m = gap_off[r + 1] - o;
+  i64 *p = pre + o + r;
+  i64 acc = 0, prev_end = 0;
+  int flag = 0;
+  for(i64 k = 0; k < m; ++k) {
+    R2 g{gs[o + k], ge[o + k]};
+    if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
+      flag = 1;
+    }
+    prev_end = g.e;
+    gaps[o + k] = g;
+    p[k] = acc;
+    acc += rlen(g);
+  }
+  p[m] = acc;
+  bad[r] = flag;
+}
+
+// One thread per (entry, strand): both orientations of one gap list (m_delta.cc:94-146 for the reversed one).
+__global__ void prepare_deltas_kernel(i64 n, const i64 *rs, const i64 *re, const i64 *gap_off, const i64 *gs, const i64 *ge,
+                                      R2 *range, R2 *g_fwd, i64 *pre_fwd, R2 *g_rev, i64 *pre_rev, int *bad) {
+  i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(d >= n) {
+    return;
+  }
+  R2 rg{rs[d], re[d]};
+  range[d] = rg;
+  i64 o = gap_off[d], m = gap_off[d + 1] - o;
+  i64 *pf = pre_fwd + o + d;
+  i64 *pr = pre_rev + o + d;
+  i64 acc = 0, prev_end = 0;
+  int flag = 0;
+  for(i64 k = 0; k < m; ++k) {
+    R2 g{gs[o + k], ge[o + k]};
+    if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
+      flag = 1;
+    }
+    prev_end = g.e;
+    g_fwd[o + k] = g;
+    pf[k] = acc;
+    acc += rlen(g);
+  }
+  pf[m] = acc;
+  i64 columns = rlen(rg) + acc;
+  i64 racc = 0;
+  for(i64 k = 0; k < m; ++k) {
+    R2 g{gs[o + (m - 1 - k)], ge[o + (m - 1 - k)]};
+    R2 mg{columns - g.e + 1, columns - g.s + 1};
+    g_rev[o + k] = mg;
+    pr[k] = racc;
+    racc += rlen(mg);
+  }
+  pr[m] = racc;
+  if(flag) {
+    atomicOr(bad + d, 1);
+  }
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(64)
+translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
+                 int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off, const i64 *off_off, pm_entry_t *entries,
+                 i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow) {
+  i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(EMIT) {
+    if(ent_off[n_units] > ent_cap || off_off[n_units] > off_cap) { // uniform: buffers sized by an older run
+      if(u == 0) {
+        *overflow = 1;
+      }
+      return;
+    }
+  }
+  if(u >= n_units) {
+    return;
+  }
+  Sink<EMIT> sink;
+  sink.n_ent = sink.n_off = sink.pend = sink.wpos = sink.last_start = 0;
+  sink.last_row = 0;
+  sink.ent = nullptr;
+  sink.off = nullptr;
+  sink.off_base = sink.off_cap = sink.ent_cap = 0;
+  if(EMIT) {
+    sink.ent = entries + ent_off[u];
+    sink.ent_cap = ent_off[u + 1] - ent_off[u];
+    sink.off = offsets;
+    sink.off_base = off_off[u];
+    sink.off_cap = off_off[u + 1] - off_off[u];
+  }
+  int st = run_unit<EMIT>(left, right, ds, u_delta[u], u_left[u], u_right[u], sink);
+  if(!EMIT) {
+    status[u] = st;
+    cnt_ent[u] = sink.n_ent;
+    cnt_off[u] = sink.n_off;
+  }
+}
+
+__global__ void p2s_batch_kernel(RowsD rows, i64 n, const int *row, const i64 *si, i64 *out, int *status) {
+  i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(q >= n) {
+    return;
+  }
+  int r = row[q];
+  if(rows.bad[r]) {
+    status[q] = PM_ST_MALFORMED_INPUT;
+    out[q] = 0;
+    return;
+  }
+  i64 v = 0;
+  status[q] = profile_idx_of_seq_idx(row_view(rows, r), si[q], v);
+  out[q] = v;
+}
+
+__global__ void s2p_batch_kernel(RowsD rows, i64 n, const int *row, const i64 *pi, i64 *out, int *status) {
+  i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(q >= n) {
+    return;
+  }
+  int r = row[q];
+  if(rows.bad[r]) {
+    status[q] = PM_ST_MALFORMED_INPUT;
+    out[q] = 0;
+    return;
+  }
+  i64 v = 0;
+  bool none = false;
+  int st = seq_idx_of_profile_idx(row_view(rows, r), pi[q], v, none);
+  status[q] = st ? st : (none ? PM_ST_IS_NONE : PM_ST_OK);
+  out[q] = v;
+}
+
+// ------------------------------------------------------------------ device-resident tables
+
+struct RowsStore {
+  DevBuf range, length, gap_off, gaps, pre, bad, raw_s, raw_e, raw_gs, raw_ge;
+  i64 n = 0, G = 0;
+  RowsD view() const {
+    RowsD d;
+    d.n = n;
+    d.range = (const R2 *)range.p;
+    d.length = (const i64 *)length.p;
+    d.gap_off = (const i64 *)gap_off.p;
+    d.gaps = (const R2 *)gaps.p;
+    d.pre = (const i64 *)pre.p;
+    d.bad = (const int *)bad.p;
+    return d;
+  }
+};
+
+static int check_csr(const int64_t *off, int64_t n, const char *what) {
+  if(n < 0) {
+    return fail(PM_E_INVALID, std::string(what) + ": negative count");
+  }
+  if(!off) {
+    return fail(PM_E_INVALID, std::string(what) + ": null offsets");
+  }
+  if(off[0] != 0) {
+    return fail(PM_E_INVALID, std::string(what) + ": offsets must start at 0");
+  }
+  for(int64_t k = 0; k < n; ++k) {
+    if(off[k + 1] < off[k]) {
+      return fail(PM_E_INVALID, std::string(what) + ": offsets not ascending");
+    }
+    if(off[k + 1] - off[k] > 0x7fffffff) {
+      return fail(PM_E_INVALID, std::string(what) + ": more than 2^31 gaps in one list");
+    }
+  }
+  return PM_OK;
+}
+
+static int upload_rows(const pm_rows_t *h, RowsStore &s, hipStream_t stream) {
+  if(!h || h->n < 0 || (h->n > 0 && (!h->start || !h->end || !h->length))) {
+    return fail(PM_E_INVALID, "rows: null array");
+  }
+  int rc = check_csr(h->gap_off, h->n, "rows.gap_off");
+  if(rc) {
+    return rc;
+  }
+  s.n = h->n;
+  s.G = h->gap_off[h->n];
+  if(s.G > 0 && (!h->gap_start || !h->gap_end)) {
+    return fail(PM_E_INVALID, "rows: null gap arrays");
+  }
+  size_t n8 = (size_t)s.n * 8, g8 = (size_t)s.G * 8;
+  PM_TRY(s.range.alloc(n8 * 2));
+  PM_TRY(s.length.upload(h->length, n8, stream));
+  PM_TRY(s.gap_off.upload(h->gap_off, n8 + 8, stream));
+  PM_TRY(s.gaps.alloc(g8 * 2));
+  PM_TRY(s.pre.alloc(g8 + n8));
+  PM_TRY(s.bad.alloc((size_t)s.n * 4));
+  PM_TRY(s.raw_s.upload(h->start, n8, stream));
+  PM_TRY(s.raw_e.upload(h->end, n8, stream));
+  PM_TRY(s.raw_gs.upload(h->gap_start, g8, stream));
+  PM_TRY(s.raw_ge.upload(h->gap_end, g8, stream));
+  if(s.n > 0) {
+    unsigned blocks = (unsigned)((s.n + 255) / 256);
+    prepare_rows_kernel<<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw_s.p, (const i64 *)s.raw_e.p, (const i64 *)s.gap_off.p,
+                                                    (const i64 *)s.raw_gs.p, (const i64 *)s.raw_ge.p, (R2 *)s.range.p, (R2 *)s.gaps.p,
+                                                    (i64 *)s.pre.p, (int *)s.bad.p);
+    PM_HIP(hipGetLastError());
+  }
+  return PM_OK;
+}
+
+struct DeltasStore {
+  DevBuf ref, qry, ref_off, qry_off, bad;
+  DevBuf ref_gaps[2], ref_pre[2], qry_gaps[2], qry_pre[2];
+  DevBuf raw[8];
+  i64 n = 0, Gr = 0, Gq = 0;
+  DeltasD view() const {
+    DeltasD d;
+    d.n = n;
+    d.ref = (const R2 *)ref.p;
+    d.qry = (const R2 *)qry.p;
+    d.ref_off = (const i64 *)ref_off.p;
+    d.qry_off = (const i64 *)qry_off.p;
+    for(int o = 0; o < 2; ++o) {
+      d.ref_gaps[o] = (const R2 *)ref_gaps[o].p;
+      d.ref_pre[o] = (const i64 *)ref_pre[o].p;
+      d.qry_gaps[o] = (const R2 *)qry_gaps[o].p;
+      d.qry_pre[o] = (const i64 *)qry_pre[o].p;
+    }
+    d.bad = (const int *)bad.p;
+    return d;
+  }
+};
+
+static int upload_deltas(const pm_deltas_t *h, DeltasStore &s, hipStream_t stream) {
+  if(!h || h->n < 0 || (h->n > 0 && (!h->ref_start || !h->ref_end || !h->qry_start || !h->qry_end))) {
+    return fail(PM_E_INVALID, "deltas: null array");
+  }
+  int rc = check_csr(h->ref_gap_off, h->n, "deltas.ref_gap_off");
+  if(rc) {
+    return rc;
+  }
+  rc = check_csr(h->qry_gap_off, h->n, "deltas.qry_gap_off");
+  if(rc) {
+    return rc;
+  }
+  s.n = h->n;
+  s.Gr = h->ref_gap_off[h->n];
+  s.Gq = h->qry_gap_off[h->n];
+  if((s.Gr > 0 && (!h->ref_gap_start || !h->ref_gap_end)) || (s.Gq > 0 && (!h->qry_gap_start || !h->qry_gap_end))) {
+    return fail(PM_E_INVALID, "deltas: null gap arrays");
+  }
+  size_t n8 = (size_t)s.n * 8;
+  PM_TRY(s.ref.alloc(n8 * 2));
+  PM_TRY(s.qry.alloc(n8 * 2));
+  PM_TRY(s.ref_off.upload(h->ref_gap_off, n8 + 8, stream));
+  PM_TRY(s.qry_off.upload(h->qry_gap_off, n8 + 8, stream));
+  PM_TRY(s.bad.alloc((size_t)s.n * 4));
+  PM_HIP(hipMemsetAsync(s.bad.p, 0, (size_t)s.n * 4, stream));
+  for(int o = 0; o < 2; ++o) {
+    PM_TRY(s.ref_gaps[o].alloc((size_t)s.Gr * 16));
+    PM_TRY(s.ref_pre[o].alloc((size_t)s.Gr * 8 + n8));
+    PM_TRY(s.qry_gaps[o].alloc((size_t)s.Gq * 16));
+    PM_TRY(s.qry_pre[o].alloc((size_t)s.Gq * 8 + n8));
+  }
+  PM_TRY(s.raw[0].upload(h->ref_start, n8, stream));
+  PM_TRY(s.raw[1].upload(h->ref_end, n8, stream));
+  PM_TRY(s.raw[2].upload(h->qry_start, n8, stream));
+  PM_TRY(s.raw[3].upload(h->qry_end, n8, stream));
+  PM_TRY(s.raw[4].upload(h->ref_gap_start, (size_t)s.Gr * 8, stream));
+  PM_TRY(s.raw[5].upload(h->ref_gap_end, (size_t)s.Gr * 8, stream));
+  PM_TRY(s.raw[6].upload(h->qry_gap_start, (size_t)s.Gq * 8, stream));
+  PM_TRY(s.raw[7].upload(h->qry_gap_end, (size_t)s.Gq * 8, stream));
+  if(s.n > 0) {
+    unsigned blocks = (unsigned)((s.n + 255) / 256);
+    prepare_deltas_kernel<<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw[0].p, (const i64 *)s.raw[1].p, (const i64 *)s.ref_off.p,
+                                                      (const i64 *)s.raw[4].p, (const i64 *)s.raw[5].p, (R2 *)s.ref.p, (R2 *)s.ref_gaps[0].p,
+                                                      (i64 *)s.ref_pre[0].p, (R2 *)s.ref_gaps[1].p, (i64 *)s.ref_pre[1].p, (int *)s.bad.p);
+    prepare_deltas_kernel<<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw[2].p, (const i64 *)s.raw[3].p, (const i64 *)s.qry_off.p,
+                                                      (const i64 *)s.raw[6].p, (const i64 *)s.raw[7].p, (R2 *)s.qry.p, (R2 *)s.qry_gaps[0].p,
+                                                      (i64 *)s.qry_pre[0].p, (R2 *)s.qry_gaps[1].p, (i64 *)s.qry_pre[1].p, (int *)s.bad.p);
+    PM_HIP(hipGetLastError());
+  }
+  return PM_OK;
+}
+
+} // namespace pm
+
+using namespace pm;
+
+struct pm_job {
+  int device = 0;
+  RowsStore left, right;
+  DeltasStore deltas;
+  DevBuf u_delta, u_left, u_right;
+  i64 n_units = 0;
+  DevBuf status, cnt_ent, cnt_off, ent_off, off_off, entries, offsets, overflow, scan_tmp;
+  size_t scan_tmp_bytes = 0;
+  i64 ent_cap = 0, off_cap = 0;
+  i64 n_entries = 0, n_offsets = 0;
+  i64 input_bytes = 0;
+  hipStream_t last_stream = nullptr;
+  bool ran = false;
+};
+
+static int job_launch_count_scan(pm_job *j, hipStream_t stream) {
+  i64 U = j->n_units;
+  unsigned blocks = (unsigned)((U + 63) / 64);
+  if(U > 0) {
+    translate_kernel<false><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
+                                                       (const int *)j->u_left.p, (const int *)j->u_right.p, (int *)j->status.p,
+                                                       (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                                                       nullptr);
+    PM_HIP(hipGetLastError());
+  }
+  size_t tmp = j->scan_tmp_bytes;
+  PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off.p, (i64)0, (size_t)(U + 1),
+                                 rocprim::plus<i64>(), stream));
+  tmp = j->scan_tmp_bytes;
+  PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_off.p, (i64 *)j->off_off.p, (i64)0, (size_t)(U + 1),
+                                 rocprim::plus<i64>(), stream));
+  return PM_OK;
+}
+
+static int job_launch_emit(pm_job *j, hipStream_t stream) {
+  i64 U = j->n_units;
+  unsigned blocks = (unsigned)((U + 63) / 64);
+  if(U > 0) {
+    translate_kernel<true><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
+                                                      (const int *)j->u_left.p, (const int *)j->u_right.p, nullptr, nullptr, nullptr,
+                                                      (const i64 *)j->ent_off.p, (const i64 *)j->off_off.p, (pm_entry_t *)j->entries.p,
+                                                      (i64 *)j->offsets.p, j->ent_cap, j->off_cap, (int *)j->overflow.p);
+    PM_HIP(hipGetLastError());
+  }
+  return PM_OK;
+}
+
+static int job_read_totals(pm_job *j, hipStream_t stream) {
+  i64 tot[2] = {0, 0};
+  PM_HIP(hipMemcpyAsync(&tot[0], (i64 *)j->ent_off.p + j->n_units, 8, hipMemcpyDeviceToHost, stream));
+  PM_HIP(hipMemcpyAsync(&tot[1], (i64 *)j->off_off.p + j->n_units, 8, hipMemcpyDeviceToHost, stream));
+  PM_HIP(hipStreamSynchronize(stream));
+  j->n_entries = tot[0];
+  j->n_offsets = tot[1];
+  return PM_OK;
+}
+
+extern "C" {
+
+int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units, int device,
+                  pm_job_t **out) {
+  if(!out) {
+    return fail(PM_E_INVALID, "pm_job_create: null out");
+  }
+  *out = nullptr;
+  if(!units || units->n < 0 || (units->n > 0 && (!units->delta || !units->left || !units->right))) {
+    return fail(PM_E_INVALID, "pm_job_create: bad units");
+  }
+  int rc = use_device(device);
+  if(rc) {
+    return rc;
+  }
+  if(!left || !right || !deltas) {
+    return fail(PM_E_INVALID, "pm_job_create: null table");
+  }
+  for(int64_t u = 0; u < units->n; ++u) {
+    if(units->delta[u] < 0 || units->delta[u] >= deltas->n || units->left[u] < 0 || units->left[u] >= left->n || units->right[u] < 0 ||
+       units->right[u] >= right->n) {
+      return fail(PM_E_INVALID, "pm_job_create: unit index out of range");
+    }
+  }
+  pm_job *j = new(std::nothrow) pm_job();
+  if(!j) {
+    return fail(PM_E_INVALID, "out of host memory");
+  }
+  j->device = device;
+  hipStream_t stream = nullptr;
+#define JTRY(x)        \
+  do {                 \
+    int rc_ = (x);     \
+    if(rc_) {          \
+      pm_job_destroy(j); \
+      return rc_;      \
+    }                  \
+  } while(0)
+  JTRY(upload_rows(left, j->left, stream));
+  JTRY(upload_rows(right, j->right, stream));
+  JTRY(upload_deltas(deltas, j->deltas, stream));
+  i64 U = j->n_units = units->n;
+  JTRY(j->u_delta.upload(units->delta, (size_t)U * 4, stream));
+  JTRY(j->u_left.upload(units->left, (size_t)U * 4, stream));
+  JTRY(j->u_right.upload(units->right, (size_t)U * 4, stream));
+  JTRY(j->status.alloc((size_t)U * 4));
+  JTRY(j->cnt_ent.alloc((size_t)(U + 1) * 8));
+  JTRY(j->cnt_off.alloc((size_t)(U + 1) * 8));
+  JTRY(j->ent_off.alloc((size_t)(U + 1) * 8));
+  JTRY(j->off_off.alloc((size_t)(U + 1) * 8));
+  JTRY(j->overflow.alloc(4));
+  if(hipMemsetAsync(j->cnt_ent.p, 0, (size_t)(U + 1) * 8, stream) != hipSuccess ||
+     hipMemsetAsync(j->cnt_off.p, 0, (size_t)(U + 1) * 8, stream) != hipSuccess ||
+     hipMemsetAsync(j->overflow.p, 0, 4, stream) != hipSuccess) {
+    pm_job_destroy(j);
+    return fail(PM_E_HIP, "hipMemsetAsync failed");
+  }
+  size_t tmp = 0;
+  if(rocprim::exclusive_scan(nullptr, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off.p, (i64)0, (size_t)(U + 1), rocprim::plus<i64>(),
+                             stream) != hipSuccess) {
+    pm_job_destroy(j);
+    return fail(PM_E_HIP, "rocprim scan sizing failed");
+  }
+  j->scan_tmp_bytes = tmp;
+  JTRY(j->scan_tmp.alloc(tmp ? tmp : 8));
+  // Size the outputs once: the inputs of a job never change, so neither do its output sizes.
+  JTRY(job_launch_count_scan(j, stream));
+  JTRY(job_read_totals(j, stream));
+  j->ent_cap = j->n_entries;
+  j->off_cap = j->n_offsets;
+  JTRY(j->entries.alloc((size_t)j->ent_cap * sizeof(pm_entry_t)));
+  JTRY(j->offsets.alloc((size_t)j->off_cap * 8));
+  // free the SoA staging copies
+  j->left.raw_s.release();
+  j->left.raw_e.release();
+  j->left.raw_gs.release();
+  j->left.raw_ge.release();
+  j->right.raw_s.release();
+  j->right.raw_e.release();
+  j->right.raw_gs.release();
+  j->right.raw_ge.release();
+  for(int k = 0; k < 8; ++k) {
+    j->deltas.raw[k].release();
+  }
+  // algorithmic input bytes: the tables the unit kernels can touch + unit triples
+  j->input_bytes = (j->left.n + j->right.n) * (16 + 8 + 8 + 4) + (j->left.G + j->right.G) * (16 + 8) +
+                   j->deltas.n * (32 + 16 + 4) + (j->deltas.Gr + j->deltas.Gq) * (16 + 8) + U * 12;
+#undef JTRY
+  *out = j;
+  return PM_OK;
+}
+
+int pm_job_run(pm_job_t *j, void *hip_stream) {
+  if(!j) {
+    return fail(PM_E_INVALID, "pm_job_run: null job");
+  }
+  int rc = use_device(j->device);
+  if(rc) {
+    return rc;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  PM_TRY(job_launch_count_scan(j, stream));
+  PM_TRY(job_launch_emit(j, stream));
+  j->last_stream = stream;
+  j->ran = true;
+  return PM_OK;
+}
+
+int pm_job_sizes(pm_job_t *j, int64_t *n_entries, int64_t *n_offsets) {
+  if(!j) {
+    return fail(PM_E_INVALID, "pm_job_sizes: null job");
+  }
+  int rc = use_device(j->device);
+  if(rc) {
+    return rc;
+  }
+  if(!j->ran) {
+    return fail(PM_E_INVALID, "pm_job_sizes: pm_job_run has not been called");
+  }
+  PM_TRY(job_read_totals(j, j->last_stream));
+  int ovf = 0;
+  PM_HIP(hipMemcpy(&ovf, j->overflow.p, 4, hipMemcpyDeviceToHost));
+  if(ovf || j->n_entries > j->ent_cap || j->n_offsets > j->off_cap) {
+    return fail(PM_E_HIP, "output buffers smaller than this run's output (inputs changed under the job?)");
+  }
+  if(n_entries) {
+    *n_entries = j->n_entries;
+  }
+  if(n_offsets) {
+    *n_offsets = j->n_offsets;
+  }
+  return PM_OK;
+}
+
+int pm_job_fetch(pm_job_t *j, int32_t *unit_status, int64_t *unit_entry_off, pm_entry_t *entries, int64_t *offsets) {
+  int64_t ne = 0, no = 0;
+  int rc = pm_job_sizes(j, &ne, &no);
+  if(rc) {
+    return rc;
+  }
+  i64 U = j->n_units;
+  std::vector<int32_t> st_local;
+  int32_t *st = unit_status;
+  if(!st) {
+    st_local.resize((size_t)U);
+    st = st_local.data();
+  }
+  if(U > 0) {
+    PM_HIP(hipMemcpy(st, j->status.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+  }
+  if(unit_entry_off) {
+    PM_HIP(hipMemcpy(unit_entry_off, j->ent_off.p, (size_t)(U + 1) * 8, hipMemcpyDeviceToHost));
+  }
+  if(entries && ne > 0) {
+    PM_HIP(hipMemcpy(entries, j->entries.p, (size_t)ne * sizeof(pm_entry_t), hipMemcpyDeviceToHost));
+  }
+  if(offsets && no > 0) {
+    PM_HIP(hipMemcpy(offsets, j->offsets.p, (size_t)no * 8, hipMemcpyDeviceToHost));
+  }
+  for(i64 u = 0; u < U; ++u) {
+    if(st[u] != PM_ST_OK) {
+      char msg[128];
+      snprintf(msg, sizeof msg, "unit %lld ended with status %d", (long long)u, (int)st[u]);
+      return fail(PM_E_UNIT, msg);
+    }
+  }
+  return PM_OK;
+}
+
+int pm_job_algorithmic_bytes(pm_job_t *j, int64_t *bytes) {
+  if(!j || !bytes) {
+    return fail(PM_E_INVALID, "pm_job_algorithmic_bytes: null argument");
+  }
+  // inputs once + per unit status/counts/offsets + entries + offsets
+  *bytes = j->input_bytes + j->n_units * (4 + 16 + 16) + j->ent_cap * (int64_t)sizeof(pm_entry_t) + j->off_cap * 8;
+  return PM_OK;
+}
+
+void pm_job_destroy(pm_job_t *j) {
+  if(!j) {
+    return;
+  }
+  (void)hipSetDevice(j->device);
+  delete j;
+}
+
+static int rows_batch(const pm_rows_t *rows, int64_t n, const int32_t *row, const int64_t *in, int64_t *out, int32_t *status, int device,
+                      bool p2s) {
+  if(n < 0 || (n > 0 && (!row || !in || !out || !status))) {
+    return fail(PM_E_INVALID, "rows batch: null array");
+  }
+  int rc = use_device(device);
+  if(rc) {
+    return rc;
+  }
+  if(!rows) {
+    return fail(PM_E_INVALID, "rows batch: null rows");
+  }
+  for(int64_t q = 0; q < n; ++q) {
+    if(row[q] < 0 || row[q] >= rows->n) {
+      return fail(PM_E_INVALID, "rows batch: row index out of range");
+    }
+  }
+  RowsStore s;
+  hipStream_t stream = nullptr;
+  PM_TRY(upload_rows(rows, s, stream));
+  DevBuf d_row, d_in, d_out, d_st;
+  PM_TRY(d_row.upload(row, (size_t)n * 4, stream));
+  PM_TRY(d_in.upload(in, (size_t)n * 8, stream));
+  PM_TRY(d_out.alloc((size_t)n * 8));
+  PM_TRY(d_st.alloc((size_t)n * 4));
+  if(n > 0) {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if(p2s) {
+      p2s_batch_kernel<<<blocks, 256, 0, stream>>>(s.view(), n, (const int *)d_row.p, (const i64 *)d_in.p, (i64 *)d_out.p, (int *)d_st.p);
+    }
+    else {
+      s2p_batch_kernel<<<blocks, 256, 0, stream>>>(s.view(), n, (const int *)d_row.p, (const i64 *)d_in.p, (i64 *)d_out.p, (int *)d_st.p);
+    }
+    PM_HIP(hipGetLastError());
+    PM_HIP(hipMemcpy(out, d_out.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    PM_HIP(hipMemcpy(status, d_st.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  return PM_OK;
+}
+
+int pm_rows_profile_idx_of_seq_idx_batch(const pm_rows_t *rows, int64_t n, const int32_t *row, const int64_t *seq_idx,
+                                         int64_t *profile_idx, int32_t *status, int device) {
+  return rows_batch(rows, n, row, seq_idx, profile_idx, status, device, true);
+}
+
+int pm_rows_seq_idx_of_profile_idx_batch(const pm_rows_t *rows, int64_t n, const int32_t *row, const int64_t *profile_idx,
+                                         int64_t *seq_idx, int32_t *status, int device) {
+  return rows_batch(rows, n, row, profile_idx, seq_idx, status, device, false);
+}
+
+} // extern "C"

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures under tests/golden/ from the upstream reference ITSELF.
+
+Needs oracle/_ref/ (the reference's own C++ compiled from /root/reference by `make -C oracle ref`), so it
+only runs in the dev container; the GPU box and CI use the committed outputs.  Fixtures are data only:
+seeded synthetic inputs (paramugsy_amd/synth.py) and the bytes the reference binaries printed for them.
+
+  translate_<name>/   profiles-l/profiles, profiles-r/profiles, nucmer_*.delta, nucmer.list  (inputs)
+                      expected.delta   = oracle/_ref/m_translate profiles-l profiles-r nucmer.list expected.delta
+                                         (run with cwd = the case directory so the first line is stable)
+  sort_<name>.delta / sort_<name>.expected      = oracle/_ref/m_sort_delta < in > expected
+  maf_<name>.maf / maf_<name>.expected          = oracle/_ref/maf_analyzer in > expected
+  units_cmds.txt / units_expected.txt           = oracle/_ref/ref_units < cmds > expected
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from paramugsy_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+TRANSLATE_CASES = {
+    # name: (seed, kwargs)
+    "typical": (101, dict(n_left=2, n_right=2, genome_len=20000, n_blocks=25, entries_per_delta=25, n_deltas=2)),
+    "gappy": (202, dict(n_left=2, n_right=3, genome_len=12000, n_blocks=30, mean_cols=200, gap_rate=0.05, mean_gap=6.0,
+                        indel_rate=0.02, mean_indel=4.0, adjacent_prob=0.1, edge_gap_prob=0.5, entries_per_delta=30, n_deltas=1)),
+    "reverse": (303, dict(n_left=2, n_right=2, genome_len=8000, n_blocks=30, mean_cols=120, gap_rate=0.08, indel_rate=0.05,
+                          mean_len=400, entries_per_delta=40, rev_prob=0.5, delta_rev_prob=0.5, spacing=5, n_deltas=1)),
+    "tiny_blocks": (1007, dict(n_left=2, n_right=2, genome_len=3000, n_blocks=150, mean_cols=8, gap_rate=0.1, mean_gap=3.0,
+                               indel_rate=0.05, mean_indel=8.0, mean_len=150, entries_per_delta=40, spacing=3,
+                               edge_gap_prob=0.4, adjacent_prob=0.15, delta_rev_prob=0.4, n_deltas=1)),
+}
+
+
+def relativise(case_dir: str, w: synth.Workload) -> None:
+    """nucmer.list must hold paths relative to the case directory (the tests run with cwd = case dir)."""
+    with open(w.list_path, "w") as f:
+        for p in w.delta_paths:
+            f.write(os.path.basename(p) + "\n")
+
+
+def make_translate_cases() -> None:
+    for name, (seed, kw) in TRANSLATE_CASES.items():
+        case = os.path.join(HERE, "translate_" + name)
+        shutil.rmtree(case, ignore_errors=True)
+        w = synth.make_workload(case, seed, **kw)
+        relativise(case, w)
+        r = subprocess.run([os.path.join(REF, "m_translate"), "profiles-l", "profiles-r", "nucmer.list", "expected.delta"], cwd=case)
+        assert r.returncode == 0, (name, r.returncode)
+        print("translate_%s: %d bytes expected" % (name, os.path.getsize(os.path.join(case, "expected.delta"))))
+    # empty / degenerate job: no delta files at all, and a side with no rows
+    case = os.path.join(HERE, "translate_empty")
+    shutil.rmtree(case, ignore_errors=True)
+    os.makedirs(os.path.join(case, "profiles-l"))
+    os.makedirs(os.path.join(case, "profiles-r"))
+    open(os.path.join(case, "profiles-l", "profiles"), "w").close()
+    rng = np.random.default_rng(7)
+    synth.write_side(os.path.join(case, "profiles-r"), synth.gen_side(rng, ["R0.chr"], 2000, 3), "r")
+    with open(os.path.join(case, "nucmer_0.delta"), "w") as f:
+        f.write(synth.gen_delta_text(rng, ["L0.chr"], ["R0.chr"], 2000, 2000, 5, mean_len=300))
+    with open(os.path.join(case, "nucmer.list"), "w") as f:
+        f.write("nucmer_0.delta\n")
+    r = subprocess.run([os.path.join(REF, "m_translate"), "profiles-l", "profiles-r", "nucmer.list", "expected.delta"], cwd=case)
+    assert r.returncode == 0
+    print("translate_empty: %d bytes expected" % os.path.getsize(os.path.join(case, "expected.delta")))
+
+
+def make_sort_cases() -> None:
+    rng = np.random.default_rng(404)
+    text = synth.gen_delta_text(rng, ["b.chr", "a.chr", "c.chr"], ["y.chr", "x.chr"], 50000, 50000, 60, mean_len=800, group=3)
+    # the reference's one in-tree known-answer vector (lib/profiles_lib/m_delta.cc:43-49) as an extra entry
+    text += ">a.chr x.chr 50000 50000\n1 2000 1 2000 0 0 0\n106\n-6\n1797\n-9\n-9\n-1\n7\n1\n0\n"
+    for name, body in (("mixed", text), ("headers_only", "/s/ref /s/qry\nNUCMER\n")):
+        src = os.path.join(HERE, "sort_%s.delta" % name)
+        with open(src, "w") as f:
+            f.write(body)
+        with open(src) as fin, open(os.path.join(HERE, "sort_%s.expected" % name), "w") as fout:
+            r = subprocess.run([os.path.join(REF, "m_sort_delta")], stdin=fin, stdout=fout)
+        assert r.returncode == 0
+        print("sort_%s ok" % name)
+
+
+def make_maf_cases() -> None:
+    rng = np.random.default_rng(505)
+    blocks = synth.gen_side(rng, ["A", "B", "C"], 5000, 20, mean_cols=150, spacing=30)
+    cases = {"synthetic": synth.side_to_maf_text(blocks)}
+    # adjacent blocks (spacing 0..1) so that the merge branches of _insert are taken, shuffled block order
+    blocks2 = synth.gen_side(rng, ["A", "B"], 3000, 25, mean_cols=60, spacing=2, gap_rate=0.0, edge_gap_prob=0.0)
+    order = rng.permutation(len(blocks2))
+    cases["adjacent_shuffled"] = synth.side_to_maf_text([blocks2[i] for i in order])
+    for name, body in cases.items():
+        src = os.path.join(HERE, "maf_%s.maf" % name)
+        with open(src, "w") as f:
+            f.write(body)
+        with open(os.path.join(HERE, "maf_%s.expected" % name), "w") as fout:
+            r = subprocess.run([os.path.join(REF, "maf_analyzer"), src], stdout=fout)
+        assert r.returncode == 0
+        print("maf_%s ok" % name)
+    # BASELINE config 1: the reference's own tests/highly_stitchable.maf.  The input stays in /root/reference
+    # (not copied); only the bytes the reference printed for it are kept.
+    ref_maf = "/root/reference/tests/highly_stitchable.maf"
+    if os.path.exists(ref_maf):
+        with open(os.path.join(HERE, "maf_highly_stitchable.expected"), "w") as fout:
+            subprocess.run([os.path.join(REF, "maf_analyzer"), ref_maf], stdout=fout, check=True)
+
+
+def make_unit_cases() -> None:
+    rng = np.random.default_rng(606)
+    lines = ["dparse 1 2000 1 2000 106 -6 1797 -9 -9 -1 7 1", "d2o", "drev"]  # m_delta.cc:43-49
+    for _ in range(120):
+        size = int(rng.integers(1, 60))
+        text = ["A"] * size
+        for _g in range(int(rng.integers(0, 6))):
+            at = int(rng.integers(0, len(text) + 1))
+            text[at:at] = ["-"] * int(rng.integers(1, 5))
+        t = "".join(text).encode()
+        gs = synth.gaps_of_text(t)
+        start = int(rng.integers(1, 1000))
+        fwd = rng.random() < 0.6
+        s, e = (start, start + size - 1) if fwd else (start + size - 1, start)
+        plen = len(t) + (int(rng.integers(-3, 4)) if rng.random() < 0.1 else 0)
+        lines.append("profile %d %d %d %d %s" % (s, e, plen, len(gs), " ".join("%d %d" % g for g in gs)))
+        lo, hi = min(s, e), max(s, e)
+        for _q in range(10):
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                lines.append("p2s %d" % int(rng.integers(lo - 2, hi + 3)))
+            elif k == 1:
+                lines.append("s2p %d" % int(rng.integers(-1, plen + 3)))
+            elif k == 2:
+                lines.append("sub %d %d" % (int(rng.integers(-1, plen + 3)), int(rng.integers(-1, plen + 3))))
+            else:
+                lines.append("subseq %d %d" % (int(rng.integers(lo - 1, hi + 2)), int(rng.integers(lo - 1, hi + 2))))
+        offs = synth._delta_offsets(rng, int(rng.integers(5, 80)), 0.1, 2.0, 0.1)[0]
+        lines.append("dparse 10 100 200 300 " + " ".join(str(v) for v in offs))
+        lines.append("drev")
+        lines.append("d2o")
+    cmds = "\n".join(lines) + "\n"
+    with open(os.path.join(HERE, "units_cmds.txt"), "w") as f:
+        f.write(cmds)
+    r = subprocess.run([os.path.join(REF, "ref_units")], input=cmds.encode(), capture_output=True, check=True)
+    with open(os.path.join(HERE, "units_expected.txt"), "wb") as f:
+        f.write(r.stdout)
+    print("units: %d commands" % len(lines))
+
+
+if __name__ == "__main__":
+    if not os.path.exists(os.path.join(REF, "m_translate")):
+        sys.exit("oracle/_ref missing: run `make -C oracle ref` where /root/reference exists")
+    make_translate_cases()
+    make_sort_cases()
+    make_maf_cases()
+    make_unit_cases()

@@ -1,0 +1,176 @@
+"""Parity of the HIP translate path with the oracle and with the golden fixtures the upstream reference
+produced.  Everything here calls through the C ABI of libparamugsy_amd.so.  Bit-exact: integer coordinates."""
+import filecmp
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from paramugsy_amd import capi, synth
+from paramugsy_amd.translate import TranslateJob, Workload, translate, profile_idx_of_seq_idx, seq_idx_of_profile_idx
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["typical", "gappy", "reverse", "tiny_blocks", "empty"]
+
+
+def case_paths(name):
+    case = os.path.join(GOLDEN, "translate_" + name)
+    with open(os.path.join(case, "nucmer.list")) as f:
+        deltas = [ln.strip() for ln in f if ln.strip()]
+    return case, deltas
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_file_level_bytes_equal_reference_golden(name, tmp_path):
+    case, deltas = case_paths(name)
+    out = str(tmp_path / "out.delta")
+    cwd = os.getcwd()
+    os.chdir(case)  # the first output line echoes the directory arguments
+    try:
+        translate("profiles-l", "profiles-r", deltas, out)
+    finally:
+        os.chdir(cwd)
+    assert filecmp.cmp(out, os.path.join(case, "expected.delta"), shallow=False)
+
+
+@pytest.mark.parametrize("name", ["typical", "reverse"])
+def test_cli_drop_in_bytes_equal_reference_golden(name, tmp_path):
+    case, _ = case_paths(name)
+    exe = os.path.join(ROOT, "bin", "m_translate")
+    out = str(tmp_path / "cli.delta")
+    r = subprocess.run([exe, "profiles-l", "profiles-r", "nucmer.list", out], cwd=case, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(out, os.path.join(case, "expected.delta"), shallow=False)
+    r = subprocess.run([exe, "profiles-l"], capture_output=True)  # m_translate_main.cc:22-25
+    assert r.returncode == 1 and b"Usage: m_translate" in r.stderr
+
+
+def assert_same_result(res, ora):
+    assert np.array_equal(res.status, ora["status"])
+    assert np.array_equal(res.unit_entry_off, ora["unit_entry_off"])
+    assert len(res.entries) == len(ora["entries"])
+    for k in ("ref_start", "ref_end", "qry_start", "qry_end", "n_offsets"):
+        assert np.array_equal(res.entries[k], ora["entries"][k]), k
+    # offsets: compare per entry through each side's own offset_begin (layouts agree, but do not rely on it)
+    assert np.array_equal(res.entries["offset_begin"], ora["entries"]["offset_begin"])
+    assert np.array_equal(res.offsets, ora["offsets"])
+
+
+MODES = {
+    "typical": dict(),
+    "gappy": dict(gap_rate=0.05, mean_gap=6.0, indel_rate=0.02, mean_indel=4.0, adjacent_prob=0.1, edge_gap_prob=0.5),
+    "reverse": dict(genome_len=8000, n_blocks=30, mean_cols=120, gap_rate=0.08, indel_rate=0.05, mean_len=400,
+                    entries_per_delta=80, rev_prob=0.5, delta_rev_prob=0.5, spacing=5),
+    "tiny_blocks": dict(genome_len=3000, n_blocks=150, mean_cols=8, gap_rate=0.1, mean_gap=3.0, indel_rate=0.05, mean_indel=8.0,
+                        mean_len=150, entries_per_delta=60, spacing=3, edge_gap_prob=0.4, adjacent_prob=0.15, delta_rev_prob=0.4),
+    "long_rows": dict(n_left=2, n_right=2, genome_len=400000, n_blocks=12, mean_cols=20000, gap_rate=0.02, mean_len=6000,
+                      entries_per_delta=60, spacing=200),
+}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("seed", [21, 22])
+def test_job_level_equals_oracle(mode, seed, oracle_build, tmp_path):
+    import pyoracle
+    w = synth.make_workload(str(tmp_path / "job"), seed * 100 + len(mode), **MODES[mode])
+    t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+    assert t.n_units > 10
+    job = TranslateJob(t)
+    job.run()
+    res = job.fetch()
+    ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
+    assert_same_result(res, ora)
+    assert res.all_ok and len(res.entries) > 0
+    # idempotence: a second pass over the resident batch gives the same bytes
+    job.run()
+    res2 = job.fetch()
+    assert np.array_equal(res2.offsets, res.offsets) and np.array_equal(res2.entries, res.entries)
+    job.close()
+
+
+def test_failure_classes_equal_oracle(oracle_build, tmp_path):
+    """Units the reference would die in (exceptions / asserts): same class per unit, and the entries emitted before
+    the failure are the same.  Inputs: consistent tables whose p_length / ranges are then corrupted."""
+    import pyoracle
+    w = synth.make_workload(str(tmp_path / "job"), 4242, **MODES["reverse"])
+    t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+    rng = np.random.default_rng(9)
+    # shrink some p_length values (Profile_idx_out_of_range), shift some row ranges (length assert / Seq_idx_out_of_range)
+    L = t.left["length"].copy()
+    pick = rng.random(len(L)) < 0.3
+    L[pick] -= rng.integers(1, 40, size=int(pick.sum()))
+    t.left["length"] = np.maximum(L, 1)
+    R = t.right["end"].copy()
+    pick = rng.random(len(R)) < 0.3
+    R[pick] += rng.integers(-30, 30, size=int(pick.sum()))
+    t.right["end"] = np.maximum(R, 1)
+    job = TranslateJob(t)
+    job.run()
+    res = job.fetch()
+    ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
+    assert_same_result(res, ora)
+    assert not res.all_ok
+    assert len(set(res.status.tolist()) - {0}) >= 2  # more than one failure class was exercised
+
+
+def test_malformed_gap_lists_are_refused_not_miscomputed(tmp_path):
+    w = synth.make_workload(str(tmp_path / "job"), 77)
+    t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+    # swap two gaps of the first left row that has at least two: no longer ascending
+    off = t.left["gap_off"]
+    rows = np.nonzero(np.diff(off) >= 2)[0]
+    r = int(rows[0])
+    a = int(off[r])
+    for k in ("gap_start", "gap_end"):
+        t.left[k][[a, a + 1]] = t.left[k][[a + 1, a]]
+    job = TranslateJob(t)
+    job.run()
+    res = job.fetch()
+    touched = t.units["left"] == r
+    assert touched.any()
+    assert (res.status[touched] == capi.PM_ST_MALFORMED_INPUT).all()
+    assert (res.status[~touched] == 0).all()
+
+
+def test_empty_batches():
+    z = np.zeros(0, dtype=np.int64)
+    z1 = np.zeros(1, dtype=np.int64)
+    rows = {"start": z, "end": z, "length": z, "gap_off": z1, "gap_start": z, "gap_end": z}
+    deltas = {k: z for k in ("ref_start", "ref_end", "qry_start", "qry_end", "ref_gap_start", "ref_gap_end", "qry_gap_start", "qry_gap_end")}
+    deltas["ref_gap_off"] = z1
+    deltas["qry_gap_off"] = z1
+    from paramugsy_amd.translate import Tables
+    zi = np.zeros(0, dtype=np.int32)
+    job = TranslateJob(Tables(rows, rows, deltas, {"delta": zi, "left": zi, "right": zi}))
+    job.run()
+    res = job.fetch()
+    assert len(res.entries) == 0 and len(res.offsets) == 0 and res.unit_entry_off.tolist() == [0]
+
+
+def test_batched_index_conversions_equal_oracle(oracle_build, tmp_path):
+    import pyoracle
+    w = synth.make_workload(str(tmp_path / "job"), 31, **MODES["gappy"])
+    t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+    rows = t.left
+    rng = np.random.default_rng(5)
+    n = 20000
+    row = rng.integers(0, len(rows["start"]), size=n).astype(np.int32)
+    lo = np.minimum(rows["start"], rows["end"])[row]
+    hi = np.maximum(rows["start"], rows["end"])[row]
+    si = rng.integers(lo - 3, hi + 4)
+    pi = rng.integers(-2, rows["length"][row] + 4)
+    a, sa = profile_idx_of_seq_idx(rows, row, si)
+    b, sb = pyoracle.profile_idx_of_seq_idx(rows, row, si)
+    assert np.array_equal(sa, sb) and np.array_equal(a[sa == 0], b[sb == 0])
+    assert (sa != 0).any() and (sa == 0).any()
+    a, sa = seq_idx_of_profile_idx(rows, row, pi)
+    b, sb = pyoracle.seq_idx_of_profile_idx(rows, row, pi)
+    assert np.array_equal(sa, sb) and np.array_equal(a[sa == 0], b[sb == 0])
+    assert set(sa.tolist()) >= {0, capi.PM_ST_IS_NONE, capi.PM_ST_PROFILE_IDX_OUT_OF_RANGE}
+    # round trip, a size-independent property: every base maps to a column that maps back to it
+    ok = sa == 0
+    c, sc = profile_idx_of_seq_idx(rows, row[ok], a[ok])
+    assert (sc == 0).all() and np.array_equal(c, pi[ok])
