@@ -113,6 +113,9 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
 /* One pass of the hot path over every unit: count, scan, emit.  Asynchronous on `hip_stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  Inputs and outputs stay in HBM. */
 int pm_job_run(pm_job_t *job, void *hip_stream);
+/* The same pass with HIP events recorded on `hip_stream` between its three phases; waits for completion and
+ * reports each phase's device time in milliseconds (measurement aid for bench.py; any pointer may be NULL). */
+int pm_job_run_profiled(pm_job_t *job, void *hip_stream, float *ms_count, float *ms_scan, float *ms_emit);
 /* Wait for the last run and report the output sizes. */
 int pm_job_sizes(pm_job_t *job, int64_t *n_entries, int64_t *n_offsets);
 /* Copy results to host arrays sized from pm_job_sizes.  unit_entry_off has units.n + 1 elements: unit u owns

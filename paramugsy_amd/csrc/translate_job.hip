@@ -484,6 +484,60 @@ int pm_job_run(pm_job_t *j, void *hip_stream) {
   return PM_OK;
 }
 
+int pm_job_run_profiled(pm_job_t *j, void *hip_stream, float *ms_count, float *ms_scan, float *ms_emit) {
+  if(!j) {
+    return fail(PM_E_INVALID, "pm_job_run_profiled: null job");
+  }
+  int rc = use_device(j->device);
+  if(rc) {
+    return rc;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  hipEvent_t ev[4];
+  for(int k = 0; k < 4; ++k) {
+    PM_HIP(hipEventCreate(&ev[k]));
+  }
+  i64 U = j->n_units;
+  unsigned blocks = (unsigned)((U + 63) / 64);
+  PM_HIP(hipEventRecord(ev[0], stream));
+  if(U > 0) {
+    translate_kernel<false><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
+                                                       (const int *)j->u_left.p, (const int *)j->u_right.p, (int *)j->status.p,
+                                                       (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                                                       nullptr);
+  }
+  PM_HIP(hipEventRecord(ev[1], stream));
+  size_t tmp = j->scan_tmp_bytes;
+  PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off.p, (i64)0, (size_t)(U + 1),
+                                 rocprim::plus<i64>(), stream));
+  tmp = j->scan_tmp_bytes;
+  PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_off.p, (i64 *)j->off_off.p, (i64)0, (size_t)(U + 1),
+                                 rocprim::plus<i64>(), stream));
+  PM_HIP(hipEventRecord(ev[2], stream));
+  PM_TRY(job_launch_emit(j, stream));
+  PM_HIP(hipEventRecord(ev[3], stream));
+  PM_HIP(hipEventSynchronize(ev[3]));
+  float ms[3] = {0, 0, 0};
+  for(int k = 0; k < 3; ++k) {
+    PM_HIP(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
+  }
+  for(int k = 0; k < 4; ++k) {
+    (void)hipEventDestroy(ev[k]);
+  }
+  if(ms_count) {
+    *ms_count = ms[0];
+  }
+  if(ms_scan) {
+    *ms_scan = ms[1];
+  }
+  if(ms_emit) {
+    *ms_emit = ms[2];
+  }
+  j->last_stream = stream;
+  j->ran = true;
+  return PM_OK;
+}
+
 int pm_job_sizes(pm_job_t *j, int64_t *n_entries, int64_t *n_offsets) {
   if(!j) {
     return fail(PM_E_INVALID, "pm_job_sizes: null job");
