@@ -15,6 +15,11 @@
 
 #include "../../include/paramugsy_amd.h"
 
+// The unit arithmetic is plain integer code; marking it host+device lets tests/tools/unit_host_harness.cpp run
+// the very same functions on the CPU under sanitizers (GPU sanitizers are not available on the pool).  The
+// library itself only ever calls them from kernels.
+#define PM_HD __host__ __device__
+
 namespace pm {
 
 typedef long long i64;
@@ -49,14 +54,14 @@ struct DeltasD {
   const int *bad;
 };
 
-__device__ __forceinline__ i64 rlen(R2 r) { return (r.s <= r.e ? r.e - r.s : r.s - r.e) + 1; } // m_range.hh:34
-__device__ __forceinline__ bool fwd(R2 r) { return r.s <= r.e; }                               // m_range.hh:36
-__device__ __forceinline__ R2 fwd_of(R2 r) { return fwd(r) ? r : R2{r.e, r.s}; }
-__device__ __forceinline__ i64 imax(i64 a, i64 b) { return a > b ? a : b; }
-__device__ __forceinline__ i64 imin(i64 a, i64 b) { return a < b ? a : b; }
+PM_HD __forceinline__ i64 rlen(R2 r) { return (r.s <= r.e ? r.e - r.s : r.s - r.e) + 1; } // m_range.hh:34
+PM_HD __forceinline__ bool fwd(R2 r) { return r.s <= r.e; }                               // m_range.hh:36
+PM_HD __forceinline__ R2 fwd_of(R2 r) { return fwd(r) ? r : R2{r.e, r.s}; }
+PM_HD __forceinline__ i64 imax(i64 a, i64 b) { return a > b ? a : b; }
+PM_HD __forceinline__ i64 imin(i64 a, i64 b) { return a < b ? a : b; }
 
 // m_range.hh:80-94
-__device__ __forceinline__ bool overlap(R2 a, R2 b, R2 &o) {
+PM_HD __forceinline__ bool overlap(R2 a, R2 b, R2 &o) {
   R2 fa = fwd_of(a), fb = fwd_of(b);
   o.s = imax(fa.s, fb.s);
   o.e = imin(fa.e, fb.e);
@@ -75,7 +80,7 @@ struct PV {
 // a3, m_profile.cc:91-112.  The scan adds gap k while gap[k].s <= offset + pre[k] and stops at the first
 // failure; gap[k].s - pre[k] is non-decreasing on ascending disjoint lists, so that first failure is a
 // lower bound.
-__device__ inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out) {
+PM_HD inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out) {
   R2 f = fwd_of(p.range);
   if(!(f.s <= si && si <= f.e)) {
     return PM_ST_SEQ_IDX_OUT_OF_RANGE;
@@ -98,7 +103,7 @@ __device__ inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out) {
 
 // a4, m_profile.cc:114-149.  First gap whose end is >= pi decides: inside it -> none, else the gaps
 // before it are skipped.
-__device__ inline int seq_idx_of_profile_idx(const PV &p, i64 pi, i64 &out, bool &none) {
+PM_HD inline int seq_idx_of_profile_idx(const PV &p, i64 pi, i64 &out, bool &none) {
   none = false;
   if(!(pi < p.len + 1)) {
     return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
@@ -132,7 +137,7 @@ struct GapView {
   i64 L;
 };
 
-__device__ __forceinline__ R2 view_get(const GapView &v, int i) {
+PM_HD __forceinline__ R2 view_get(const GapView &v, int i) {
   if(!v.mirror) {
     R2 r = v.g[v.lo + i];
     return R2{imax(r.s, v.ws), imin(r.e, v.we)};
@@ -144,7 +149,7 @@ __device__ __forceinline__ R2 view_get(const GapView &v, int i) {
 
 // a5, m_profile.cc:160-206.  On an ascending disjoint list the gaps overlapping [s,e] are one index range.
 // Returns status; `none` mirrors the reference's empty option; seq = the sub profile's p_range.
-__device__ inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, bool &none) {
+PM_HD inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, bool &none) {
   none = false;
   if(s <= 0 || p.len < s || e <= 0 || p.len < e) {
     return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
@@ -214,7 +219,7 @@ __device__ inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &
 }
 
 // m_profile.cc:208-212
-__device__ inline int subset_seq(const PV &p, i64 s, i64 e, GapView &v, R2 &seq) {
+PM_HD inline int subset_seq(const PV &p, i64 s, i64 e, GapView &v, R2 &seq) {
   i64 ps, pe;
   int st = profile_idx_of_seq_idx(p, s, ps);
   if(st) {
@@ -240,15 +245,15 @@ struct PairCursor {
   bool held0, held1;
   R2 hold0, hold1;
 
-  __device__ __forceinline__ bool has(int r) const { return r ? (held1 || at1 < v1.n) : (held0 || at0 < v0.n); }
-  __device__ __forceinline__ R2 front(int r) const {
+  PM_HD __forceinline__ bool has(int r) const { return r ? (held1 || at1 < v1.n) : (held0 || at0 < v0.n); }
+  PM_HD __forceinline__ R2 front(int r) const {
     if(r) {
       return held1 ? hold1 : view_get(v1, at1);
     }
     return held0 ? hold0 : view_get(v0, at0);
   }
-  __device__ __forceinline__ bool done() const { return !has(0) && !has(1); }
-  __device__ __forceinline__ void pop(int r) {
+  PM_HD __forceinline__ bool done() const { return !has(0) && !has(1); }
+  PM_HD __forceinline__ void pop(int r) {
     if(r) {
       if(held1) {
         held1 = false;
@@ -266,7 +271,7 @@ struct PairCursor {
       }
     }
   }
-  __device__ __forceinline__ int push_back(int r, R2 g) {
+  PM_HD __forceinline__ int push_back(int r, R2 g) {
     if(r ? held1 : held0) {
       return PM_ST_ALREADY_UNNEXT;
     }
@@ -281,7 +286,7 @@ struct PairCursor {
     return PM_ST_OK;
   }
   // m_translate.cc:34-62
-  __device__ __forceinline__ int pick(i64 pos0, i64 pos1, bool &have, int &row, R2 &gap) const {
+  PM_HD __forceinline__ int pick(i64 pos0, i64 pos1, bool &have, int &row, R2 &gap) const {
     bool h0 = has(0), h1 = has(1);
     have = h0 || h1;
     if(h0 && h1) {
@@ -323,7 +328,7 @@ struct Sink {
   i64 off_cap;     // EMIT: this unit's offset count (exact, from the COUNT pass)
   i64 ent_cap;
 
-  __device__ __forceinline__ void put(i64 v) {
+  PM_HD __forceinline__ void put(i64 v) {
     if(EMIT) {
       i64 at = n_off + pend;
       if(at < off_cap) { // offsets of a segment that is later dropped may run past the exact slot
@@ -332,7 +337,7 @@ struct Sink {
     }
     ++pend;
   }
-  __device__ __forceinline__ int gap(int row, R2 g) {
+  PM_HD __forceinline__ int gap(int row, R2 g) {
     int st = PM_ST_OK;
     if(pend > 0 && (g.s < last_start || (g.s == last_start && last_row == 0 && row == 1))) {
       st = PM_ST_OFFSET_ORDER;
@@ -347,11 +352,11 @@ struct Sink {
     last_row = row;
     return st;
   }
-  __device__ __forceinline__ void drop() {
+  PM_HD __forceinline__ void drop() {
     pend = 0;
     wpos = 0;
   }
-  __device__ __forceinline__ void commit(R2 ref, R2 qry) {
+  PM_HD __forceinline__ void commit(R2 ref, R2 qry) {
     put(0);
     if(EMIT) {
       if(n_ent < ent_cap) {
@@ -383,13 +388,13 @@ struct Merge {
   i64 query_columns;
   Sink<EMIT> sink;
 
-  __device__ __forceinline__ void b_restart(i64 r, i64 q) {
+  PM_HD __forceinline__ void b_restart(i64 r, i64 q) {
     b_ref_start = b_ref_pos = r;
     b_query_start = b_query_pos = q;
     b_sum0 = b_sum1 = 0;
     sink.drop();
   }
-  __device__ __forceinline__ int b_add_gap(int row, R2 d) { // m_delta_builder.hh:32-63
+  PM_HD __forceinline__ int b_add_gap(int row, R2 d) { // m_delta_builder.hh:32-63
     i64 walked = row ? (b_query_pos - b_query_start) + b_sum1 : (b_ref_pos - b_ref_start) + b_sum0;
     R2 g{d.s + walked + 1, d.e + walked + 1};
     if(row) {
@@ -404,13 +409,13 @@ struct Merge {
     }
     return sink.gap(row, g);
   }
-  __device__ __forceinline__ i64 qcol(i64 pi) const { return mirrored ? query_columns - pi + 1 : pi; }
-  __device__ __forceinline__ void b_finish() { // m_delta_builder.cc:7-22
+  PM_HD __forceinline__ i64 qcol(i64 pi) const { return mirrored ? query_columns - pi + 1 : pi; }
+  PM_HD __forceinline__ void b_finish() { // m_delta_builder.cc:7-22
     if(b_ref_start != b_ref_pos && b_query_start != b_query_pos) {
       sink.commit(R2{b_ref_start, b_ref_pos - 1}, R2{qcol(b_query_start), qcol(b_query_pos - 1)});
     }
   }
-  __device__ __forceinline__ void consume_delta_piece(int row, R2 d) { // m_translate.cc:220-231
+  PM_HD __forceinline__ void consume_delta_piece(int row, R2 d) { // m_translate.cc:220-231
     if(row) {
       ref_pos += d.e + 1;
       query_pos += d.s;
@@ -421,7 +426,7 @@ struct Merge {
     }
     column += d.e + 1;
   }
-  __device__ __forceinline__ void close_segment(int row, R2 g) { // m_translate.cc:309-316,436-443
+  PM_HD __forceinline__ void close_segment(int row, R2 g) { // m_translate.cc:309-316,436-443
     b_ref_pos += g.s;
     b_query_pos += g.s;
     if(row) { // m_translate.cc:233-244
@@ -437,11 +442,11 @@ struct Merge {
     b_finish();
     b_restart(ref_pos, query_pos);
   }
-  __device__ __forceinline__ R2 rel(int row, R2 g) const {
+  PM_HD __forceinline__ R2 rel(int row, R2 g) const {
     i64 base = row ? query_pos : ref_pos;
     return R2{g.s - base, g.e - base};
   }
-  __device__ inline int step() { // m_translate.cc:279-472
+  PM_HD inline int step() { // m_translate.cc:279-472
     bool have_p, have_d;
     int prow = 0, drow = 0;
     R2 pgap{0, 0}, dgap{0, 0};
@@ -499,7 +504,7 @@ struct Merge {
   }
 };
 
-__device__ __forceinline__ PV row_view(const RowsD &rows, int r) {
+PM_HD __forceinline__ PV row_view(const RowsD &rows, int r) {
   PV p;
   p.range = rows.range[r];
   p.len = rows.length[r];
@@ -512,7 +517,7 @@ __device__ __forceinline__ PV row_view(const RowsD &rows, int r) {
 
 // One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
 template <bool EMIT>
-__device__ inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r,
+PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r,
                                Sink<EMIT> &sink) {
   if(left.bad[l] | right.bad[r] | ds.bad[d]) {
     return PM_ST_MALFORMED_INPUT;

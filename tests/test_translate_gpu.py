@@ -110,14 +110,22 @@ def corrupt_tables(t, rng):
                 rows["gap_end"][a:b] += sh
             else:
                 rows["length"][r] = max(1, rows["length"][r] - sh)
-    for name in ("ref", "qry"):
-        off = t.deltas[name + "_gap_off"]
-        for d in np.nonzero(rng.random(len(off) - 1) < 0.2)[0]:
-            a, b = int(off[d]), int(off[d + 1])
-            if b > a:
-                k, sh = int(rng.integers(0, b - a)), int(rng.integers(1, 10))
-                t.deltas[name + "_gap_end"][a + k:b] += sh
-                t.deltas[name + "_gap_start"][a + k + 1:b] += sh
+    # stretch one gap of an entry and move every later gap of BOTH rows along with it: the entry's columns stay
+    # a valid alignment (no column gapped in both rows), only its ranges no longer fit them
+    D = t.deltas
+    for d in np.nonzero(rng.random(len(D["ref_start"])) < 0.2)[0]:
+        name = ("ref", "qry")[int(rng.integers(0, 2))]
+        a, b = int(D[name + "_gap_off"][d]), int(D[name + "_gap_off"][d + 1])
+        if b <= a:
+            continue
+        k, sh = a + int(rng.integers(0, b - a)), int(rng.integers(1, 10))
+        pivot = D[name + "_gap_end"][k]
+        D[name + "_gap_end"][k] += sh
+        for other in ("ref", "qry"):
+            oa, ob = int(D[other + "_gap_off"][d]), int(D[other + "_gap_off"][d + 1])
+            later = np.arange(oa, ob)[D[other + "_gap_start"][oa:ob] > pivot]
+            D[other + "_gap_start"][later] += sh
+            D[other + "_gap_end"][later] += sh
 
 
 @pytest.mark.parametrize("seed", [4242, 4243, 4244])
@@ -134,6 +142,25 @@ def test_failure_classes_equal_oracle(seed, oracle_build, tmp_path):
     ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
     assert_same_result(res, ora)
     assert not res.all_ok and (res.status != 0).sum() >= 3
+
+
+def test_column_gapped_in_both_rows_is_refused(oracle_build):
+    """A delta entry with the same column gapped in its reference row AND its query row cannot come out of a
+    delta file (m_delta.cc:50-68 hands out columns once) and makes the reference's writer emit a stray 0.
+    The builder's gaps then arrive out of the writer's merge order; the library refuses the unit
+    (PM_ST_OFFSET_ORDER) instead of printing something else."""
+    from paramugsy_amd.translate import Tables
+    i64 = lambda *v: np.array(v, dtype=np.int64)
+    left = {"start": i64(1), "end": i64(100), "length": i64(100), "gap_off": i64(0, 0), "gap_start": i64(), "gap_end": i64()}
+    right = {"start": i64(1), "end": i64(100), "length": i64(100), "gap_off": i64(0, 0), "gap_start": i64(), "gap_end": i64()}
+    deltas = {"ref_start": i64(1), "ref_end": i64(99), "qry_start": i64(1), "qry_end": i64(99),
+              "ref_gap_off": i64(0, 1), "ref_gap_start": i64(50), "ref_gap_end": i64(50),
+              "qry_gap_off": i64(0, 1), "qry_gap_start": i64(50), "qry_gap_end": i64(50)}
+    z = np.zeros(1, dtype=np.int32)
+    job = TranslateJob(Tables(left, right, deltas, {"delta": z, "left": z, "right": z}))
+    job.run()
+    res = job.fetch()
+    assert res.status.tolist() == [capi.PM_ST_OFFSET_ORDER]
 
 
 def test_malformed_gap_lists_are_refused_not_miscomputed(tmp_path):

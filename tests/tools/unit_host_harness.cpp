@@ -1,0 +1,174 @@
+// tests/tools/unit_host_harness.cpp -- TEST TOOL.  Runs the device-side unit arithmetic of
+// paramugsy_amd/csrc/translate_device.hpp on the CPU (the functions are __host__ __device__), so that the
+// exact code the kernels execute can be checked against the oracle without a GPU and under
+// -fsanitize=address,undefined (GPU sanitizers are not available on the pool).  Built by
+// tests/test_device_code_on_host.py with hipcc; never part of libparamugsy_amd.so.
+//
+// C entry point: same flat tables as pm_job_create, same outputs as pm_job_fetch.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../paramugsy_amd/csrc/translate_device.hpp"
+
+using namespace pm;
+
+namespace {
+
+struct HostRows {
+  std::vector<R2> range, gaps;
+  std::vector<i64> length, gap_off, pre;
+  std::vector<int> bad;
+  RowsD view() const {
+    RowsD d;
+    d.n = (i64)range.size();
+    d.range = range.data();
+    d.length = length.data();
+    d.gap_off = gap_off.data();
+    d.gaps = gaps.data();
+    d.pre = pre.data();
+    d.bad = bad.data();
+    return d;
+  }
+};
+
+// the same construction as prepare_rows_kernel
+void prepare_rows(const pm_rows_t *h, HostRows &s) {
+  i64 n = h->n, G = h->gap_off[n];
+  s.range.resize(n);
+  s.length.assign(h->length, h->length + n);
+  s.gap_off.assign(h->gap_off, h->gap_off + n + 1);
+  s.gaps.resize(G + 1);
+  s.pre.resize(G + n + 1);
+  s.bad.resize(n + 1);
+  for(i64 r = 0; r < n; ++r) {
+    s.range[r] = R2{h->start[r], h->end[r]};
+    i64 o = h->gap_off[r], m = h->gap_off[r + 1] - o;
+    i64 *p = s.pre.data() + o + r;
+    i64 acc = 0, prev_end = 0;
+    int flag = 0;
+    for(i64 k = 0; k < m; ++k) {
+      R2 g{h->gap_start[o + k], h->gap_end[o + k]};
+      if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
+        flag = 1;
+      }
+      prev_end = g.e;
+      s.gaps[o + k] = g;
+      p[k] = acc;
+      acc += rlen(g);
+    }
+    p[m] = acc;
+    s.bad[r] = flag;
+  }
+}
+
+struct HostDeltas {
+  std::vector<R2> ref, qry, rg[2], qg[2];
+  std::vector<i64> ref_off, qry_off, rp[2], qp[2];
+  std::vector<int> bad;
+};
+
+// the same construction as prepare_deltas_kernel
+void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *off, const int64_t *gs, const int64_t *ge,
+                    std::vector<R2> &range, std::vector<R2> &gf, std::vector<i64> &pf, std::vector<R2> &gr, std::vector<i64> &pr,
+                    std::vector<int> &bad) {
+  i64 G = off[n];
+  range.resize(n);
+  gf.resize(G + 1);
+  gr.resize(G + 1);
+  pf.resize(G + n + 1);
+  pr.resize(G + n + 1);
+  for(i64 d = 0; d < n; ++d) {
+    R2 rg{rs[d], re[d]};
+    range[d] = rg;
+    i64 o = off[d], m = off[d + 1] - o;
+    i64 acc = 0, prev_end = 0;
+    for(i64 k = 0; k < m; ++k) {
+      R2 g{gs[o + k], ge[o + k]};
+      if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
+        bad[d] = 1;
+      }
+      prev_end = g.e;
+      gf[o + k] = g;
+      pf[o + d + k] = acc;
+      acc += rlen(g);
+    }
+    pf[o + d + m] = acc;
+    i64 columns = rlen(rg) + acc, racc = 0;
+    for(i64 k = 0; k < m; ++k) {
+      R2 g{gs[o + (m - 1 - k)], ge[o + (m - 1 - k)]};
+      R2 mg{columns - g.e + 1, columns - g.s + 1};
+      gr[o + k] = mg;
+      pr[o + d + k] = racc;
+      racc += rlen(mg);
+    }
+    pr[o + d + m] = racc;
+  }
+}
+
+} // namespace
+
+extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+                             int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets, pm_entry_t *entries,
+                             int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
+  HostRows L, R;
+  prepare_rows(left, L);
+  prepare_rows(right, R);
+  HostDeltas D;
+  i64 n = deltas->n;
+  D.bad.assign(n + 1, 0);
+  D.ref_off.assign(deltas->ref_gap_off, deltas->ref_gap_off + n + 1);
+  D.qry_off.assign(deltas->qry_gap_off, deltas->qry_gap_off + n + 1);
+  prepare_strand(n, deltas->ref_start, deltas->ref_end, deltas->ref_gap_off, deltas->ref_gap_start, deltas->ref_gap_end, D.ref, D.rg[0],
+                 D.rp[0], D.rg[1], D.rp[1], D.bad);
+  prepare_strand(n, deltas->qry_start, deltas->qry_end, deltas->qry_gap_off, deltas->qry_gap_start, deltas->qry_gap_end, D.qry, D.qg[0],
+                 D.qp[0], D.qg[1], D.qp[1], D.bad);
+  DeltasD dv;
+  dv.n = n;
+  dv.ref = D.ref.data();
+  dv.qry = D.qry.data();
+  dv.ref_off = D.ref_off.data();
+  dv.qry_off = D.qry_off.data();
+  for(int o = 0; o < 2; ++o) {
+    dv.ref_gaps[o] = D.rg[o].data();
+    dv.ref_pre[o] = D.rp[o].data();
+    dv.qry_gaps[o] = D.qg[o].data();
+    dv.qry_pre[o] = D.qp[o].data();
+  }
+  dv.bad = D.bad.data();
+  RowsD lv = L.view(), rv = R.view();
+  i64 U = units->n;
+  std::vector<i64> cnt_e(U + 1, 0), cnt_o(U + 1, 0);
+  for(i64 u = 0; u < U; ++u) { // COUNT pass
+    Sink<false> sink;
+    memset(&sink, 0, sizeof sink);
+    status[u] = run_unit<false>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], sink);
+    cnt_e[u] = sink.n_ent;
+    cnt_o[u] = sink.n_off;
+  }
+  std::vector<i64> eo(U + 1, 0), oo(U + 1, 0);
+  for(i64 u = 0; u < U; ++u) {
+    eo[u + 1] = eo[u] + cnt_e[u];
+    oo[u + 1] = oo[u] + cnt_o[u];
+  }
+  memcpy(unit_entry_off, eo.data(), (size_t)(U + 1) * 8);
+  *n_entries = eo[U];
+  *n_offsets = oo[U];
+  if(eo[U] > entries_cap || oo[U] > offsets_cap) {
+    return 1; // caller re-calls with bigger buffers
+  }
+  for(i64 u = 0; u < U; ++u) { // EMIT pass
+    Sink<true> sink;
+    memset(&sink, 0, sizeof sink);
+    sink.ent = entries + eo[u];
+    sink.ent_cap = eo[u + 1] - eo[u];
+    sink.off = (i64 *)offsets;
+    sink.off_base = oo[u];
+    sink.off_cap = oo[u + 1] - oo[u];
+    int st = run_unit<true>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], sink);
+    if(st != status[u]) {
+      return 2; // the two passes must agree
+    }
+  }
+  return 0;
+}
