@@ -152,6 +152,38 @@ void pm_workload_destroy(pm_workload_t *w);
 int pm_translate_files(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                        const char *out_path, int device);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Profile x profile DP (BASELINE.json's GCUPS metric).  NO REFERENCE COUNTERPART: the reference has no DP, no
+ * scores, no traceback; this interface and the computation behind it are specified by this
+ * repo (oracle/dp_oracle.h) and checked against its own scalar oracle only.
+ *
+ * A profile is a run of 8-byte columns {nA, nC, nG, nT, nGap, 0, 0, 0} (how many rows hold each symbol).
+ * Pair k aligns columns [off_a[k], off_a[k+1]) of cols_a with columns [off_b[k], off_b[k+1]) of cols_b,
+ * globally, with affine gaps, int32 scores; recurrence and tie-breaking: oracle/dp_oracle.h.
+ * Limits: |sub| <= 127, gap penalties in [0, 32767], profile length <= 2^24 columns, scores within +-2^29. */
+typedef struct pm_dp_params {
+  int32_t sub[25]; /* sub[a*5+b], symbols A, C, G, T, gap */
+  int32_t gap_open;
+  int32_t gap_extend;
+} pm_dp_params_t;
+
+typedef struct pm_dp_batch pm_dp_batch_t; /* opaque; owns device memory */
+
+/* Upload a batch (host pointers).  tb_budget_bytes bounds the traceback workspace (<= 0: 32 GiB); pairs are
+ * processed in consecutive chunks that fit it. */
+int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
+                       const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out);
+/* One pass over every pair: fill (scores + 4 decision bits per cell) and, when traceback != 0, the path walk.
+ * Asynchronous on hip_stream. */
+int pm_dp_batch_run(pm_dp_batch_t *batch, int traceback, void *hip_stream);
+/* Same, timed with HIP events on the stream (waits): device milliseconds of the fill and traceback kernels. */
+int pm_dp_batch_run_profiled(pm_dp_batch_t *batch, int traceback, void *hip_stream, float *ms_fill, float *ms_traceback);
+/* scores[n_pairs]; n_ops[n_pairs]; ops: pair k owns bytes [off_a[k]+off_b[k], off_a[k+1]+off_b[k+1]) and its path is
+ * the LAST n_ops[k] bytes of that slot, first op first (0 = M, 1 = I: column of B against a gap, 2 = D). */
+int pm_dp_batch_fetch(pm_dp_batch_t *batch, int32_t *scores, uint8_t *ops, int32_t *n_ops);
+int pm_dp_batch_info(pm_dp_batch_t *batch, int64_t *cells, int64_t *traceback_bytes_per_run, int64_t *input_bytes, int32_t *n_chunks);
+void pm_dp_batch_destroy(pm_dp_batch_t *batch);
+
 #ifdef __cplusplus
 }
 #endif

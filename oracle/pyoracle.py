@@ -95,3 +95,70 @@ def enumerate_units(left_dir, right_dir, delta_paths):
 def translate_files(left_dir, right_dir, delta_paths, out_path) -> int:
     arr = (C.c_char_p * len(delta_paths))(*[p.encode() for p in delta_paths])
     return lib().pmo_translate_files(left_dir.encode(), right_dir.encode(), arr, len(delta_paths), out_path.encode())
+
+
+# ---------------------------------------------------------------- profile DP oracle (oracle/dp_oracle.c)
+# "Parity unpinned": no reference counterpart exists for the DP.
+
+DP_LIB_PATH = os.path.join(_HERE, "_build", "libdp_oracle.so")
+_dp = None
+
+
+def dp_lib() -> C.CDLL:
+    global _dp
+    if _dp is None:
+        if not os.path.exists(DP_LIB_PATH):
+            raise RuntimeError("%s missing: run `make -C oracle oracle`" % DP_LIB_PATH)
+        from paramugsy_amd.dp import PmDpParams
+        o = C.CDLL(DP_LIB_PATH)
+        o.dp_oracle_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(PmDpParams), C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        o.dp_oracle_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(PmDpParams), C.c_void_p]
+        o.dp_oracle_score_batch.restype = None
+        o.dp_oracle_score_of_path.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(PmDpParams), C.c_void_p, C.c_int32,
+                                              C.POINTER(C.c_int32)]
+        _dp = o
+    return _dp
+
+
+def dp_align(inputs, params):
+    """(scores, per-pair op arrays, first op first) from the scalar oracle; `inputs` is a paramugsy_amd.dp.DpInputs."""
+    o = dp_lib()
+    n = inputs.n_pairs
+    scores = np.zeros(n, dtype=np.int32)
+    n_ops = np.zeros(n, dtype=np.int32)
+    ops = np.zeros(int(inputs.off_a[-1] + inputs.off_b[-1]), dtype=np.uint8)
+    ca = np.ascontiguousarray(inputs.cols_a)
+    cb = np.ascontiguousarray(inputs.cols_b)
+    oa = np.ascontiguousarray(inputs.off_a, dtype=np.int64)
+    ob = np.ascontiguousarray(inputs.off_b, dtype=np.int64)
+    rc = o.dp_oracle_align_batch(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, n, C.byref(params),
+                                 scores.ctypes.data, ops.ctypes.data, n_ops.ctypes.data)
+    assert rc == 0
+    paths = []
+    for k in range(n):
+        s = int(oa[k] + ob[k])
+        paths.append(ops[s:s + int(n_ops[k])].copy())
+    return scores, paths
+
+
+def dp_scores(inputs, params):
+    o = dp_lib()
+    scores = np.zeros(inputs.n_pairs, dtype=np.int32)
+    ca = np.ascontiguousarray(inputs.cols_a)
+    cb = np.ascontiguousarray(inputs.cols_b)
+    oa = np.ascontiguousarray(inputs.off_a, dtype=np.int64)
+    ob = np.ascontiguousarray(inputs.off_b, dtype=np.int64)
+    o.dp_oracle_score_batch(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, inputs.n_pairs, C.byref(params), scores.ctypes.data)
+    return scores
+
+
+def dp_score_of_path(inputs, params, k, path):
+    """Re-scores a path under the specification -> (rc, score); rc != 0 when the path does not span the pair."""
+    o = dp_lib()
+    a = np.ascontiguousarray(inputs.cols_a[inputs.off_a[k]:inputs.off_a[k + 1]])
+    b = np.ascontiguousarray(inputs.cols_b[inputs.off_b[k]:inputs.off_b[k + 1]])
+    p = np.ascontiguousarray(path, dtype=np.uint8)
+    s = C.c_int32()
+    rc = o.dp_oracle_score_of_path(a.ctypes.data, len(a), b.ctypes.data, len(b), C.byref(params), p.ctypes.data, len(p), C.byref(s))
+    return rc, s.value

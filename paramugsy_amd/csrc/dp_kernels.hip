@@ -1,0 +1,560 @@
+// dp_kernels.hip -- profile x profile affine-gap DP (global alignment), gfx950.
+//
+// NO REFERENCE COUNTERPART: orbitz/paramugsy contains no DP, no scores and no traceback.  The
+// computation is specified by this repo (oracle/dp_oracle.h, DESIGN.md "Profile DP specification") because
+// BASELINE.json's metric is profile-DP GCUPS; the kernel is checked against that scalar oracle only.
+//
+// Mapping (DESIGN.md "dp_fill_kernel"):
+//   * one 64-lane wavefront per profile pair, one pair per workgroup, thousands of pairs per launch;
+//   * the columns of B are cut into stripes of 64 lanes x C columns; a lane keeps its C columns' state
+//     (H-gap_open of the previous row, F, and the columns' substitution weights) in registers for the whole
+//     stripe: 5 VGPRs per column;
+//   * the wave sweeps the rows of A as an anti-diagonal wavefront: at step t lane l is on row t-l.  The two
+//     values a row hands to the next lane (H-gap_open and E of the lane's last column) move with one
+//     v_mov_b32_dpp wave_shr:1 each;
+//   * A's packed columns are loaded 64 at a time (one coalesced 512-byte load per 64 steps), expanded to
+//     int16 pairs and staged in a 128-row LDS ring; each lane reads its row with one ds_read_b128;
+//   * the column score is sum-of-pairs = 3 x v_dot2c_i32_i16 accumulating onto the diagonal (the last half
+//     lane of the third dot carries gap_open so that the stored H-gap_open needs no correction);
+//   * max-plus recurrence in int32 VALU (no MFMA: nothing to contract);
+//   * traceback: 4 decision bits per cell, shifted into a word with v_alignbit_b32 (one op per bit), one
+//     coalesced 256-byte store per step: tb[stripe][step][lane];
+//   * stripe boundary (last column of a stripe, per row): written by lane 63, read back 64 rows at a time.
+// Algorithmic HBM traffic per cell: 0.5 byte of traceback written + (8 bytes per column of A per stripe +
+// 8 bytes per column of B) read, i.e. ~0.5 B/cell for kilobase profiles; the kernel is VALU-issue bound
+// (18 VALU ops per cell), not HBM bound.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pm_internal.hpp"
+
+namespace pm {
+
+typedef long long i64;
+typedef unsigned long long u64;
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+#define DP_NEG_INF (-(1 << 29))
+#define DPP_WAVE_SHR1 0x138
+
+struct DpParamsD {
+  int sub[25];
+  int go;
+  int ge;
+};
+
+__device__ __forceinline__ int dot2(int a, int b, int acc) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
+}
+
+__device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)lo & 0xffffu) | ((unsigned)hi << 16)); }
+
+// lane l takes lane l-1's value; lane 0 takes `lane0`.  Needs all 64 lanes enabled.
+__device__ __forceinline__ int from_left(int lane0, int v) {
+  return __builtin_amdgcn_update_dpp(lane0, v, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+
+// Words of traceback one pair needs: stripes x (la + 63) steps x 64 lanes (C = 8: one word per lane per step).
+__host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
+  i64 W = 64 * C;
+  i64 stripes = (lb + W - 1) / W;
+  return stripes * (la + 63) * 64 * (C / 8);
+}
+
+template <int C, bool TRACE>
+__global__ void __launch_bounds__(64)
+dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
+               const i64 *__restrict__ off_b, i64 first_pair, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
+               int2 *__restrict__ bnd, int *__restrict__ scores, DpParamsD P) {
+  static_assert(C == 8, "one traceback word per lane per step");
+  __shared__ int4 ring[128];
+  const int lane = threadIdx.x;
+  const i64 pair = first_pair + blockIdx.x;
+  const i64 a0 = off_a[pair], b0 = off_b[pair];
+  const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
+  const u64 *A = cols_a + a0;
+  const u64 *B = cols_b + b0;
+  unsigned *tbp = TRACE ? tb + tb_off[blockIdx.x] : nullptr;
+  int2 *bp = bnd + a0;
+  const int go = P.go, ge = P.ge;
+  constexpr int W = 64 * C;
+  const int n_stripes = (lb + W - 1) / W;
+  const int steps = la + 63;
+  int result = 0;
+  if(la == 0 || lb == 0) { // one profile empty: a single gap run
+    int n = la + lb;
+    if(lane == 0) {
+      scores[pair] = n == 0 ? 0 : -(go + (n - 1) * ge);
+    }
+    return;
+  }
+
+  for(int s = 0; s < n_stripes; ++s) {
+    const int j0 = s * W + lane * C; // this lane's first column of B (0-based)
+    int w0[C], w1[C], w2[C], hop[C], f[C];
+#pragma unroll
+    for(int c = 0; c < C; ++c) {
+      const int j = j0 + c;
+      const bool in = j < lb;
+      const u64 col = in ? B[j] : 0ull;
+      int cb[5], w[5];
+#pragma unroll
+      for(int b = 0; b < 5; ++b) {
+        cb[b] = (int)((col >> (8 * b)) & 0xff);
+      }
+#pragma unroll
+      for(int a = 0; a < 5; ++a) {
+        int acc = 0;
+#pragma unroll
+        for(int b = 0; b < 5; ++b) {
+          acc += cb[b] * P.sub[a * 5 + b];
+        }
+        w[a] = acc;
+      }
+      w0[c] = pack16(w[0], w[1]);
+      w1[c] = pack16(w[2], w[3]);
+      w2[c] = pack16(w[4], in ? go : 0); // A's third pair is (nGap, 1): the 1 picks up gap_open
+      hop[c] = -(go + j * ge) - go;      // H[0][j+1] - gap_open
+      f[c] = DP_NEG_INF;
+    }
+    int diag_in = (j0 == 0 ? 0 : -(go + (j0 - 1) * ge)) - go; // H[0][j0] - gap_open
+    int ho_last = 0, e_last = DP_NEG_INF;
+    int bin_ho = 0, bin_e = DP_NEG_INF;
+    if(s > 0) {
+      // lane 63's stores of the previous stripe must be visible to every lane's loads
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+
+    for(int t = 0; t < steps; ++t) {
+      if((t & 63) == 0) {
+        // stage rows [t, t+63] of A: one coalesced 8-byte load per lane, expanded to int16 pairs
+        const int r = t + lane;
+        int4 v = make_int4(0, 0, 0, 0);
+        if(r < la) {
+          const u64 col = A[r];
+          v.x = (int)(col & 0xff) | ((int)((col >> 8) & 0xff) << 16);
+          v.y = (int)((col >> 16) & 0xff) | ((int)((col >> 24) & 0xff) << 16);
+          v.z = (int)((col >> 32) & 0xff) | (1 << 16);
+        }
+        ring[r & 127] = v;
+        if(s > 0) {
+          int2 b = make_int2(0, DP_NEG_INF);
+          if(r < la) {
+            b = bp[r];
+          }
+          bin_ho = b.x;
+          bin_e = b.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      // what the column left of the stripe hands to lane 0 for row t
+      int b_ho, b_e;
+      if(s == 0) {
+        b_ho = -(go + t * ge) - go; // H[t+1][0] - gap_open
+        b_e = DP_NEG_INF;
+      }
+      else {
+        b_ho = __builtin_amdgcn_readlane(bin_ho, t & 63);
+        b_e = __builtin_amdgcn_readlane(bin_e, t & 63);
+      }
+      const int ho_in = from_left(b_ho, ho_last);
+      const int e_in = from_left(b_e, e_last);
+      const int ii = t - lane; // this lane's row of A (0-based)
+      if(ii >= 0 && ii < la) {
+        const int4 a = ring[ii & 127];
+        int ho_left = ho_in, e = e_in, diag = diag_in;
+        unsigned acc = 0;
+#pragma unroll
+        for(int c = 0; c < C; ++c) {
+          // E: horizontal gap.  ties -> open
+          const int e_x = e - ge;
+          acc = __builtin_amdgcn_alignbit(acc, ho_left - e_x, 31); // bit = E extended
+          e = max(e_x, ho_left);
+          // F: vertical gap.  ties -> open
+          const int f_x = f[c] - ge;
+          acc = __builtin_amdgcn_alignbit(acc, hop[c] - f_x, 31); // bit = F extended
+          const int fv = max(f_x, hop[c]);
+          f[c] = fv;
+          // diagonal: H[i-1][j-1] - gap_open + s(i,j) + gap_open
+          const int d = dot2(a.x, w0[c], dot2(a.y, w1[c], dot2(a.z, w2[c], diag)));
+          const int m = max(e, fv);
+          acc = __builtin_amdgcn_alignbit(acc, d - m, 31);  // bit = not diagonal
+          acc = __builtin_amdgcn_alignbit(acc, e - fv, 31); // bit = F beats E
+          const int h = max(d, m);
+          diag = hop[c];
+          ho_left = h - go;
+          hop[c] = ho_left;
+        }
+        if(TRACE) {
+          tbp[((i64)s * steps + t) * 64 + lane] = acc;
+        }
+        ho_last = ho_left;
+        e_last = e;
+        diag_in = ho_in;
+        if(lane == 63 && s + 1 < n_stripes) {
+          bp[ii] = make_int2(ho_left, e);
+        }
+      }
+    }
+    if(s == n_stripes - 1) {
+      const int jj = lb - 1 - s * W;
+      const int cstar = jj % C;
+      int hv = hop[0];
+#pragma unroll
+      for(int c = 1; c < C; ++c) {
+        hv = c == cstar ? hop[c] : hv;
+      }
+      result = __builtin_amdgcn_readlane(hv, jj / C) + go;
+    }
+  }
+  if(lane == 0) {
+    scores[pair] = result;
+  }
+}
+
+// One lane per pair walks the stored decisions from (la, lb) back to (0, 0).  Ops are written right-aligned
+// into the pair's (la+lb)-byte slot: the path is its last n_ops bytes, in forward order.
+template <int C>
+__global__ void dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b, i64 first_pair, i64 n_pairs,
+                                    const i64 *__restrict__ tb_off, const unsigned *__restrict__ tb, unsigned char *__restrict__ ops,
+                                    int *__restrict__ n_ops) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= n_pairs) {
+    return;
+  }
+  const i64 pair = first_pair + k;
+  const int la = (int)(off_a[pair + 1] - off_a[pair]), lb = (int)(off_b[pair + 1] - off_b[pair]);
+  const unsigned *tbp = tb + tb_off[k];
+  unsigned char *out = ops + off_a[pair] + off_b[pair];
+  constexpr int W = 64 * C;
+  const i64 steps = la + 63;
+  int i = la, j = lb, n = 0, state = 0;
+  int at = la + lb;
+  while(i > 0 || j > 0) {
+    int op;
+    if(i == 0) {
+      op = 1;
+      --j;
+    }
+    else if(j == 0) {
+      op = 2;
+      --i;
+    }
+    else {
+      const int jj = j - 1;
+      const int s = jj / W, l = (jj % W) / C, c = jj % C;
+      const unsigned word = tbp[((i64)s * steps + (i - 1 + l)) * 64 + l];
+      const unsigned nib = (word >> (4 * (C - 1 - c))) & 15u;
+      if(state == 0) {
+        if(!(nib & 2u)) {
+          op = 0;
+          --i;
+          --j;
+        }
+        else {
+          state = (nib & 1u) ? 2 : 1;
+          continue;
+        }
+      }
+      else if(state == 1) {
+        op = 1;
+        if(!(nib & 8u)) {
+          state = 0;
+        }
+        --j;
+      }
+      else {
+        op = 2;
+        if(!(nib & 4u)) {
+          state = 0;
+        }
+        --i;
+      }
+    }
+    out[--at] = (unsigned char)op;
+    ++n;
+  }
+  n_ops[pair] = n;
+}
+
+} // namespace pm
+
+using namespace pm;
+
+struct pm_dp_batch {
+  int device = 0;
+  i64 n_pairs = 0, total_a = 0, total_b = 0;
+  std::vector<i64> off_a, off_b;
+  DevBuf cols_a, cols_b, d_off_a, d_off_b, bnd, scores, ops, n_ops, tb, d_tb_off;
+  std::vector<i64> chunk_first;            // first pair of each chunk, plus n_pairs
+  std::vector<std::vector<i64> > chunk_tb; // per chunk: word offsets of its pairs
+  i64 tb_words_cap = 0;
+  DpParamsD params;
+  i64 cells = 0;
+  hipStream_t last_stream = nullptr;
+};
+
+extern "C" {
+
+int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
+                       const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out) {
+  if(!out) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: null out");
+  }
+  *out = nullptr;
+  if(n_pairs < 0 || !off_a || !off_b || !params) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: null argument");
+  }
+  int rc = use_device(device);
+  if(rc) {
+    return rc;
+  }
+  if(off_a[0] != 0 || off_b[0] != 0) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: offsets must start at 0");
+  }
+  for(int64_t k = 0; k < n_pairs; ++k) {
+    if(off_a[k + 1] < off_a[k] || off_b[k + 1] < off_b[k] || off_a[k + 1] - off_a[k] > (1 << 24) || off_b[k + 1] - off_b[k] > (1 << 24)) {
+      return fail(PM_E_INVALID, "pm_dp_batch_create: bad profile length");
+    }
+  }
+  if((off_a[n_pairs] > 0 && !cols_a) || (off_b[n_pairs] > 0 && !cols_b)) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: null columns");
+  }
+  // int16 weights: |sum_b count * sub| must stay below 2^15 (255 rows x |sub| <= 127)
+  for(int k = 0; k < 25; ++k) {
+    if(params->sub[k] < -127 || params->sub[k] > 127) {
+      return fail(PM_E_INVALID, "pm_dp_batch_create: substitution entries must be within [-127, 127]");
+    }
+  }
+  if(params->gap_open < 0 || params->gap_open > 32767 || params->gap_extend < 0 || params->gap_extend > 32767) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: gap penalties must be within [0, 32767]");
+  }
+  pm_dp_batch *h = new(std::nothrow) pm_dp_batch();
+  if(!h) {
+    return fail(PM_E_INVALID, "out of host memory");
+  }
+  h->device = device;
+  h->n_pairs = n_pairs;
+  h->off_a.assign(off_a, off_a + n_pairs + 1);
+  h->off_b.assign(off_b, off_b + n_pairs + 1);
+  h->total_a = off_a[n_pairs];
+  h->total_b = off_b[n_pairs];
+  memcpy(h->params.sub, params->sub, sizeof h->params.sub);
+  h->params.go = params->gap_open;
+  h->params.ge = params->gap_extend;
+#define DTRY(x)               \
+  do {                        \
+    int rc_ = (x);            \
+    if(rc_) {                 \
+      pm_dp_batch_destroy(h); \
+      return rc_;             \
+    }                         \
+  } while(0)
+  hipStream_t stream = nullptr;
+  DTRY(h->cols_a.upload(cols_a, (size_t)h->total_a * 8, stream));
+  DTRY(h->cols_b.upload(cols_b, (size_t)h->total_b * 8, stream));
+  DTRY(h->d_off_a.upload(off_a, (size_t)(n_pairs + 1) * 8, stream));
+  DTRY(h->d_off_b.upload(off_b, (size_t)(n_pairs + 1) * 8, stream));
+  DTRY(h->bnd.alloc((size_t)h->total_a * 8));
+  DTRY(h->scores.alloc((size_t)n_pairs * 4));
+  DTRY(h->n_ops.alloc((size_t)n_pairs * 4));
+  DTRY(h->ops.alloc((size_t)(h->total_a + h->total_b)));
+  // chunks: consecutive pairs whose traceback fits the budget; the buffer is reused chunk after chunk
+  if(tb_budget_bytes <= 0) {
+    tb_budget_bytes = (int64_t)32 << 30;
+  }
+  i64 budget_words = tb_budget_bytes / 4;
+  h->chunk_first.push_back(0);
+  std::vector<i64> cur;
+  i64 used = 0;
+  for(i64 k = 0; k < n_pairs; ++k) {
+    i64 la = off_a[k + 1] - off_a[k], lb = off_b[k + 1] - off_b[k];
+    i64 need = dp_tb_words(la, lb, 8);
+    h->cells += la * lb;
+    if(!cur.empty() && used + need > budget_words) {
+      h->chunk_tb.push_back(cur);
+      h->chunk_first.push_back(k);
+      h->tb_words_cap = std::max(h->tb_words_cap, used);
+      cur.clear();
+      used = 0;
+    }
+    cur.push_back(used);
+    used += need;
+  }
+  h->chunk_tb.push_back(cur);
+  h->chunk_first.push_back(n_pairs);
+  h->tb_words_cap = std::max(h->tb_words_cap, used);
+  DTRY(h->tb.alloc((size_t)h->tb_words_cap * 4));
+  // per-chunk offset tables live back to back in one device array
+  {
+    std::vector<i64> flat;
+    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+      flat.insert(flat.end(), h->chunk_tb[c].begin(), h->chunk_tb[c].end());
+    }
+    DTRY(h->d_tb_off.upload(flat.data(), flat.size() * 8, stream));
+  }
+#undef DTRY
+  *out = h;
+  return PM_OK;
+}
+
+static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_trace) {
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float acc_fill = 0, acc_trace = 0;
+  bool timed = ms_fill || ms_trace;
+  if(timed) {
+    for(int k = 0; k < 3; ++k) {
+      PM_HIP(hipEventCreate(&ev[k]));
+    }
+  }
+  for(size_t c = 0; c + 1 < h->chunk_first.size(); ++c) {
+    i64 first = h->chunk_first[c], n = h->chunk_first[c + 1] - first;
+    if(n <= 0) {
+      continue;
+    }
+    const i64 *tb_off = (const i64 *)h->d_tb_off.p + first;
+    if(timed) {
+      PM_HIP(hipEventRecord(ev[0], stream));
+    }
+    if(traceback) {
+      dp_fill_kernel<8, true><<<(unsigned)n, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
+                                                              (const i64 *)h->d_off_b.p, first, tb_off, (unsigned *)h->tb.p,
+                                                              (int2 *)h->bnd.p, (int *)h->scores.p, h->params);
+    }
+    else {
+      dp_fill_kernel<8, false><<<(unsigned)n, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
+                                                               (const i64 *)h->d_off_b.p, first, tb_off, (unsigned *)h->tb.p,
+                                                               (int2 *)h->bnd.p, (int *)h->scores.p, h->params);
+    }
+    PM_HIP(hipGetLastError());
+    if(timed) {
+      PM_HIP(hipEventRecord(ev[1], stream));
+    }
+    if(traceback) {
+      dp_traceback_kernel<8><<<(unsigned)((n + 63) / 64), 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, n,
+                                                                           tb_off, (const unsigned *)h->tb.p, (unsigned char *)h->ops.p,
+                                                                           (int *)h->n_ops.p);
+      PM_HIP(hipGetLastError());
+    }
+    if(timed) {
+      PM_HIP(hipEventRecord(ev[2], stream));
+      PM_HIP(hipEventSynchronize(ev[2]));
+      float a = 0, b = 0;
+      PM_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
+      PM_HIP(hipEventElapsedTime(&b, ev[1], ev[2]));
+      acc_fill += a;
+      acc_trace += b;
+    }
+  }
+  if(timed) {
+    for(int k = 0; k < 3; ++k) {
+      (void)hipEventDestroy(ev[k]);
+    }
+  }
+  if(ms_fill) {
+    *ms_fill = acc_fill;
+  }
+  if(ms_trace) {
+    *ms_trace = acc_trace;
+  }
+  h->last_stream = stream;
+  return PM_OK;
+}
+
+int pm_dp_batch_run(pm_dp_batch_t *h, int traceback, void *hip_stream) {
+  if(!h) {
+    return fail(PM_E_INVALID, "pm_dp_batch_run: null batch");
+  }
+  int rc = use_device(h->device);
+  if(rc) {
+    return rc;
+  }
+  return dp_run(h, (hipStream_t)hip_stream, traceback, nullptr, nullptr);
+}
+
+int pm_dp_batch_run_profiled(pm_dp_batch_t *h, int traceback, void *hip_stream, float *ms_fill, float *ms_traceback) {
+  if(!h) {
+    return fail(PM_E_INVALID, "pm_dp_batch_run_profiled: null batch");
+  }
+  int rc = use_device(h->device);
+  if(rc) {
+    return rc;
+  }
+  float a = 0, b = 0;
+  rc = dp_run(h, (hipStream_t)hip_stream, traceback, &a, &b);
+  if(ms_fill) {
+    *ms_fill = a;
+  }
+  if(ms_traceback) {
+    *ms_traceback = b;
+  }
+  return rc;
+}
+
+int pm_dp_batch_fetch(pm_dp_batch_t *h, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
+  if(!h) {
+    return fail(PM_E_INVALID, "pm_dp_batch_fetch: null batch");
+  }
+  int rc = use_device(h->device);
+  if(rc) {
+    return rc;
+  }
+  PM_HIP(hipStreamSynchronize(h->last_stream));
+  if(scores && h->n_pairs > 0) {
+    PM_HIP(hipMemcpy(scores, h->scores.p, (size_t)h->n_pairs * 4, hipMemcpyDeviceToHost));
+  }
+  if(n_ops && h->n_pairs > 0) {
+    PM_HIP(hipMemcpy(n_ops, h->n_ops.p, (size_t)h->n_pairs * 4, hipMemcpyDeviceToHost));
+  }
+  if(ops && h->total_a + h->total_b > 0) {
+    PM_HIP(hipMemcpy(ops, h->ops.p, (size_t)(h->total_a + h->total_b), hipMemcpyDeviceToHost));
+  }
+  return PM_OK;
+}
+
+int pm_dp_batch_info(pm_dp_batch_t *h, int64_t *cells, int64_t *traceback_bytes_per_run, int64_t *input_bytes, int32_t *n_chunks) {
+  if(!h) {
+    return fail(PM_E_INVALID, "pm_dp_batch_info: null batch");
+  }
+  if(cells) {
+    *cells = h->cells;
+  }
+  if(traceback_bytes_per_run) {
+    i64 words = 0;
+    for(i64 k = 0; k < h->n_pairs; ++k) {
+      words += dp_tb_words(h->off_a[k + 1] - h->off_a[k], h->off_b[k + 1] - h->off_b[k], 8);
+    }
+    *traceback_bytes_per_run = words * 4;
+  }
+  if(input_bytes) {
+    // every stripe re-reads A's columns; B's columns are read once
+    i64 bytes = h->total_b * 8;
+    for(i64 k = 0; k < h->n_pairs; ++k) {
+      i64 lb = h->off_b[k + 1] - h->off_b[k];
+      bytes += ((lb + 511) / 512) * (h->off_a[k + 1] - h->off_a[k]) * 8;
+    }
+    *input_bytes = bytes;
+  }
+  if(n_chunks) {
+    *n_chunks = (int32_t)h->chunk_tb.size();
+  }
+  return PM_OK;
+}
+
+void pm_dp_batch_destroy(pm_dp_batch_t *h) {
+  if(!h) {
+    return;
+  }
+  (void)hipSetDevice(h->device);
+  delete h;
+}
+
+} // extern "C"

@@ -1,0 +1,225 @@
+"""Profile x profile affine-gap DP on the GPU (BASELINE.json's GCUPS metric): host-side wrapper.
+
+NO REFERENCE COUNTERPART.  orbitz/paramugsy has no DP, no scores and no traceback; the
+computation is specified by this repo (oracle/dp_oracle.h) and the HIP kernel is checked against this repo's
+own scalar oracle.  Everything here is plumbing around pm_dp_batch_* in libparamugsy_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+
+SYMBOLS = b"ACGT-"
+OP_M, OP_I, OP_D = 0, 1, 2
+
+
+class PmDpParams(C.Structure):
+    _fields_ = [("sub", C.c_int32 * 25), ("gap_open", C.c_int32), ("gap_extend", C.c_int32)]
+
+
+def make_params(rows_a: int, rows_b: int, match: int = 5, mismatch: int = -4, base_gap: int = -3,
+                open_per_pair: int = 8, extend_per_pair: int = 2) -> PmDpParams:
+    """Sum-of-pairs scoring: 5x5 matrix over A,C,G,T,gap and gap penalties scaled by the number of row pairs."""
+    p = PmDpParams()
+    for a in range(5):
+        for b in range(5):
+            if a == 4 and b == 4:
+                v = 0
+            elif a == 4 or b == 4:
+                v = base_gap
+            else:
+                v = match if a == b else mismatch
+            p.sub[a * 5 + b] = v
+    p.gap_open = open_per_pair * rows_a * rows_b
+    p.gap_extend = extend_per_pair * rows_a * rows_b
+    return p
+
+
+def pack_profile(rows: Sequence[bytes]) -> np.ndarray:
+    """Gapped row texts of one alignment block -> uint8 [columns, 8] packed columns {nA,nC,nG,nT,nGap,0,0,0}."""
+    n = len(rows[0])
+    out = np.zeros((n, 8), dtype=np.uint8)
+    for r in rows:
+        a = np.frombuffer(r.upper(), dtype=np.uint8)
+        assert len(a) == n
+        for k, ch in enumerate(SYMBOLS):
+            out[:, k] += (a == ch).astype(np.uint8)
+    return out
+
+
+def _lib():
+    l = capi.lib()
+    if not getattr(l, "_dp_bound", False):
+        l.pm_dp_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(PmDpParams), C.c_int64,
+                                         C.c_int, C.POINTER(C.c_void_p)]
+        l.pm_dp_batch_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        l.pm_dp_batch_run_profiled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.pm_dp_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.pm_dp_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        l.pm_dp_batch_destroy.argtypes = [C.c_void_p]
+        l.pm_dp_batch_destroy.restype = None
+        l._dp_bound = True
+    return l
+
+
+@dataclass
+class DpInputs:
+    cols_a: np.ndarray  # uint8 [total_a, 8]
+    off_a: np.ndarray   # int64 [n+1]
+    cols_b: np.ndarray
+    off_b: np.ndarray
+
+    @property
+    def n_pairs(self) -> int:
+        return len(self.off_a) - 1
+
+    @property
+    def cells(self) -> int:
+        return int((np.diff(self.off_a) * np.diff(self.off_b)).sum())
+
+
+class DpBatch:
+    """A batch of profile pairs resident in HBM (pm_dp_batch_*)."""
+
+    def __init__(self, inputs: DpInputs, params: PmDpParams, device: int = 0, tb_budget_bytes: int = 0):
+        l = _lib()
+        self.inputs = inputs
+        ca = np.ascontiguousarray(inputs.cols_a, dtype=np.uint8)
+        cb = np.ascontiguousarray(inputs.cols_b, dtype=np.uint8)
+        oa = np.ascontiguousarray(inputs.off_a, dtype=np.int64)
+        ob = np.ascontiguousarray(inputs.off_b, dtype=np.int64)
+        h = C.c_void_p()
+        capi.check(l.pm_dp_batch_create(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, len(oa) - 1, C.byref(params),
+                                        tb_budget_bytes, device, C.byref(h)))
+        self._h = h
+        self._oa, self._ob = oa, ob
+
+    def run(self, traceback: bool = True, stream: int = 0) -> None:
+        capi.check(_lib().pm_dp_batch_run(self._h, 1 if traceback else 0, C.c_void_p(stream)))
+
+    def run_profiled(self, traceback: bool = True, stream: int = 0) -> Tuple[float, float]:
+        a, b = C.c_float(), C.c_float()
+        capi.check(_lib().pm_dp_batch_run_profiled(self._h, 1 if traceback else 0, C.c_void_p(stream), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def info(self):
+        cells, tb, inp, chunks = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        capi.check(_lib().pm_dp_batch_info(self._h, C.byref(cells), C.byref(tb), C.byref(inp), C.byref(chunks)))
+        return {"cells": cells.value, "traceback_bytes": tb.value, "input_bytes": inp.value, "chunks": chunks.value}
+
+    def fetch(self, with_paths: bool = True):
+        n = len(self._oa) - 1
+        scores = np.zeros(n, dtype=np.int32)
+        n_ops = np.zeros(n, dtype=np.int32)
+        ops = np.zeros(int(self._oa[-1] + self._ob[-1]) if with_paths else 0, dtype=np.uint8)
+        capi.check(_lib().pm_dp_batch_fetch(self._h, scores.ctypes.data, ops.ctypes.data if with_paths else None,
+                                            n_ops.ctypes.data if with_paths else None))
+        return scores, ops, n_ops
+
+    def paths(self, ops: np.ndarray, n_ops: np.ndarray) -> List[np.ndarray]:
+        """Per-pair op arrays (first op first) from the right-aligned slots."""
+        out = []
+        for k in range(len(n_ops)):
+            end = int(self._oa[k + 1] + self._ob[k + 1])
+            out.append(ops[end - int(n_ops[k]):end])
+        return out
+
+    def close(self) -> None:
+        if self._h:
+            _lib().pm_dp_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- synthetic workloads
+
+def synth_pairs(seed: int, n_pairs: int, rows: int, length: int, sub_rate: float = 0.08, indel_rate: float = 0.01,
+                row_noise: float = 0.1, gap_col_rate: float = 0.05, vary_length: bool = False) -> DpInputs:
+    """`n_pairs` pairs of `rows`-row profiles, `length` columns each (PCG64, seeded).
+
+    A's consensus is uniform ACGT; B's consensus is A's with substitutions and short indels, cut or padded to
+    `length` (or, with vary_length, left at its natural length); each row copies its consensus with probability
+    1-row_noise, else a random base; a column of a row is a gap with probability gap_col_rate."""
+    rng = np.random.default_rng(seed)
+
+    def rows_to_counts(cons: np.ndarray) -> np.ndarray:
+        L = len(cons)
+        r = np.broadcast_to(cons, (rows, L)).copy()
+        noise = rng.random((rows, L)) < row_noise
+        r[noise] = rng.integers(0, 4, size=int(noise.sum()))
+        gaps = rng.random((rows, L)) < gap_col_rate
+        r[gaps] = 4
+        out = np.zeros((L, 8), dtype=np.uint8)
+        for s in range(5):
+            out[:, s] = (r == s).sum(axis=0)
+        return out
+
+    A, B, la, lb = [], [], [], []
+    for _ in range(n_pairs):
+        ca = rng.integers(0, 4, size=length)
+        cb = ca.copy()
+        subs = rng.random(length) < sub_rate
+        cb[subs] = rng.integers(0, 4, size=int(subs.sum()))
+        n_ind = rng.poisson(length * indel_rate)
+        for _k in range(int(n_ind)):
+            at = int(rng.integers(0, len(cb)))
+            ln = int(rng.geometric(0.5))
+            if rng.random() < 0.5:
+                cb = np.delete(cb, slice(at, at + ln))
+            else:
+                cb = np.insert(cb, at, rng.integers(0, 4, size=ln))
+        if not vary_length:
+            if len(cb) >= length:
+                cb = cb[:length]
+            else:
+                cb = np.concatenate([cb, rng.integers(0, 4, size=length - len(cb))])
+        if len(cb) == 0:
+            cb = rng.integers(0, 4, size=1)
+        A.append(rows_to_counts(ca))
+        B.append(rows_to_counts(cb))
+        la.append(len(ca))
+        lb.append(len(cb))
+    off_a = np.concatenate([[0], np.cumsum(la)]).astype(np.int64)
+    off_b = np.concatenate([[0], np.cumsum(lb)]).astype(np.int64)
+    return DpInputs(np.concatenate(A), off_a, np.concatenate(B), off_b)
+
+
+def synth_pairs_fast(seed: int, n_pairs: int, rows: int, length: int, sub_rate: float = 0.08, row_noise: float = 0.1,
+                     gap_col_rate: float = 0.05, shift_rate: float = 0.3) -> DpInputs:
+    """Vectorised generator for large benches: equal lengths; B = A's consensus with substitutions and, for a
+    fraction of pairs, a cyclic shift by a few columns (so optimal paths carry gaps)."""
+    rng = np.random.default_rng(seed)
+    L = length
+    ca = rng.integers(0, 4, size=(n_pairs, L), dtype=np.int8)
+    cb = ca.copy()
+    subs = rng.random((n_pairs, L)) < sub_rate
+    cb[subs] = rng.integers(0, 4, size=int(subs.sum()), dtype=np.int8)
+    shift = np.where(rng.random(n_pairs) < shift_rate, rng.integers(1, 6, size=n_pairs), 0)
+    for k in np.nonzero(shift)[0]:
+        cb[k] = np.roll(cb[k], int(shift[k]))
+
+    def counts(cons: np.ndarray) -> np.ndarray:
+        out = np.zeros((n_pairs, L, 8), dtype=np.uint8)
+        for _r in range(rows):
+            r = cons.copy()
+            noise = rng.random((n_pairs, L)) < row_noise
+            r[noise] = rng.integers(0, 4, size=int(noise.sum()), dtype=np.int8)
+            r[rng.random((n_pairs, L)) < gap_col_rate] = 4
+            for s in range(5):
+                out[:, :, s] += (r == s)
+        return out.reshape(n_pairs * L, 8)
+
+    off = (np.arange(n_pairs + 1, dtype=np.int64) * L)
+    return DpInputs(counts(ca), off, counts(cb), off.copy())

@@ -1,0 +1,117 @@
+"""Profile x profile DP on the GPU against this repo's scalar oracle (oracle/dp_oracle.c).
+NO REFERENCE COUNTERPART exists for this computation: "parity" here means kernel == this repo's own
+specification, bit-exact on int32 scores and on every traceback op."""
+import numpy as np
+import pytest
+
+from paramugsy_amd import dp
+
+pytestmark = pytest.mark.gpu
+
+
+def run_and_compare(inputs, params, tb_budget=0):
+    import pyoracle
+    batch = dp.DpBatch(inputs, params, tb_budget_bytes=tb_budget)
+    batch.run(traceback=True)
+    scores, ops, n_ops = batch.fetch()
+    o_scores, o_paths = pyoracle.dp_align(inputs, params)
+    assert np.array_equal(scores, o_scores)
+    paths = batch.paths(ops, n_ops)
+    for k in range(inputs.n_pairs):
+        assert np.array_equal(paths[k], o_paths[k]), "pair %d" % k
+    # score-only pass gives the same scores
+    batch.run(traceback=False)
+    s2, _, _ = batch.fetch(with_paths=False)
+    assert np.array_equal(s2, o_scores)
+    info = batch.info()
+    batch.close()
+    return scores, paths, info
+
+
+@pytest.mark.parametrize("rows,length", [(2, 100), (3, 700), (8, 513), (32, 300)])
+def test_equal_length_pairs(rows, length, oracle_build):
+    inputs = dp.synth_pairs(1000 + rows, 12, rows, length)
+    run_and_compare(inputs, dp.make_params(rows, rows))
+
+
+def test_ragged_lengths_and_stripe_edges(oracle_build):
+    # lengths around the stripe width (512 columns of B) and the LDS ring (64/128 rows of A), plus tiny profiles
+    rng = np.random.default_rng(5)
+    la = [1, 1, 2, 63, 64, 65, 127, 128, 129, 200, 511, 512, 513, 1025, 37, 300]
+    lb = [1, 5, 1, 512, 511, 513, 64, 1, 1024, 1030, 77, 512, 513, 40, 1500, 300]
+    cols = lambda n: np.concatenate([rng.integers(0, 4, size=(n, 5)).astype(np.uint8), np.zeros((n, 3), np.uint8)], axis=1)
+    A = [cols(n) for n in la]
+    B = [cols(n) for n in lb]
+    inputs = dp.DpInputs(np.concatenate(A), np.concatenate([[0], np.cumsum(la)]).astype(np.int64), np.concatenate(B),
+                         np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+    run_and_compare(inputs, dp.make_params(3, 3))
+
+
+def test_empty_profiles(oracle_build):
+    rng = np.random.default_rng(6)
+    la = [0, 5, 0, 7]
+    lb = [4, 0, 0, 7]
+    cols = lambda n: np.concatenate([rng.integers(0, 3, size=(n, 5)).astype(np.uint8), np.zeros((n, 3), np.uint8)], axis=1)
+    inputs = dp.DpInputs(np.concatenate([cols(n) for n in la]), np.concatenate([[0], np.cumsum(la)]).astype(np.int64),
+                         np.concatenate([cols(n) for n in lb]), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+    scores, paths, _ = run_and_compare(inputs, dp.make_params(2, 2))
+    assert [len(p) for p in paths] == [4, 5, 0, len(paths[3])]
+
+
+def test_varying_lengths_with_indels(oracle_build):
+    inputs = dp.synth_pairs(77, 40, 4, 400, indel_rate=0.03, vary_length=True)
+    scores, paths, _ = run_and_compare(inputs, dp.make_params(4, 4))
+    assert any((p != 0).any() for p in paths)  # some optimal paths carry gaps
+
+
+def test_chunked_workspace_gives_same_results(oracle_build):
+    inputs = dp.synth_pairs(78, 30, 2, 600)
+    params = dp.make_params(2, 2)
+    s1, p1, i1 = run_and_compare(inputs, params)
+    s2, p2, i2 = run_and_compare(inputs, params, tb_budget=3 << 20)  # forces several chunks
+    assert i1["chunks"] == 1 and i2["chunks"] > 3
+    assert np.array_equal(s1, s2) and all(np.array_equal(a, b) for a, b in zip(p1, p2))
+
+
+def test_general_substitution_matrix_and_zero_penalties(oracle_build):
+    rng = np.random.default_rng(8)
+    inputs = dp.synth_pairs(79, 10, 5, 250, vary_length=True)
+    p = dp.make_params(5, 5)
+    for k in range(25):
+        p.sub[k] = int(rng.integers(-9, 10))
+    run_and_compare(inputs, p)
+    p.gap_open = 0
+    p.gap_extend = 0
+    run_and_compare(inputs, p)  # all-ties regime: exercises every tie-break rule
+
+
+def test_full_size_properties_baseline_config_1(oracle_build):
+    """BASELINE.json configs[1] at a reduced pair count but full shape (2 rows x 1 kbp): scores equal the oracle's
+    two-row scorer on every pair; every reported path re-scores to the reported score and spans the pair."""
+    import pyoracle
+    inputs = dp.synth_pairs_fast(20261003, 512, 2, 1000)
+    params = dp.make_params(2, 2)
+    batch = dp.DpBatch(inputs, params)
+    batch.run(traceback=True)
+    scores, ops, n_ops = batch.fetch()
+    assert np.array_equal(scores, pyoracle.dp_scores(inputs, params))
+    paths = batch.paths(ops, n_ops)
+    for k in range(0, inputs.n_pairs, 7):
+        rc, s = pyoracle.dp_score_of_path(inputs, params, k, paths[k])
+        assert rc == 0 and s == scores[k]
+    batch.close()
+
+
+def test_big_profiles_8_rows_4k_columns(oracle_build):
+    """The north-star shape (8 rows x 4 kbp), a few pairs: scores vs the oracle's scorer, paths by re-scoring."""
+    import pyoracle
+    inputs = dp.synth_pairs_fast(11, 6, 8, 4096)
+    params = dp.make_params(8, 8)
+    batch = dp.DpBatch(inputs, params)
+    batch.run(traceback=True)
+    scores, ops, n_ops = batch.fetch()
+    assert np.array_equal(scores, pyoracle.dp_scores(inputs, params))
+    for k, p in enumerate(batch.paths(ops, n_ops)):
+        rc, s = pyoracle.dp_score_of_path(inputs, params, k, p)
+        assert rc == 0 and s == scores[k]
+    batch.close()

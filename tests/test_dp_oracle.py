@@ -1,0 +1,52 @@
+"""The DP oracle against an independent numpy restatement of the same specification (small cases), and its own
+internal consistency (full-matrix aligner vs two-row scorer vs path re-scoring).  CPU only.
+"Parity unpinned": there is no reference implementation of this DP."""
+import numpy as np
+import pytest
+
+from paramugsy_amd import dp
+
+NEG = -(1 << 29)
+
+
+def numpy_dp(a, b, p):
+    """Direct transcription of the recurrence in oracle/dp_oracle.h with Python ints."""
+    sub = np.array(list(p.sub), dtype=np.int64).reshape(5, 5)
+    la, lb = len(a), len(b)
+    go, ge = p.gap_open, p.gap_extend
+    H = [[0] * (lb + 1) for _ in range(la + 1)]
+    E = [[NEG] * (lb + 1) for _ in range(la + 1)]
+    F = [[NEG] * (lb + 1) for _ in range(la + 1)]
+    for j in range(1, lb + 1):
+        H[0][j] = -(go + (j - 1) * ge)
+    for i in range(1, la + 1):
+        H[i][0] = -(go + (i - 1) * ge)
+    for i in range(1, la + 1):
+        for j in range(1, lb + 1):
+            s = int(a[i - 1, :5].astype(np.int64) @ sub @ b[j - 1, :5].astype(np.int64))
+            E[i][j] = max(E[i][j - 1] - ge, H[i][j - 1] - go)
+            F[i][j] = max(F[i - 1][j] - ge, H[i - 1][j] - go)
+            H[i][j] = max(H[i - 1][j - 1] + s, E[i][j], F[i][j])
+    return H[la][lb]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_scores_match_numpy_transcription(seed, oracle_build):
+    import pyoracle
+    inputs = dp.synth_pairs(seed, 4, 3, 25, indel_rate=0.05, vary_length=True)
+    p = dp.make_params(3, 3)
+    scores, paths = pyoracle.dp_align(inputs, p)
+    fast = pyoracle.dp_scores(inputs, p)
+    for k in range(inputs.n_pairs):
+        a = inputs.cols_a[inputs.off_a[k]:inputs.off_a[k + 1]]
+        b = inputs.cols_b[inputs.off_b[k]:inputs.off_b[k + 1]]
+        assert scores[k] == numpy_dp(a, b, p) == fast[k]
+        rc, s = pyoracle.dp_score_of_path(inputs, p, k, paths[k])
+        assert rc == 0 and s == scores[k]
+        assert (paths[k] != 1).sum() == len(a) and (paths[k] != 2).sum() == len(b)
+
+
+def test_pack_profile_counts():
+    cols = dp.pack_profile([b"ACGT-N", b"AC-TTa", b"-CGTAa"])
+    assert cols[:, :5].tolist() == [[2, 0, 0, 0, 1], [0, 3, 0, 0, 0], [0, 0, 2, 0, 1], [0, 0, 0, 3, 0], [1, 0, 0, 1, 1], [2, 0, 0, 0, 0]]
+    assert (cols[:, 5:] == 0).all()
