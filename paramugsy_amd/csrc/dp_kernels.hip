@@ -131,10 +131,10 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
-    for(int t = 0; t < steps; ++t) {
-      if((t & 63) == 0) {
-        // stage rows [t, t+63] of A: one coalesced 8-byte load per lane, expanded to int16 pairs
-        const int r = t + lane;
+    for(int t0 = 0; t0 < steps; t0 += 64) {
+      {
+        // stage rows [t0, t0+63] of A: one coalesced 8-byte load per lane, expanded to int16 pairs
+        const int r = t0 + lane;
         int4 v = make_int4(0, 0, 0, 0);
         if(r < la) {
           const u64 col = A[r];
@@ -148,13 +148,16 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           if(r < la) {
             b = bp[r];
           }
-          bin_ho = b.x;
-          bin_e = b.y;
+          // consume the loaded values here, so the wait for them sits in this block (once per 64 steps) and
+          // not in front of the v_readlane of every step
+          asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(bin_ho), "=v"(bin_e) : "v"(b.x), "v"(b.y));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
+      const int t1 = min(t0 + 64, steps);
+      for(int t = t0; t < t1; ++t) {
       // what the column left of the stripe hands to lane 0 for row t
       int b_ho, b_e;
       if(s == 0) {
@@ -202,6 +205,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         if(lane == 63 && s + 1 < n_stripes) {
           bp[ii] = make_int2(ho_left, e);
         }
+      }
       }
     }
     if(s == n_stripes - 1) {
