@@ -172,7 +172,10 @@ def bench_dp(args, rank, world, local, torch, dist):
     ms_tb = sum(p[1] for p in prof) / len(prof)
     cells = info["cells"]
     alg_bytes = info["traceback_bytes"] + info["input_bytes"] + n * 4
-    valu_peak = 256 * 4 * 32 * 2.4e9  # lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz
+    # int32 VALU peak: every non-packed int32 VALU instruction measured at 4 cycles per wave64 instruction per
+    # SIMD (tools/ubench/valu_rates.hip, profiles/r01_valu_rates.txt) -> 16 lanes/clk x 4 SIMDs x 256 CUs x 2.4 GHz
+    valu_peak = 256 * 4 * 16 * 2.4e9
+    ops_per_cell = 16  # csrc/dp_kernels.hip: 3 dot2 + 3 E + 3 F + 6 H/flags + 1 (H - open)
     out = {
         "metric": "profile-DP GCUPS (global affine-gap profile x profile alignment, scores + traceback)",
         "value": cells * world * args.steps / dt / 1e9,
@@ -187,8 +190,8 @@ def bench_dp(args, rank, world, local, torch, dist):
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "dp_fill_kernel",
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "valu": {"ops_per_cell": 18, "achieved_Tops": cells * 18 / (ms_fill * 1e-3) / 1e12, "peak_Tops": valu_peak / 1e12,
-                              "frac": cells * 18 / (ms_fill * 1e-3) / valu_peak},
+                     "valu": {"ops_per_cell": ops_per_cell, "achieved_Tops": cells * ops_per_cell / (ms_fill * 1e-3) / 1e12,
+                              "peak_Tops": valu_peak / 1e12, "frac": cells * ops_per_cell / (ms_fill * 1e-3) / valu_peak},
                      "note": "max-plus recurrence: the fill kernel is bound by int32 VALU issue, not by HBM; the HBM fraction is reported as measured"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -160,7 +160,8 @@ int pm_translate_files(const char *left_dir, const char *right_dir, const char *
  * A profile is a run of 8-byte columns {nA, nC, nG, nT, nGap, 0, 0, 0} (how many rows hold each symbol).
  * Pair k aligns columns [off_a[k], off_a[k+1]) of cols_a with columns [off_b[k], off_b[k+1]) of cols_b,
  * globally, with affine gaps, int32 scores; recurrence and tie-breaking: oracle/dp_oracle.h.
- * Limits: |sub| <= 127, gap penalties in [0, 32767], profile length <= 2^24 columns, scores within +-2^29. */
+ * Limits: |sub| <= 127, gap penalties >= 0 with gap_open + gap_extend <= 32767, profile length <= 2^24 columns,
+ * (La + Lb) * gap_extend < 2^28, scores within +-2^28. */
 typedef struct pm_dp_params {
   int32_t sub[25]; /* sub[a*5+b], symbols A, C, G, T, gap */
   int32_t gap_open;

@@ -16,16 +16,21 @@
 //     int16 pairs and staged in a 128-row LDS ring; each lane reads its row with one ds_read_b128;
 //   * the column score is sum-of-pairs = 3 x v_dot2c_i32_i16 accumulating onto the diagonal (the last half
 //     lane of the third dot carries gap_open so that the stored H-gap_open needs no correction);
-//   * max-plus recurrence in int32 VALU (no MFMA: nothing to contract);
+//   * max-plus recurrence in int32 VALU (no MFMA: nothing to contract), carried in SKEWED coordinates
+//     V~[i][j] = V[i][j] + (i+j)*gap_extend for V in {H,E,F}: extending a gap then costs nothing
+//     (E~[i][j] = max(E~[i][j-1], H~[i][j-1] - (gap_open-gap_extend))), which removes the two "- gap_extend"
+//     subtractions per cell; every comparison is between values of one cell, so all decisions are unchanged, and
+//     the score is un-skewed once at the end;
 //   * traceback: 4 decision bits per cell, shifted into a word with v_alignbit_b32 (one op per bit), one
 //     coalesced 256-byte store per step: tb[stripe][step][lane];
 //   * stripe boundary (last column of a stripe, per row): written by lane 63, read back 64 rows at a time.
 // Algorithmic HBM traffic per cell: 0.5 byte of traceback written + (8 bytes per column of A per stripe +
 // 8 bytes per column of B) read, i.e. ~0.5 B/cell for kilobase profiles; the kernel is VALU-issue bound
-// (18 VALU ops per cell), not HBM bound.
+// (16 VALU ops per cell), not HBM bound.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -71,7 +76,8 @@ __global__ void __launch_bounds__(64)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, i64 first_pair, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
                int2 *__restrict__ bnd, int *__restrict__ scores, DpParamsD P) {
-  static_assert(C == 8, "one traceback word per lane per step");
+  static_assert(C % 8 == 0, "whole traceback words per lane per step");
+  constexpr int TBW = C / 8;
   __shared__ int4 ring[128];
   const int lane = threadIdx.x;
   const i64 pair = first_pair + blockIdx.x;
@@ -82,6 +88,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   unsigned *tbp = TRACE ? tb + tb_off[blockIdx.x] : nullptr;
   int2 *bp = bnd + a0;
   const int go = P.go, ge = P.ge;
+  const int gop = go - ge; // cost of opening over extending, the only gap constant left in skewed coordinates
   constexpr int W = 64 * C;
   const int n_stripes = (lb + W - 1) / W;
   const int steps = la + 63;
@@ -118,11 +125,11 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
       w0[c] = pack16(w[0], w[1]);
       w1[c] = pack16(w[2], w[3]);
-      w2[c] = pack16(w[4], in ? go : 0); // A's third pair is (nGap, 1): the 1 picks up gap_open
-      hop[c] = -(go + j * ge) - go;      // H[0][j+1] - gap_open
+      w2[c] = pack16(w[4], in ? go + ge : 0); // A's third pair is (nGap, 1): the 1 picks up gop + 2*ge
+      hop[c] = -2 * gop;                      // H~[0][j+1] - gop, H~[0][j] = -gop for j >= 1
       f[c] = DP_NEG_INF;
     }
-    int diag_in = (j0 == 0 ? 0 : -(go + (j0 - 1) * ge)) - go; // H[0][j0] - gap_open
+    int diag_in = (j0 == 0 ? 0 : -gop) - gop; // H~[0][j0] - gop
     int ho_last = 0, e_last = DP_NEG_INF;
     int bin_ho = 0, bin_e = DP_NEG_INF;
     if(s > 0) {
@@ -161,7 +168,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       // what the column left of the stripe hands to lane 0 for row t
       int b_ho, b_e;
       if(s == 0) {
-        b_ho = -(go + t * ge) - go; // H[t+1][0] - gap_open
+        b_ho = -2 * gop; // H~[t+1][0] - gop
         b_e = DP_NEG_INF;
       }
       else {
@@ -174,30 +181,39 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       if(ii >= 0 && ii < la) {
         const int4 a = ring[ii & 127];
         int ho_left = ho_in, e = e_in, diag = diag_in;
-        unsigned acc = 0;
+        unsigned accw[TBW];
+#pragma unroll
+        for(int k = 0; k < TBW; ++k) {
+          accw[k] = 0;
+        }
 #pragma unroll
         for(int c = 0; c < C; ++c) {
+          unsigned &acc = accw[c / 8];
           // E: horizontal gap.  ties -> open
-          const int e_x = e - ge;
-          acc = __builtin_amdgcn_alignbit(acc, ho_left - e_x, 31); // bit = E extended
-          e = max(e_x, ho_left);
+          acc = __builtin_amdgcn_alignbit(acc, ho_left - e, 31); // bit = E extended
+          e = max(e, ho_left);
           // F: vertical gap.  ties -> open
-          const int f_x = f[c] - ge;
-          acc = __builtin_amdgcn_alignbit(acc, hop[c] - f_x, 31); // bit = F extended
-          const int fv = max(f_x, hop[c]);
+          acc = __builtin_amdgcn_alignbit(acc, hop[c] - f[c], 31); // bit = F extended
+          const int fv = max(f[c], hop[c]);
           f[c] = fv;
-          // diagonal: H[i-1][j-1] - gap_open + s(i,j) + gap_open
+          // diagonal: (H~[i-1][j-1] - gop) + s(i,j) + gop + 2*ge
           const int d = dot2(a.x, w0[c], dot2(a.y, w1[c], dot2(a.z, w2[c], diag)));
           const int m = max(e, fv);
           acc = __builtin_amdgcn_alignbit(acc, d - m, 31);  // bit = not diagonal
           acc = __builtin_amdgcn_alignbit(acc, e - fv, 31); // bit = F beats E
           const int h = max(d, m);
           diag = hop[c];
-          ho_left = h - go;
+          ho_left = h - gop;
           hop[c] = ho_left;
         }
         if(TRACE) {
-          tbp[((i64)s * steps + t) * 64 + lane] = acc;
+          const i64 at = ((i64)s * steps + t) * 64 + lane;
+          if(TBW == 1) {
+            tbp[at] = accw[0];
+          }
+          else {
+            reinterpret_cast<uint2 *>(tbp)[at] = make_uint2(accw[0], accw[TBW - 1]);
+          }
         }
         ho_last = ho_left;
         e_last = e;
@@ -216,7 +232,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       for(int c = 1; c < C; ++c) {
         hv = c == cstar ? hop[c] : hv;
       }
-      result = __builtin_amdgcn_readlane(hv, jj / C) + go;
+      result = __builtin_amdgcn_readlane(hv, jj / C) + gop - (la + lb) * ge; // un-skew
     }
   }
   if(lane == 0) {
@@ -255,8 +271,8 @@ __global__ void dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__
     else {
       const int jj = j - 1;
       const int s = jj / W, l = (jj % W) / C, c = jj % C;
-      const unsigned word = tbp[((i64)s * steps + (i - 1 + l)) * 64 + l];
-      const unsigned nib = (word >> (4 * (C - 1 - c))) & 15u;
+      const unsigned word = tbp[(((i64)s * steps + (i - 1 + l)) * 64 + l) * (C / 8) + c / 8];
+      const unsigned nib = (word >> (4 * (7 - (c & 7)))) & 15u;
       if(state == 0) {
         if(!(nib & 2u)) {
           op = 0;
@@ -303,6 +319,7 @@ struct pm_dp_batch {
   i64 tb_words_cap = 0;
   DpParamsD params;
   i64 cells = 0;
+  int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
   hipStream_t last_stream = nullptr;
 };
 
@@ -338,14 +355,22 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
       return fail(PM_E_INVALID, "pm_dp_batch_create: substitution entries must be within [-127, 127]");
     }
   }
-  if(params->gap_open < 0 || params->gap_open > 32767 || params->gap_extend < 0 || params->gap_extend > 32767) {
-    return fail(PM_E_INVALID, "pm_dp_batch_create: gap penalties must be within [0, 32767]");
+  if(params->gap_open < 0 || params->gap_extend < 0 || params->gap_open + params->gap_extend > 32767) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: gap penalties must be >= 0 and gap_open + gap_extend <= 32767");
+  }
+  for(int64_t k = 0; k < n_pairs; ++k) {
+    if((off_a[k + 1] - off_a[k] + off_b[k + 1] - off_b[k]) * (int64_t)params->gap_extend >= (1 << 28)) {
+      return fail(PM_E_INVALID, "pm_dp_batch_create: (La + Lb) * gap_extend must stay below 2^28");
+    }
   }
   pm_dp_batch *h = new(std::nothrow) pm_dp_batch();
   if(!h) {
     return fail(PM_E_INVALID, "out of host memory");
   }
   h->device = device;
+  if(const char *e = getenv("PM_DP_COLS")) {
+    h->cols_per_lane = atoi(e) == 8 ? 8 : 16;
+  }
   h->n_pairs = n_pairs;
   h->off_a.assign(off_a, off_a + n_pairs + 1);
   h->off_b.assign(off_b, off_b + n_pairs + 1);
@@ -381,7 +406,7 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   i64 used = 0;
   for(i64 k = 0; k < n_pairs; ++k) {
     i64 la = off_a[k + 1] - off_a[k], lb = off_b[k + 1] - off_b[k];
-    i64 need = dp_tb_words(la, lb, 8);
+    i64 need = dp_tb_words(la, lb, h->cols_per_lane);
     h->cells += la * lb;
     if(!cur.empty() && used + need > budget_words) {
       h->chunk_tb.push_back(cur);
@@ -428,24 +453,42 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
     if(timed) {
       PM_HIP(hipEventRecord(ev[0], stream));
     }
-    if(traceback) {
-      dp_fill_kernel<8, true><<<(unsigned)n, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
-                                                              (const i64 *)h->d_off_b.p, first, tb_off, (unsigned *)h->tb.p,
-                                                              (int2 *)h->bnd.p, (int *)h->scores.p, h->params);
+#define DP_LAUNCH_FILL(CC, TR)                                                                                                     \
+  dp_fill_kernel<CC, TR><<<(unsigned)n, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p, \
+                                                         (const i64 *)h->d_off_b.p, first, tb_off, (unsigned *)h->tb.p, (int2 *)h->bnd.p, \
+                                                         (int *)h->scores.p, h->params)
+    if(h->cols_per_lane == 16) {
+      if(traceback) {
+        DP_LAUNCH_FILL(16, true);
+      }
+      else {
+        DP_LAUNCH_FILL(16, false);
+      }
     }
     else {
-      dp_fill_kernel<8, false><<<(unsigned)n, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
-                                                               (const i64 *)h->d_off_b.p, first, tb_off, (unsigned *)h->tb.p,
-                                                               (int2 *)h->bnd.p, (int *)h->scores.p, h->params);
+      if(traceback) {
+        DP_LAUNCH_FILL(8, true);
+      }
+      else {
+        DP_LAUNCH_FILL(8, false);
+      }
     }
+#undef DP_LAUNCH_FILL
     PM_HIP(hipGetLastError());
     if(timed) {
       PM_HIP(hipEventRecord(ev[1], stream));
     }
     if(traceback) {
-      dp_traceback_kernel<8><<<(unsigned)((n + 63) / 64), 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, n,
-                                                                           tb_off, (const unsigned *)h->tb.p, (unsigned char *)h->ops.p,
-                                                                           (int *)h->n_ops.p);
+      if(h->cols_per_lane == 16) {
+        dp_traceback_kernel<16><<<(unsigned)((n + 63) / 64), 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, n,
+                                                                              tb_off, (const unsigned *)h->tb.p, (unsigned char *)h->ops.p,
+                                                                              (int *)h->n_ops.p);
+      }
+      else {
+        dp_traceback_kernel<8><<<(unsigned)((n + 63) / 64), 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, n,
+                                                                             tb_off, (const unsigned *)h->tb.p, (unsigned char *)h->ops.p,
+                                                                             (int *)h->n_ops.p);
+      }
       PM_HIP(hipGetLastError());
     }
     if(timed) {
@@ -534,7 +577,7 @@ int pm_dp_batch_info(pm_dp_batch_t *h, int64_t *cells, int64_t *traceback_bytes_
   if(traceback_bytes_per_run) {
     i64 words = 0;
     for(i64 k = 0; k < h->n_pairs; ++k) {
-      words += dp_tb_words(h->off_a[k + 1] - h->off_a[k], h->off_b[k + 1] - h->off_b[k], 8);
+      words += dp_tb_words(h->off_a[k + 1] - h->off_a[k], h->off_b[k + 1] - h->off_b[k], h->cols_per_lane);
     }
     *traceback_bytes_per_run = words * 4;
   }
@@ -543,7 +586,8 @@ int pm_dp_batch_info(pm_dp_batch_t *h, int64_t *cells, int64_t *traceback_bytes_
     i64 bytes = h->total_b * 8;
     for(i64 k = 0; k < h->n_pairs; ++k) {
       i64 lb = h->off_b[k + 1] - h->off_b[k];
-      bytes += ((lb + 511) / 512) * (h->off_a[k + 1] - h->off_a[k]) * 8;
+      i64 W = 64 * h->cols_per_lane;
+      bytes += ((lb + W - 1) / W) * (h->off_a[k + 1] - h->off_a[k]) * 8;
     }
     *input_bytes = bytes;
   }
