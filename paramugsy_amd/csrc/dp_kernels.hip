@@ -240,69 +240,86 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   }
 }
 
-// One lane per pair walks the stored decisions from (la, lb) back to (0, 0).  Ops are written right-aligned
-// into the pair's (la+lb)-byte slot: the path is its last n_ops bytes, in forward order.
+// One wavefront per pair walks the stored decisions from (la, lb) back to (0, 0).  A lane-per-pair walk pays
+// one dependent HBM load per step; here the 64 lanes fetch the decisions of the next 64 cells along the current
+// direction (diagonal in state H, along the row in state E, along the column in state F) in one gather, a
+// ballot finds how far the run continues, and the whole run is emitted at once.  The path is written
+// right-aligned into the pair's (la+lb)-byte slot: its last n_ops bytes, first op first.
 template <int C>
-__global__ void dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b, i64 first_pair, i64 n_pairs,
-                                    const i64 *__restrict__ tb_off, const unsigned *__restrict__ tb, unsigned char *__restrict__ ops,
-                                    int *__restrict__ n_ops) {
-  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if(k >= n_pairs) {
-    return;
-  }
-  const i64 pair = first_pair + k;
+__global__ void __launch_bounds__(64)
+dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b, i64 first_pair, const i64 *__restrict__ tb_off,
+                    const unsigned *__restrict__ tb, unsigned char *__restrict__ ops, int *__restrict__ n_ops) {
+  const int lane = threadIdx.x;
+  const i64 pair = first_pair + blockIdx.x;
   const int la = (int)(off_a[pair + 1] - off_a[pair]), lb = (int)(off_b[pair + 1] - off_b[pair]);
-  const unsigned *tbp = tb + tb_off[k];
+  const unsigned *tbp = tb + tb_off[blockIdx.x];
   unsigned char *out = ops + off_a[pair] + off_b[pair];
   constexpr int W = 64 * C;
   const i64 steps = la + 63;
-  int i = la, j = lb, n = 0, state = 0;
+  int i = la, j = lb, state = 0; // wave-uniform
   int at = la + lb;
-  while(i > 0 || j > 0) {
-    int op;
-    if(i == 0) {
-      op = 1;
-      --j;
+  int guard = 2 * (la + lb) + 8; // every iteration but a state switch consumes a cell; a switch is followed by one
+  while(i > 0 && j > 0 && guard-- > 0) {
+    const int di = state != 1, dj = state != 2; // H: diagonal, E: along the row, F: along the column
+    const int ci = i - lane * di, cj = j - lane * dj;
+    const bool valid = ci >= 1 && cj >= 1;
+    unsigned nib = 0;
+    if(valid) {
+      const int jj = cj - 1;
+      const int s = jj / W, l = (jj % W) / C, c = jj % C;
+      const unsigned word = tbp[(((i64)s * steps + (ci - 1 + l)) * 64 + l) * (C / 8) + c / 8];
+      nib = (word >> (4 * (7 - (c & 7)))) & 15u;
     }
-    else if(j == 0) {
-      op = 2;
-      --i;
+    // a lane continues the run when its cell keeps the walk going in the same direction and state
+    const unsigned keep = state == 0 ? (~nib & 2u) : (state == 1 ? (nib & 8u) : (nib & 4u));
+    const unsigned long long cont = __ballot(valid && keep != 0);
+    const unsigned long long vmask = __ballot(valid);
+    const int run = cont == ~0ull ? 64 : __builtin_ctzll(~cont);
+    if(state == 0) {
+      if(run == 0) { // the cell itself is not diagonal: switch to the gap state it names, no move
+        const unsigned n0 = (unsigned)__builtin_amdgcn_readlane((int)nib, 0);
+        state = (n0 & 1u) ? 2 : 1;
+        continue;
+      }
+      if(lane < run) {
+        out[at - 1 - lane] = 0;
+      }
+      at -= run;
+      i -= run;
+      j -= run;
     }
     else {
-      const int jj = j - 1;
-      const int s = jj / W, l = (jj % W) / C, c = jj % C;
-      const unsigned word = tbp[(((i64)s * steps + (i - 1 + l)) * 64 + l) * (C / 8) + c / 8];
-      const unsigned nib = (word >> (4 * (7 - (c & 7)))) & 15u;
-      if(state == 0) {
-        if(!(nib & 2u)) {
-          op = 0;
-          --i;
-          --j;
-        }
-        else {
-          state = (nib & 1u) ? 2 : 1;
-          continue;
-        }
+      // the cells that extend are consumed in this state; the first one that does not is consumed too and
+      // returns the walk to H
+      int take = run;
+      int next = state;
+      if(run < 64 && ((vmask >> run) & 1ull)) {
+        take = run + 1;
+        next = 0;
       }
-      else if(state == 1) {
-        op = 1;
-        if(!(nib & 8u)) {
-          state = 0;
-        }
-        --j;
+      if(lane < take) {
+        out[at - 1 - lane] = (unsigned char)state; // 1 = I (state E), 2 = D (state F)
+      }
+      at -= take;
+      if(state == 1) {
+        j -= take;
       }
       else {
-        op = 2;
-        if(!(nib & 4u)) {
-          state = 0;
-        }
-        --i;
+        i -= take;
       }
+      state = next;
     }
-    out[--at] = (unsigned char)op;
-    ++n;
   }
-  n_ops[pair] = n;
+  // one profile exhausted: the rest is a single gap run
+  const int rest = i + j;
+  const unsigned char op = i == 0 ? 1 : 2;
+  for(int k = lane; k < rest; k += 64) {
+    out[at - 1 - k] = op;
+  }
+  at -= rest;
+  if(lane == 0) {
+    n_ops[pair] = la + lb - at;
+  }
 }
 
 } // namespace pm
@@ -480,14 +497,12 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
     }
     if(traceback) {
       if(h->cols_per_lane == 16) {
-        dp_traceback_kernel<16><<<(unsigned)((n + 63) / 64), 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, n,
-                                                                              tb_off, (const unsigned *)h->tb.p, (unsigned char *)h->ops.p,
-                                                                              (int *)h->n_ops.p);
+        dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off,
+                                                                (const unsigned *)h->tb.p, (unsigned char *)h->ops.p, (int *)h->n_ops.p);
       }
       else {
-        dp_traceback_kernel<8><<<(unsigned)((n + 63) / 64), 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, n,
-                                                                             tb_off, (const unsigned *)h->tb.p, (unsigned char *)h->ops.p,
-                                                                             (int *)h->n_ops.p);
+        dp_traceback_kernel<8><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off,
+                                                               (const unsigned *)h->tb.p, (unsigned char *)h->ops.p, (int *)h->n_ops.p);
       }
       PM_HIP(hipGetLastError());
     }
