@@ -64,11 +64,11 @@ __device__ __forceinline__ int from_left(int lane0, int v) {
   return __builtin_amdgcn_update_dpp(lane0, v, DPP_WAVE_SHR1, 0xf, 0xf, false);
 }
 
-// Words of traceback one pair needs: stripes x (la + 64) steps x 64 lanes x C/8 words.
+// Words of traceback one pair needs: stripes x (la + 63) steps x 64 lanes (C = 8: one word per lane per step).
 __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
   i64 W = 64 * C;
   i64 stripes = (lb + W - 1) / W;
-  return stripes * (la + 64) * 64 * (C / 8);
+  return stripes * (la + 63) * 64 * (C / 8);
 }
 
 template <int C, bool TRACE>
@@ -86,15 +86,12 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const u64 *A = cols_a + a0;
   const u64 *B = cols_b + b0;
   unsigned *tbp = TRACE ? tb + tb_off[blockIdx.x] : nullptr;
-  int2 *bp = bnd + a0 + pair; // la + 1 rows per pair (row 0 is the boundary row)
+  int2 *bp = bnd + a0;
   const int go = P.go, ge = P.ge;
   const int gop = go - ge; // cost of opening over extending, the only gap constant left in skewed coordinates
   constexpr int W = 64 * C;
   const int n_stripes = (lb + W - 1) / W;
-  // Rows: 0 is the DP's boundary row, computed like any other row from an all-zero column of A and a state that
-  // starts at -infinity; rows < 0 and > la are idle rows on the same all-zero column.  Every lane therefore runs
-  // the same code on every step (lane l is on row t - l): no divergence, no predicated state.
-  const int steps = la + 64;
+  const int steps = la + 63;
   int result = 0;
   if(la == 0 || lb == 0) { // one profile empty: a single gap run
     int n = la + lb;
@@ -103,9 +100,6 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     }
     return;
   }
-  const int s_last = n_stripes - 1;
-  const int jlast = lb - 1 - s_last * W; // column of B that holds the score, within the last stripe
-  const int t_star = la + jlast / C;      // step at which its lane is on row la
 
   for(int s = 0; s < n_stripes; ++s) {
     const int j0 = s * W + lane * C; // this lane's first column of B (0-based)
@@ -131,14 +125,13 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
       w0[c] = pack16(w[0], w[1]);
       w1[c] = pack16(w[2], w[3]);
-      w2[c] = pack16(w[4], in ? go + ge : 0); // A's third pair is (nGap, 1) on real rows: the 1 picks up gop + 2*ge
-      hop[c] = DP_NEG_INF;                    // state above the boundary row
+      w2[c] = pack16(w[4], in ? go + ge : 0); // A's third pair is (nGap, 1): the 1 picks up gop + 2*ge
+      hop[c] = -2 * gop;                      // H~[0][j+1] - gop, H~[0][j] = -gop for j >= 1
       f[c] = DP_NEG_INF;
     }
-    int diag_in = DP_NEG_INF;
-    int ho_last = DP_NEG_INF, e_last = DP_NEG_INF;
-    int bin_ho = DP_NEG_INF, bin_e = DP_NEG_INF;
-    ring[64 + lane] = make_int4(0, 0, 0, 0); // rows -63..-1
+    int diag_in = (j0 == 0 ? 0 : -gop) - gop; // H~[0][j0] - gop
+    int ho_last = 0, e_last = DP_NEG_INF;
+    int bin_ho = 0, bin_e = DP_NEG_INF;
     if(s > 0) {
       // lane 63's stores of the previous stripe must be visible to every lane's loads
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -147,20 +140,19 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
 
     for(int t0 = 0; t0 < steps; t0 += 64) {
       {
-        // stage rows [t0, t0+63]: row r >= 1 is column r-1 of A (one coalesced 8-byte load per lane, expanded to
-        // int16 pairs); row 0 and rows past la are the all-zero column
+        // stage rows [t0, t0+63] of A: one coalesced 8-byte load per lane, expanded to int16 pairs
         const int r = t0 + lane;
         int4 v = make_int4(0, 0, 0, 0);
-        if(r >= 1 && r <= la) {
-          const u64 col = A[r - 1];
+        if(r < la) {
+          const u64 col = A[r];
           v.x = (int)(col & 0xff) | ((int)((col >> 8) & 0xff) << 16);
           v.y = (int)((col >> 16) & 0xff) | ((int)((col >> 24) & 0xff) << 16);
           v.z = (int)((col >> 32) & 0xff) | (1 << 16);
         }
         ring[r & 127] = v;
         if(s > 0) {
-          int2 b = make_int2(DP_NEG_INF, DP_NEG_INF);
-          if(r <= la) {
+          int2 b = make_int2(0, DP_NEG_INF);
+          if(r < la) {
             b = bp[r];
           }
           // consume the loaded values here, so the wait for them sits in this block (once per 64 steps) and
@@ -173,37 +165,30 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
       const int t1 = min(t0 + 64, steps);
       for(int t = t0; t < t1; ++t) {
-        // what the column left of the stripe hands to lane 0 for row t: H~ - gop and E~ of that column
-        int b_ho, b_e;
-        if(s == 0) {
-          b_ho = t == 0 ? -gop : -2 * gop; // H~[0][0] = 0, H~[t][0] = -gop
-          b_e = DP_NEG_INF;
-        }
-        else {
-          b_ho = __builtin_amdgcn_readlane(bin_ho, t & 63);
-          b_e = __builtin_amdgcn_readlane(bin_e, t & 63);
-        }
-        const int ho_in = from_left(b_ho, ho_last);
-        const int e_in = from_left(b_e, e_last);
-        const int ii = t - lane; // this lane's row
+      // what the column left of the stripe hands to lane 0 for row t
+      int b_ho, b_e;
+      if(s == 0) {
+        b_ho = -2 * gop; // H~[t+1][0] - gop
+        b_e = DP_NEG_INF;
+      }
+      else {
+        b_ho = __builtin_amdgcn_readlane(bin_ho, t & 63);
+        b_e = __builtin_amdgcn_readlane(bin_e, t & 63);
+      }
+      const int ho_in = from_left(b_ho, ho_last);
+      const int e_in = from_left(b_e, e_last);
+      const int ii = t - lane; // this lane's row of A (0-based)
+      if(ii >= 0 && ii < la) {
         const int4 a = ring[ii & 127];
-        int ho_left = ho_in, e = e_in;
+        int ho_left = ho_in, e = e_in, diag = diag_in;
         unsigned accw[TBW];
 #pragma unroll
         for(int k = 0; k < TBW; ++k) {
           accw[k] = 0;
         }
-        // diagonal term of cell c: (H~[i-1][j-1] - gop) + s(i,j) + gop + 2*ge.  It depends only on the previous
-        // row, so the one for cell c+1 is formed from hop[c] BEFORE cell c overwrites hop[c]: the per-column state
-        // is then updated in place, with no register copies.
-        int d = dot2(a.x, w0[0], dot2(a.y, w1[0], dot2(a.z, w2[0], diag_in)));
 #pragma unroll
         for(int c = 0; c < C; ++c) {
           unsigned &acc = accw[c / 8];
-          int d_next = 0;
-          if(c + 1 < C) {
-            d_next = dot2(a.x, w0[c + 1], dot2(a.y, w1[c + 1], dot2(a.z, w2[c + 1], hop[c])));
-          }
           // E: horizontal gap.  ties -> open
           acc = __builtin_amdgcn_alignbit(acc, ho_left - e, 31); // bit = E extended
           e = max(e, ho_left);
@@ -211,13 +196,15 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           acc = __builtin_amdgcn_alignbit(acc, hop[c] - f[c], 31); // bit = F extended
           const int fv = max(f[c], hop[c]);
           f[c] = fv;
+          // diagonal: (H~[i-1][j-1] - gop) + s(i,j) + gop + 2*ge
+          const int d = dot2(a.x, w0[c], dot2(a.y, w1[c], dot2(a.z, w2[c], diag)));
           const int m = max(e, fv);
           acc = __builtin_amdgcn_alignbit(acc, d - m, 31);  // bit = not diagonal
           acc = __builtin_amdgcn_alignbit(acc, e - fv, 31); // bit = F beats E
           const int h = max(d, m);
+          diag = hop[c];
           ho_left = h - gop;
           hop[c] = ho_left;
-          d = d_next;
         }
         if(TRACE) {
           const i64 at = ((i64)s * steps + t) * 64 + lane;
@@ -231,19 +218,21 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         ho_last = ho_left;
         e_last = e;
         diag_in = ho_in;
-        if(lane == 63 && ii >= 0 && s < s_last) {
+        if(lane == 63 && s + 1 < n_stripes) {
           bp[ii] = make_int2(ho_left, e);
         }
-        if(s == s_last && t == t_star) { // wave-uniform: the score's lane has just finished row la
-          const int cstar = jlast % C;
-          int hv = hop[0];
-#pragma unroll
-          for(int c = 1; c < C; ++c) {
-            hv = c == cstar ? hop[c] : hv;
-          }
-          result = __builtin_amdgcn_readlane(hv, jlast / C) + gop - (la + lb) * ge; // un-skew
-        }
       }
+      }
+    }
+    if(s == n_stripes - 1) {
+      const int jj = lb - 1 - s * W;
+      const int cstar = jj % C;
+      int hv = hop[0];
+#pragma unroll
+      for(int c = 1; c < C; ++c) {
+        hv = c == cstar ? hop[c] : hv;
+      }
+      result = __builtin_amdgcn_readlane(hv, jj / C) + gop - (la + lb) * ge; // un-skew
     }
   }
   if(lane == 0) {
@@ -266,7 +255,7 @@ dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b
   const unsigned *tbp = tb + tb_off[blockIdx.x];
   unsigned char *out = ops + off_a[pair] + off_b[pair];
   constexpr int W = 64 * C;
-  const i64 steps = la + 64;
+  const i64 steps = la + 63;
   int i = la, j = lb, state = 0; // wave-uniform
   int at = la + lb;
   int guard = 2 * (la + lb) + 8; // every iteration but a state switch consumes a cell; a switch is followed by one
@@ -278,7 +267,7 @@ dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b
     if(valid) {
       const int jj = cj - 1;
       const int s = jj / W, l = (jj % W) / C, c = jj % C;
-      const unsigned word = tbp[(((i64)s * steps + (ci + l)) * 64 + l) * (C / 8) + c / 8];
+      const unsigned word = tbp[(((i64)s * steps + (ci - 1 + l)) * 64 + l) * (C / 8) + c / 8];
       nib = (word >> (4 * (7 - (c & 7)))) & 15u;
     }
     // a lane continues the run when its cell keeps the walk going in the same direction and state
@@ -420,7 +409,7 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   DTRY(h->cols_b.upload(cols_b, (size_t)h->total_b * 8, stream));
   DTRY(h->d_off_a.upload(off_a, (size_t)(n_pairs + 1) * 8, stream));
   DTRY(h->d_off_b.upload(off_b, (size_t)(n_pairs + 1) * 8, stream));
-  DTRY(h->bnd.alloc((size_t)(h->total_a + n_pairs) * 8));
+  DTRY(h->bnd.alloc((size_t)h->total_a * 8));
   DTRY(h->scores.alloc((size_t)n_pairs * 4));
   DTRY(h->n_ops.alloc((size_t)n_pairs * 4));
   DTRY(h->ops.alloc((size_t)(h->total_a + h->total_b)));
