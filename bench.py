@@ -89,6 +89,28 @@ def timed_region(torch, dist, fn, steps, warmup):
     return dt
 
 
+def measured_traffic(kernel_substr, config_key):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/pmc_traffic.json), if the bench
+    configuration is the profiled one.  rocprofv3 cannot run inside bench.py; the file is written by
+    tools/summarize_prof.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same script.
+    FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes: MI355X_MICROARCH.md, HBM); both
+    counters are in KB."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    entry = table.get(config_key)
+    if not entry:
+        return None
+    for name, c in entry.items():
+        if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return int((2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
+    return None
+
+
 def bench_translate(args, rank, world, local, torch, dist):
     from paramugsy_amd import synth
     from paramugsy_amd.translate import TranslateJob, Workload
@@ -113,6 +135,8 @@ def bench_translate(args, rank, world, local, torch, dist):
     # the dominant kernel is whichever of the two unit passes is longer; both read the same tables, the emit
     # pass also writes the entries and offsets
     dom_ms = max(ms_count, ms_emit)
+    dom_name = "translate_kernel<true>" if ms_emit >= ms_count else "translate_kernel<false>"
+    tr_key = "translate:%d:%d:%d:%d:%d" % (args.tr_genomes, args.tr_genome_len, args.tr_blocks, args.tr_deltas, args.tr_entries)
     out = {
         "metric": "translate work units/s (delta entry x left row x right row; m_translate.cc:625-647)",
         "value": units * world * args.steps / dt,
@@ -124,8 +148,8 @@ def bench_translate(args, rank, world, local, torch, dist):
                    "units_per_rank": units, "entries_out": n_ent, "offsets_out": n_off},
         "kernel_ms": {"translate_kernel<count>": ms_count, "rocprim_scan_x2": ms_scan, "translate_kernel<emit>": ms_emit},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "translate_kernel<emit>" if ms_emit >= ms_count else "translate_kernel<count>",
+                     "frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(dom_name, tr_key),
+                     "kernel": dom_name,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "latency/divergence-bound integer state machine, one lane per unit; not an HBM-bound kernel (SURVEY 8d)"},
     }
@@ -171,7 +195,9 @@ def bench_dp(args, rank, world, local, torch, dist):
     ms_fill = sum(p[0] for p in prof) / len(prof)
     ms_tb = sum(p[1] for p in prof) / len(prof)
     cells = info["cells"]
-    alg_bytes = info["traceback_bytes"] + info["input_bytes"] + n * 4
+    # algorithmic bytes per launch: 0.5 byte of decisions per cell + the packed columns read
+    # (B once, A once per stripe) + the scores; the skew padding of the decision buffer is not counted
+    alg_bytes = cells // 2 + info["input_bytes"] + n * 4
     # int32 VALU peak: every non-packed int32 VALU instruction measured at 4 cycles per wave64 instruction per
     # SIMD (tools/ubench/valu_rates.hip, profiles/r01_valu_rates.txt) -> 16 lanes/clk x 4 SIMDs x 256 CUs x 2.4 GHz
     valu_peak = 256 * 4 * 16 * 2.4e9
@@ -188,7 +214,8 @@ def bench_dp(args, rank, world, local, torch, dist):
                    "reference_counterpart": "none: the reference has no DP (SURVEY.md 0); specification and oracle are this repo's own"},
         "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_traceback_kernel": ms_tb},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg_bytes / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "dp_fill_kernel",
+                     "frac": alg_bytes / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": measured_traffic("dp_fill_kernel", "dp:%d:%d:%d" % (n, rows, L)), "kernel": "dp_fill_kernel",
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "valu": {"ops_per_cell": ops_per_cell, "achieved_Tops": cells * ops_per_cell / (ms_fill * 1e-3) / 1e12,
                               "peak_Tops": valu_peak / 1e12, "frac": cells * ops_per_cell / (ms_fill * 1e-3) / valu_peak},

@@ -3,6 +3,7 @@
 
   summarize_prof.py stats <dir> <out.csv>          kernel_stats.csv with kernel names cut to 100 chars
   summarize_prof.py pmc <out.json> <label>=<dir>...  per-kernel averages of every counter found, KB units as rocprofv3 reports them
+  summarize_prof.py traffic profiles/pmc_traffic.json <config key> fetch=<dir> write=<dir>   table bench.py reads `traffic` from
 """
 import collections
 import csv
@@ -34,8 +35,21 @@ def pmc(out, pairs):
     json.dump(res, open(out, "w"), indent=1)
 
 
+def traffic(out, key, pairs):
+    """Merge the FETCH_SIZE / WRITE_SIZE means of one bench configuration into profiles/pmc_traffic.json under `key`
+    (the key bench.py builds from its workload arguments)."""
+    tmp = out + ".tmp"
+    pmc(tmp, pairs)
+    table = json.load(open(out)) if os.path.exists(out) else {}
+    table[key] = json.load(open(tmp))
+    os.unlink(tmp)
+    json.dump(table, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4:])
     else:
         pmc(sys.argv[2], sys.argv[3:])
