@@ -112,6 +112,11 @@ translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_
   if(u >= n_units) {
     return;
   }
+  if(EMIT) {
+    if(ent_off[u + 1] == ent_off[u] && off_off[u + 1] == off_off[u]) {
+      return; // the count pass found nothing to write for this unit (most left x right pairs of an entry)
+    }
+  }
   Sink<EMIT> sink;
   sink.n_ent = sink.n_off = sink.pend = sink.wpos = sink.last_start = 0;
   sink.last_row = 0;
