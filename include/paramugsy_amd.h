@@ -152,6 +152,15 @@ void pm_workload_destroy(pm_workload_t *w);
 int pm_translate_files(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                        const char *out_path, int device);
 
+/* The two tools of lib/profiles_cpp that compile upstream (nothing in the reference invokes them).
+ * pm_sort_delta   == m_sort_delta (lib/profiles_cpp/m_sort_delta.cc:58-91): delta text in, the same entries sorted by
+ *                    (header pair, ref start, query start, ref end, query end) out; like upstream no file header is
+ *                    written.  in_path/out_path NULL = stdin/stdout.
+ * pm_maf_analyzer == maf_analyzer <maf> (lib/profiles_cpp/maf_analyzer.cc:12-38): per genome the ranges NOT covered
+ *                    by the MAF's rows, upstream's arithmetic quirks included (maf_analyzer_missing.cc:115,119-126). */
+int pm_sort_delta(const char *in_path, const char *out_path, int device);
+int pm_maf_analyzer(const char *maf_path, const char *out_path, int device);
+
 /* ------------------------------------------------------------------------------------------------------
  * Profile x profile DP (BASELINE.json's GCUPS metric).  NO REFERENCE COUNTERPART: the reference has no DP, no
  * scores, no traceback; this interface and the computation behind it are specified by this

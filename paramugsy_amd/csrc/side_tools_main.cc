@@ -1,0 +1,31 @@
+// side_tools_main.cc -- drop-in executables for the two lib/profiles_cpp tools that compile upstream:
+//   m_sort_delta  < in.delta > out.delta      (lib/profiles_cpp/m_sort_delta.cc:73-91)
+//   maf_analyzer  <maf>       > report        (lib/profiles_cpp/maf_analyzer.cc:12-38)
+// Same command lines and output bytes; the work runs on the GPU through the C ABI.  PARAMUGSY_DEVICE selects the device.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/paramugsy_amd.h"
+
+int main(int argc, char **argv) {
+  const char *dev_env = getenv("PARAMUGSY_DEVICE");
+  int device = dev_env ? atoi(dev_env) : 0;
+#if defined(PM_TOOL_SORT_DELTA)
+  (void)argc;
+  (void)argv;
+  int rc = pm_sort_delta(nullptr, nullptr, device);
+#elif defined(PM_TOOL_MAF_ANALYZER)
+  if(argc < 2) {
+    fprintf(stderr, "Usage: maf_analyzer <maf>\n"); // upstream dereferences argv[1] unchecked
+    return 1;
+  }
+  int rc = pm_maf_analyzer(argv[1], nullptr, device);
+#else
+#error "define PM_TOOL_SORT_DELTA or PM_TOOL_MAF_ANALYZER"
+#endif
+  if(rc != PM_OK) {
+    fprintf(stderr, "error %d: %s\n", rc, pm_last_error());
+    return 134;
+  }
+  return 0;
+}

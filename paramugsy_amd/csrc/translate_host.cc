@@ -219,6 +219,21 @@ int parse_delta_file(const std::string &path, DeltaTable &t) {
   if(!read_whole_file(path, text)) {
     return fail(PM_E_PARSE, path + ": cannot read delta file (the reference throws Delta_stream_parse_error, m_delta.cc:72-92)");
   }
+  return parse_delta_text(text, path, t);
+}
+
+bool read_stream(FILE *f, std::string &out) {
+  std::string buf;
+  char chunk[1 << 16];
+  size_t n;
+  while((n = fread(chunk, 1, sizeof chunk, f)) > 0) {
+    buf.append(chunk, n);
+  }
+  out.swap(buf);
+  return !ferror(f);
+}
+
+int parse_delta_text(const std::string &text, const std::string &path, DeltaTable &t) {
   if(t.ref_gap_off.empty()) {
     t.ref_gap_off.push_back(0);
     t.qry_gap_off.push_back(0);
@@ -236,11 +251,11 @@ int parse_delta_file(const std::string &path, DeltaTable &t) {
     return fail(PM_E_PARSE, path + ": missing stream type line");
   }
   std::string ref_name, qry_name;
+  long long l1 = 0, l2 = 0; // header lengths in force (M_delta_stream::header_lengths_, m_delta.hh:77)
   std::vector<long long> offsets;
   while(lines.next(b, e)) {
     if(b < e && *b == '>') {
       p = b + 1;
-      long long l1, l2;
       if(!next_token(p, e, tb, te)) {
         return fail(PM_E_PARSE, path + ": bad alignment header");
       }
@@ -280,6 +295,8 @@ int parse_delta_file(const std::string &path, DeltaTable &t) {
     }
     t.ref_name.push_back(ref_name);
     t.qry_name.push_back(qry_name);
+    t.ref_len.push_back(l1);
+    t.qry_len.push_back(l2);
     t.ref_start.push_back(v[0]);
     t.ref_end.push_back(v[1]);
     t.qry_start.push_back(v[2]);

@@ -23,6 +23,7 @@ struct Side {
 // Parsed delta entries of all files of a job, flat (the layout pm_deltas_t points into).
 struct DeltaTable {
   std::vector<std::string> ref_name, qry_name; // header names in force for each entry
+  std::vector<long long> ref_len, qry_len;     // header lengths in force for each entry
   std::vector<long long> ref_start, ref_end, qry_start, qry_end;
   std::vector<long long> ref_gap_off, ref_gap_start, ref_gap_end;
   std::vector<long long> qry_gap_off, qry_gap_start, qry_gap_end;
@@ -44,6 +45,8 @@ struct Workload {
 int parse_profiles(const std::string &path, Side &side);
 void build_side_index(Side &side);
 int parse_delta_file(const std::string &path, DeltaTable &table);
+int parse_delta_text(const std::string &text, const std::string &label, DeltaTable &table);
+bool read_stream(FILE *f, std::string &out);
 void enumerate_units(const Side &left, const Side &right, const DeltaTable &table, size_t first_entry, UnitList &units);
 int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const std::vector<int32_t> &status,
                   const std::vector<int64_t> &unit_entry_off, const std::vector<pm_entry_t> &entries, const std::vector<int64_t> &offsets,
