@@ -18,8 +18,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pm_internal.hpp"
@@ -510,8 +512,37 @@ void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_del
 
 int translate_to_file(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
                       int device) {
+  // PM_TIMING=1: phase times on stderr (where a whole job spends its wall time)
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto now = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+  };
+  double t0 = now();
+  // the HIP runtime takes ~0.25 s to come up in a fresh process: let it do so while the host parses
+  int init_rc = PM_OK;
+  std::string init_msg;
+  std::thread init([&]() {
+    init_rc = use_device(device);
+    if(init_rc) {
+      init_msg = pm_last_error(); // the error slot is per thread
+    }
+  });
   Workload w;
-  PM_TRY(load_workload(left_dir, right_dir, delta_paths, w));
+  int load_rc = load_workload(left_dir, right_dir, delta_paths, w);
+  std::string load_msg = load_rc ? pm_last_error() : "";
+  init.join();
+  if(init_rc) {
+    return fail(init_rc, init_msg);
+  }
+  if(load_rc) {
+    return fail(load_rc, load_msg);
+  }
+  double t1 = now();
+  if(timing) {
+    fprintf(stderr, "[pm] parse + enumerate: %.3f s (%zu units)\n", t1 - t0, w.units.delta.size());
+  }
   std::string last_left, last_right;
   if(!w.units.delta.empty()) {
     pm_rows_t lv, rv;
@@ -520,11 +551,13 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
     workload_views(w, &lv, &rv, &dv, &uv);
     pm_job_t *job = nullptr;
     PM_TRY(pm_job_create(&lv, &rv, &dv, &uv, device, &job));
+    double t2 = now();
     int rc = pm_job_run(job, nullptr);
     int64_t ne = 0, no = 0;
     if(!rc) {
       rc = pm_job_sizes(job, &ne, &no);
     }
+    double t3 = now();
     std::vector<int32_t> status((size_t)uv.n);
     std::vector<int64_t> ent_off((size_t)uv.n + 1);
     std::vector<pm_entry_t> entries((size_t)ne);
@@ -539,7 +572,12 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
     if(rc) {
       return rc;
     }
+    double t4 = now();
     PM_TRY(write_results(out, w.left, w.right, w.units, status, ent_off, entries, offsets, last_left, last_right));
+    if(timing) {
+      fprintf(stderr, "[pm] device init + upload + prepare + sizing: %.3f s; run: %.4f s; fetch: %.3f s; format + write: %.3f s\n", t2 - t1,
+              t3 - t2, t4 - t3, now() - t4);
+    }
   }
   if(w.parse_rc) {
     return fail(w.parse_rc, w.parse_msg);
@@ -554,10 +592,7 @@ extern "C" int pm_translate_files(const char *left_dir, const char *right_dir, c
   if(!left_dir || !right_dir || !out_path || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
     return pm::fail(PM_E_INVALID, "pm_translate_files: null argument");
   }
-  int rc = pm::use_device(device);
-  if(rc) {
-    return rc;
-  }
+  int rc = PM_OK;
   std::vector<std::string> paths;
   for(int k = 0; k < n_paths; ++k) {
     if(!delta_paths[k]) {

@@ -221,3 +221,17 @@ def test_batched_index_conversions_equal_oracle(oracle_build, tmp_path):
     ok = (sa == 0) & (pi >= 1)  # a4 does not reject pi <= 0 (m_profile.cc:115); those map outside the row
     c, sc = profile_idx_of_seq_idx(rows, row[ok], a[ok])
     assert (sc == 0).all() and np.array_equal(c, pi[ok])
+
+
+def test_full_size_job_bytes_equal_cpu_side(oracle_build, tmp_path):
+    """The bench workload at full size (1.45 M work units, 64 MB of delta text) through the drop-in executable,
+    byte for byte against the upstream binary when it travelled with the snapshot (oracle/_ref), else the oracle."""
+    w = synth.make_workload(str(tmp_path / "job"), 20261003, n_left=4, n_right=4, genome_len=1000000, n_blocks=2500, n_deltas=16,
+                            entries_per_delta=6000, mean_len=1500)
+    ref = os.path.join(ROOT, "oracle", "_ref", "m_translate")
+    cpu = ref if os.path.exists(ref) else os.path.join(oracle_build, "oracle_m_translate")
+    a, b = str(tmp_path / "cpu.delta"), str(tmp_path / "gpu.delta")
+    assert subprocess.run([cpu, w.left_dir, w.right_dir, w.list_path, a]).returncode == 0
+    assert subprocess.run([os.path.join(ROOT, "bin", "m_translate"), w.left_dir, w.right_dir, w.list_path, b]).returncode == 0
+    assert os.path.getsize(a) > 50_000_000
+    assert filecmp.cmp(a, b, shallow=False)
