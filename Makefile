@@ -5,7 +5,7 @@ ARCH     ?= gfx950
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 CSRC      = paramugsy_amd/csrc
 LIB       = paramugsy_amd/libparamugsy_amd.so
-LIB_SRCS  = $(CSRC)/pm_common.hip $(CSRC)/translate_job.hip $(CSRC)/translate_host.cc $(CSRC)/side_tools.hip $(wildcard $(CSRC)/dp_*.hip)
+LIB_SRCS  = $(CSRC)/pm_common.hip $(CSRC)/translate_job.hip $(CSRC)/translate_host.cc $(CSRC)/side_tools.hip $(CSRC)/profiles_make.hip $(wildcard $(CSRC)/dp_*.hip)
 LIB_HDRS  = $(wildcard $(CSRC)/*.hpp) include/paramugsy_amd.h
 
 .PHONY: all lib cli oracle clean
@@ -17,7 +17,11 @@ lib: $(LIB)
 $(LIB): $(LIB_SRCS) $(LIB_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_SRCS)
 
-cli: bin/m_translate bin/m_sort_delta bin/maf_analyzer
+cli: bin/m_translate bin/m_sort_delta bin/maf_analyzer bin/mugsy_profiles
+
+bin/mugsy_profiles: $(CSRC)/mugsy_profiles_main.cc $(LIB)
+	mkdir -p bin
+	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/mugsy_profiles_main.cc -Lparamugsy_amd -lparamugsy_amd -Wl,-rpath,'$$ORIGIN/../paramugsy_amd'
 
 bin/m_sort_delta bin/maf_analyzer: $(CSRC)/side_tools_main.cc $(LIB)
 	mkdir -p bin
@@ -33,5 +37,5 @@ oracle:
 	if [ -d /root/reference/lib ]; then $(MAKE) -C oracle ref; fi
 
 clean:
-	rm -f $(LIB) bin/m_translate bin/m_sort_delta bin/maf_analyzer
+	rm -f $(LIB) bin/m_translate bin/m_sort_delta bin/maf_analyzer bin/mugsy_profiles
 	$(MAKE) -C oracle clean

@@ -161,6 +161,12 @@ int pm_translate_files(const char *left_dir, const char *right_dir, const char *
 int pm_sort_delta(const char *in_path, const char *out_path, int device);
 int pm_maf_analyzer(const char *maf_path, const char *out_path, int device);
 
+/* `mugsy_profiles make -in_maf <maf> -out_dir <dir> -basename <b>` (lib/profiles/m_make.ml:90-93): writes <dir>/profiles
+ * (records of lib/profiles/m_profile.ml:122-135, the translate path's input) and <dir>/sequences.fasta (one consensus
+ * per block, m_make.ml:15-45).  <dir> must exist.  Restated from the OCaml source, which cannot be run in this build
+ * image: see the header of csrc/profiles_make.hip. */
+int pm_profiles_make(const char *in_maf, const char *out_dir, const char *basename, int device);
+
 /* ------------------------------------------------------------------------------------------------------
  * Profile x profile DP (BASELINE.json's GCUPS metric).  NO REFERENCE COUNTERPART: the reference has no DP, no
  * scores, no traceback; this interface and the computation behind it are specified by this

@@ -52,7 +52,7 @@ EXPORTS = [
     "pm_job_create", "pm_job_run", "pm_job_run_profiled", "pm_job_sizes", "pm_job_fetch", "pm_job_algorithmic_bytes", "pm_job_destroy",
     "pm_rows_profile_idx_of_seq_idx_batch", "pm_rows_seq_idx_of_profile_idx_batch",
     "pm_workload_load", "pm_workload_tables", "pm_workload_row_name", "pm_workload_destroy",
-    "pm_translate_files", "pm_sort_delta", "pm_maf_analyzer",
+    "pm_translate_files", "pm_sort_delta", "pm_maf_analyzer", "pm_profiles_make",
     "pm_dp_batch_create", "pm_dp_batch_run", "pm_dp_batch_run_profiled", "pm_dp_batch_fetch", "pm_dp_batch_info", "pm_dp_batch_destroy",
 ]
 
@@ -95,6 +95,7 @@ def lib() -> C.CDLL:
         l.pm_translate_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_int]
         l.pm_sort_delta.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         l.pm_maf_analyzer.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        l.pm_profiles_make.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         _lib = l
     return _lib
 

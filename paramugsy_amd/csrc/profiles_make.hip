@@ -1,0 +1,362 @@
+// profiles_make.hip -- `mugsy_profiles make`: MAF -> <out_dir>/profiles + <out_dir>/sequences.fasta  (SURVEY.md 8f.1).
+// The producer of the translate path's input format.  Reference (OCaml, cannot be built or run in this image, so
+// this is RESTATED FROM SOURCE, NOT EXECUTED -- parity for it is pinned only by hand-derived fixtures and a Python
+// transcription of the same source, tests/test_profiles_make_*.py):
+//   lib/profiles/m_profile_stream.ml:16-74   MAF lines -> row profiles, block names "%s.%s_%04d"
+//   lib/profiles/m_profile.ml:29-47           gaps_of_text: 1-based inclusive runs of '-'
+//   lib/profiles/m_profile.ml:122-135         record layout of the `profiles` file
+//   lib/profiles/m_make.ml:15-62              combine_text fold -> per-block consensus, FASTA layout
+//   lib/profiles/m_range.ml:60-65             of_maf
+// Text parsing and printing stay on the host; the two byte kernels (gap runs of every row, consensus of every
+// block) run on the GPU: one thread per text byte / per block column, coalesced along the row text.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <string>
+#include <vector>
+
+#include "pm_internal.hpp"
+#include "translate_host.hpp"
+
+namespace pm {
+
+typedef long long i64;
+
+// start[i] = 1 when byte i opens a run of '-' within its row, stop[i] = 1 when it closes one.
+__global__ void gap_flags_kernel(i64 n, const unsigned char *text, const unsigned char *row_first, const unsigned char *row_last, int *start,
+                                 int *stop) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) {
+    return;
+  }
+  bool g = text[i] == '-';
+  bool prev = !row_first[i] && text[i - 1] == '-';
+  bool next = !row_last[i] && text[i + 1] == '-';
+  start[i] = g && !prev;
+  stop[i] = g && !next;
+}
+
+// k-th opening and k-th closing byte of the whole buffer belong to the same run (runs never cross a row).
+__global__ void gap_runs_kernel(i64 n, const int *start, const int *stop, const int *start_scan, const int *stop_scan, const int *col,
+                                i64 *gap_start, i64 *gap_end) {
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) {
+    return;
+  }
+  if(start[i]) {
+    gap_start[start_scan[i]] = col[i] + 1; // 1-based column
+  }
+  if(stop[i]) {
+    gap_end[stop_scan[i]] = col[i] + 1;
+  }
+}
+
+// m_make.ml:15-28 folded over the rows of a block (:35-45): one thread per block column.
+__global__ void consensus_kernel(i64 n_cols, int n_blocks, const i64 *cons_off, const int *block_first_row, const i64 *row_off,
+                                 const unsigned char *text, unsigned char *cons) {
+  i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= n_cols) {
+    return;
+  }
+  int lo = 0, hi = n_blocks; // block of this column: last b with cons_off[b] <= g
+  while(hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if(cons_off[mid] <= g) {
+      lo = mid;
+    }
+    else {
+      hi = mid;
+    }
+  }
+  i64 c = g - cons_off[lo];
+  int r0 = block_first_row[lo], r1 = block_first_row[lo + 1];
+  unsigned char x = text[row_off[r0] + c];
+  for(int r = r0 + 1; r < r1; ++r) {
+    unsigned char b = text[row_off[r] + c];
+    if(x == b) {
+    }
+    else if(x != '-' && b != '-') {
+      x = 'N';
+    }
+    else if(x == '-') {
+      x = b;
+    }
+  }
+  cons[g] = x;
+}
+
+struct MakeRow {
+  std::string seq_name;
+  long long start, end; // p_range
+  long long src_size;
+  int block;
+  int minor;
+};
+
+// m_profile_stream.ml:16-74
+static int parse_maf_for_make(const std::string &maf, std::vector<MakeRow> &rows, std::string &text, std::vector<i64> &row_off,
+                              std::vector<int> &block_first_row) {
+  const char *p = maf.data(), *end = p + maf.size();
+  auto getline = [&](const char *&b, const char *&e) {
+    if(p >= end) {
+      return false;
+    }
+    b = p;
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    e = nl ? nl : end;
+    p = nl ? nl + 1 : end;
+    return true;
+  };
+  row_off.push_back(0);
+  int block = 0;
+  const char *b, *e;
+  for(;;) {
+    bool found = false; // drop_until_score, :23-32
+    while(getline(b, e)) {
+      if(e - b >= 8 && memcmp(b, "a score=", 8) == 0) {
+        found = true;
+        break;
+      }
+    }
+    if(!found) {
+      break;
+    }
+    block_first_row.push_back((int)rows.size());
+    int idx = 0;
+    for(;;) { // stream_profiles, :35-58
+      if(!getline(b, e)) {
+        if(idx == 0) {
+          return fail(PM_E_PARSE, "make: Expected alignment, did not get (m_profile_stream.ml:55)");
+        }
+        break;
+      }
+      if(e == b) {
+        break;
+      }
+      if(e - b >= 2 && b[0] == 's' && b[1] == ' ') {
+        std::vector<std::pair<const char *, const char *> > tok; // split_maf, :16-21
+        const char *q = b;
+        while(q < e) {
+          while(q < e && (*q == ' ' || *q == '\t')) ++q;
+          if(q < e) {
+            const char *t0 = q;
+            while(q < e && *q != ' ' && *q != '\t') ++q;
+            tok.push_back(std::make_pair(t0, q));
+          }
+        }
+        if(tok.size() != 7) {
+          return fail(PM_E_PARSE, "make: Unknown maf line (m_profile_stream.ml:21)");
+        }
+        auto num = [&](size_t k, long long &v) {
+          std::string sx(tok[k].first, tok[k].second);
+          char *endp = nullptr;
+          v = strtoll(sx.c_str(), &endp, 10);
+          return !sx.empty() && endp && *endp == 0;
+        };
+        MakeRow r;
+        long long st, sz;
+        if(!num(2, st) || !num(3, sz) || !num(5, r.src_size)) {
+          return fail(PM_E_PARSE, "make: int_of_string failure on an `s` line");
+        }
+        size_t dl = (size_t)(tok[4].second - tok[4].first);
+        if(dl != 1 || (*tok[4].first != '+' && *tok[4].first != '-')) {
+          return fail(PM_E_PARSE, "make: Invalid direction (m_profile_stream.ml:14)");
+        }
+        if(*tok[4].first == '+') { // m_range.ml:60-65
+          r.start = st + 1;
+          r.end = st + sz;
+        }
+        else {
+          r.start = r.src_size - st;
+          r.end = r.src_size - st - (sz - 1);
+        }
+        r.seq_name.assign(tok[1].first, tok[1].second);
+        r.block = block;
+        r.minor = idx++;
+        rows.push_back(r);
+        text.append(tok[6].first, tok[6].second);
+        row_off.push_back((i64)text.size());
+      }
+      else if(b[0] == '#') {
+        continue;
+      }
+      else {
+        return fail(PM_E_PARSE, "make: Unknown line (m_profile_stream.ml:53)");
+      }
+    }
+    ++block;
+  }
+  block_first_row.push_back((int)rows.size());
+  return PM_OK;
+}
+
+} // namespace pm
+
+using namespace pm;
+
+extern "C" int pm_profiles_make(const char *in_maf, const char *out_dir, const char *basename, int device) {
+  if(!in_maf || !out_dir || !basename) {
+    return fail(PM_E_INVALID, "pm_profiles_make: null argument");
+  }
+  int rc = use_device(device);
+  if(rc) {
+    return rc;
+  }
+  std::string maf;
+  {
+    FILE *f = fopen(in_maf, "rb");
+    if(!f) {
+      return fail(PM_E_IO, std::string("cannot open ") + in_maf);
+    }
+    read_stream(f, maf);
+    fclose(f);
+  }
+  std::vector<MakeRow> rows;
+  std::string text;
+  std::vector<i64> row_off;
+  std::vector<int> block_first_row;
+  PM_TRY(parse_maf_for_make(maf, rows, text, row_off, block_first_row));
+  int n_rows = (int)rows.size(), n_blocks = (int)block_first_row.size() - 1;
+  i64 n = (i64)text.size();
+  // every row of a block must have the block's column count (assert at m_make.ml:16)
+  std::vector<i64> cons_off((size_t)n_blocks + 1, 0);
+  for(int b = 0; b < n_blocks; ++b) {
+    int r0 = block_first_row[b], r1 = block_first_row[b + 1];
+    i64 cols = r1 > r0 ? row_off[(size_t)r0 + 1] - row_off[r0] : 0;
+    for(int r = r0; r < r1; ++r) {
+      if(row_off[(size_t)r + 1] - row_off[r] != cols) {
+        return fail(PM_E_PARSE, "make: rows of one block differ in length (assert, m_make.ml:16)");
+      }
+    }
+    cons_off[(size_t)b + 1] = cons_off[b] + cols;
+  }
+  std::vector<i64> gap_off((size_t)n_rows + 1, 0), gap_start, gap_end;
+  std::string cons((size_t)cons_off[n_blocks], '\0');
+  if(n > 0) {
+    // per-byte helpers: column within the row, first/last byte of a row
+    std::vector<int> col((size_t)n);
+    std::vector<unsigned char> first((size_t)n, 0), last((size_t)n, 0);
+    for(int r = 0; r < n_rows; ++r) {
+      i64 a = row_off[r], z = row_off[(size_t)r + 1];
+      for(i64 i = a; i < z; ++i) {
+        col[(size_t)i] = (int)(i - a);
+      }
+      if(z > a) {
+        first[(size_t)a] = 1;
+        last[(size_t)z - 1] = 1;
+      }
+    }
+    DevBuf d_text, d_first, d_last, d_col, d_start, d_stop, d_sscan, d_escan, d_tmp, d_gs, d_ge;
+    PM_TRY(d_text.upload(text.data(), (size_t)n, nullptr));
+    PM_TRY(d_first.upload(first.data(), (size_t)n, nullptr));
+    PM_TRY(d_last.upload(last.data(), (size_t)n, nullptr));
+    PM_TRY(d_col.upload(col.data(), (size_t)n * 4, nullptr));
+    PM_TRY(d_start.alloc((size_t)n * 4));
+    PM_TRY(d_stop.alloc((size_t)n * 4));
+    PM_TRY(d_sscan.alloc((size_t)n * 4));
+    PM_TRY(d_escan.alloc((size_t)n * 4));
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    gap_flags_kernel<<<blocks, 256>>>(n, (const unsigned char *)d_text.p, (const unsigned char *)d_first.p, (const unsigned char *)d_last.p,
+                                      (int *)d_start.p, (int *)d_stop.p);
+    PM_HIP(hipGetLastError());
+    size_t bytes = 0;
+    PM_HIP(rocprim::exclusive_scan(nullptr, bytes, (int *)d_start.p, (int *)d_sscan.p, 0, (size_t)n, rocprim::plus<int>()));
+    PM_TRY(d_tmp.alloc(bytes ? bytes : 8));
+    PM_HIP(rocprim::exclusive_scan(d_tmp.p, bytes, (int *)d_start.p, (int *)d_sscan.p, 0, (size_t)n, rocprim::plus<int>()));
+    PM_HIP(rocprim::exclusive_scan(d_tmp.p, bytes, (int *)d_stop.p, (int *)d_escan.p, 0, (size_t)n, rocprim::plus<int>()));
+    std::vector<int> sscan((size_t)n), sflag((size_t)n);
+    PM_HIP(hipMemcpy(sscan.data(), d_sscan.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    PM_HIP(hipMemcpy(sflag.data(), d_start.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    i64 total = sscan[(size_t)n - 1] + sflag[(size_t)n - 1];
+    for(int r = 0; r < n_rows; ++r) {
+      gap_off[r] = row_off[r] < n ? sscan[(size_t)row_off[r]] : total;
+    }
+    gap_off[n_rows] = total;
+    gap_start.resize((size_t)total);
+    gap_end.resize((size_t)total);
+    if(total > 0) {
+      PM_TRY(d_gs.alloc((size_t)total * 8));
+      PM_TRY(d_ge.alloc((size_t)total * 8));
+      gap_runs_kernel<<<blocks, 256>>>(n, (const int *)d_start.p, (const int *)d_stop.p, (const int *)d_sscan.p, (const int *)d_escan.p,
+                                       (const int *)d_col.p, (i64 *)d_gs.p, (i64 *)d_ge.p);
+      PM_HIP(hipGetLastError());
+      PM_HIP(hipMemcpy(gap_start.data(), d_gs.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+      PM_HIP(hipMemcpy(gap_end.data(), d_ge.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+    }
+    if(cons_off[n_blocks] > 0) {
+      DevBuf d_coff, d_bfr, d_roff, d_cons;
+      PM_TRY(d_coff.upload(cons_off.data(), ((size_t)n_blocks + 1) * 8, nullptr));
+      PM_TRY(d_bfr.upload(block_first_row.data(), ((size_t)n_blocks + 1) * 4, nullptr));
+      PM_TRY(d_roff.upload(row_off.data(), ((size_t)n_rows + 1) * 8, nullptr));
+      PM_TRY(d_cons.alloc((size_t)cons_off[n_blocks]));
+      i64 nc = cons_off[n_blocks];
+      consensus_kernel<<<(unsigned)((nc + 255) / 256), 256>>>(nc, n_blocks, (const i64 *)d_coff.p, (const int *)d_bfr.p, (const i64 *)d_roff.p,
+                                                             (const unsigned char *)d_text.p, (unsigned char *)d_cons.p);
+      PM_HIP(hipGetLastError());
+      PM_HIP(hipMemcpy(&cons[0], d_cons.p, (size_t)nc, hipMemcpyDeviceToHost));
+    }
+  }
+  // m_make.ml:48-62: both files are created even when the MAF holds no block
+  std::string dir(out_dir);
+  FILE *fp = fopen((dir + "/profiles").c_str(), "wb");
+  FILE *ff = fopen((dir + "/sequences.fasta").c_str(), "wb");
+  if(!fp || !ff) {
+    if(fp) fclose(fp);
+    if(ff) fclose(ff);
+    return fail(PM_E_IO, "cannot create output files in " + dir + " (the directory must exist)");
+  }
+  std::string buf;
+  char major[1024];
+  for(int r = 0; r < n_rows; ++r) { // m_profile.ml:122-135
+    snprintf(major, sizeof major, "%s.%s_%04d", basename, basename, rows[r].block); // m_profile_stream.ml:65
+    buf += major;
+    buf += ' ';
+    buf += std::to_string(rows[r].minor);
+    buf += ' ';
+    buf += rows[r].seq_name;
+    buf += ' ';
+    buf += std::to_string(rows[r].start);
+    buf += ' ';
+    buf += std::to_string(rows[r].end);
+    buf += ' ';
+    buf += std::to_string(row_off[(size_t)r + 1] - row_off[r]);
+    buf += ' ';
+    buf += std::to_string(rows[r].src_size);
+    buf += '\n';
+    for(i64 g = gap_off[r]; g < gap_off[(size_t)r + 1]; ++g) {
+      buf += std::to_string(gap_start[(size_t)g]);
+      buf += ' ';
+      buf += std::to_string(gap_end[(size_t)g]);
+      buf += '\n';
+    }
+    buf += "0\n";
+    buf.append(text, (size_t)row_off[r], (size_t)(row_off[(size_t)r + 1] - row_off[r]));
+    buf += '\n';
+    if(buf.size() > (1 << 20)) {
+      fwrite(buf.data(), 1, buf.size(), fp);
+      buf.clear();
+    }
+  }
+  fwrite(buf.data(), 1, buf.size(), fp);
+  buf.clear();
+  for(int b = 0; b < n_blocks; ++b) { // m_make.ml:35-45
+    if(block_first_row[(size_t)b + 1] == block_first_row[b]) {
+      continue;
+    }
+    snprintf(major, sizeof major, "%s.%s_%04d", basename, basename, b);
+    buf += '>';
+    buf += major;
+    buf += '\n';
+    buf.append(cons, (size_t)cons_off[b], (size_t)(cons_off[(size_t)b + 1] - cons_off[b]));
+    buf += "\n\n";
+  }
+  fwrite(buf.data(), 1, buf.size(), ff);
+  fclose(fp);
+  fclose(ff);
+  return PM_OK;
+}

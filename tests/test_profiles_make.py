@@ -1,0 +1,93 @@
+"""`mugsy_profiles make`.  The reference is OCaml and cannot run here: the oracle
+(oracle/make_oracle.py) is a transcription of its source, pinned by a fixture whose expected bytes were derived BY
+HAND from the cited lines (tests/golden/make_handmade.*): "restated from source, not executed".
+Hand derivation of the fixture, block 0 (8 columns):
+  G1 '+' start 0 size 6  -> range (1, 6);   text ACG--TAC -> gaps (4,5)
+  G2 '-' start 10 size 7, src 50 -> range (50-10, 50-10-6) = (40, 34); text AC-TTTAC -> gaps (3,3)
+  G3 '+' start 3 size 5  -> range (4, 8);   text --GATTA- -> gaps (1,2) (8,8)
+  consensus = fold of combine_text over the rows (m_make.ml:35-45), column by column: 1 A,A,- -> A; 2 C,C,- -> C; 3 G,-,G -> G; 4 -,T,A -> T then T vs A -> N; 5 -,T,T -> T;
+                    6 T,T,T -> T; 7 A,A,A -> A; 8 C,C,- -> C        => ACGNTTAC
+"""
+import os
+import sys
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import make_oracle  # noqa: E402
+
+
+def test_oracle_matches_hand_derived_fixture():
+    prof, fasta = make_oracle.make(open(os.path.join(GOLDEN, "make_handmade.maf")).read(), "x")
+    assert prof == open(os.path.join(GOLDEN, "make_handmade.profiles")).read()
+    assert fasta == open(os.path.join(GOLDEN, "make_handmade.fasta")).read()
+
+
+def test_oracle_rejects_what_the_reference_rejects():
+    with pytest.raises(ValueError):
+        make_oracle.make("a score=1\ns\ttabbed 0 1 + 1 A\n", "x")  # "Unknown line": not prefixed by "s "
+    with pytest.raises(ValueError):
+        make_oracle.make("a score=1\n", "x")  # "Expected alignment, did not get"
+    with pytest.raises(ValueError):
+        make_oracle.make("a score=1\ns g 0 1 * 1 A\n", "x")  # Invalid direction
+    with pytest.raises(AssertionError):
+        make_oracle.make("a score=1\ns g 0 2 + 9 AC\ns h 0 3 + 9 ACG\n", "x")  # combine_text assert
+
+
+def test_profiles_written_by_oracle_are_read_back_by_the_translate_parser(tmp_path):
+    """The format contract between the two stages: what `make` writes is what the translate path's loader reads."""
+    import numpy as np
+    from paramugsy_amd import synth
+    from paramugsy_amd.translate import Workload
+    rng = np.random.default_rng(3)
+    blocks = synth.gen_side(rng, ["A.c", "B.c"], 5000, 12, mean_cols=120)
+    prof, _ = make_oracle.make(synth.side_to_maf_text(blocks), "l")
+    assert prof == synth.rows_to_profiles_text(blocks, "l")  # the generator's shortcut equals the stage's output
+    (tmp_path / "l").mkdir()
+    (tmp_path / "r").mkdir()
+    (tmp_path / "l" / "profiles").write_text(prof)
+    (tmp_path / "r" / "profiles").write_text("")
+    t = Workload.load(str(tmp_path / "l"), str(tmp_path / "r"), []).tables()
+    assert len(t.left["start"]) == sum(len(b.rows) for b in blocks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["handmade", "synthetic", "empty"])
+def test_gpu_make_equals_oracle(case, tmp_path):
+    import numpy as np
+    from paramugsy_amd import capi, synth
+    if case == "handmade":
+        maf = open(os.path.join(GOLDEN, "make_handmade.maf")).read()
+    elif case == "synthetic":
+        rng = np.random.default_rng(11)
+        maf = synth.side_to_maf_text(synth.gen_side(rng, ["A.c", "B.c", "C.c"], 60000, 80, mean_cols=500, gap_rate=0.03, edge_gap_prob=0.4))
+    else:
+        maf = "##maf version=1\n"
+    src = tmp_path / "in.maf"
+    src.write_text(maf)
+    out = tmp_path / "out"
+    out.mkdir()
+    capi.check(capi.lib().pm_profiles_make(str(src).encode(), str(out).encode(), b"x", 0))
+    prof, fasta = make_oracle.make(maf, "x")
+    assert (out / "profiles").read_text() == prof
+    assert (out / "sequences.fasta").read_text() == fasta
+
+
+@pytest.mark.gpu
+def test_gpu_make_cli_and_errors(tmp_path):
+    import subprocess
+    from paramugsy_amd import capi
+    exe = os.path.join(ROOT, "bin", "mugsy_profiles")
+    out = tmp_path / "o" / "nested"
+    r = subprocess.run([exe, "make", "-in_maf", os.path.join(GOLDEN, "make_handmade.maf"), "-out_dir", str(out), "-basename", "x"],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert (out / "profiles").read_text() == open(os.path.join(GOLDEN, "make_handmade.profiles")).read()
+    assert (out / "sequences.fasta").read_text() == open(os.path.join(GOLDEN, "make_handmade.fasta")).read()
+    bad = tmp_path / "bad.maf"
+    bad.write_text("a score=1\ns g 0 2 + 9 AC\ns h 0 3 + 9 ACG\n")
+    rc = capi.lib().pm_profiles_make(str(bad).encode(), str(tmp_path).encode(), b"x", 0)
+    assert rc == capi.PM_E_PARSE
+    assert subprocess.run([exe, "make", "-in_maf", str(bad)], capture_output=True).returncode != 0
