@@ -71,16 +71,17 @@ def timed_region(torch, dist, fn, steps, warmup):
     """W untimed steps, barrier + sync, exactly K steps, sync + barrier; returns the MAX wall time over ranks (s)."""
     for _ in range(warmup):
         fn()
+    dev = torch.cuda.current_device()
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[dev])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[dev])
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
