@@ -647,8 +647,7 @@ void translate_unit(DeltaEntry const &de_in, Profile const &left, Profile const 
 
   /* :612-618.  The reference has no bound here; a bound far above any terminating run turns a
    * would-be endless loop into a reportable failure. */
-  long budget = 4 * (long)(left_sub.gaps.size() + right_gaps.size() + d_ref_sub.gaps.size() + d_query_sub.gaps.size()) +
-                2 * (cols.e - cols.s + 1) + 64;
+  long budget = 4 * (long)(left_sub.gaps.size() + right_gaps.size() + d_ref_sub.gaps.size() + d_query_sub.gaps.size()) + 64;
   while(!m.rows.done() || !m.delta.done()) {
     if(budget-- <= 0) {
       throw Failure(STEP_LIMIT);

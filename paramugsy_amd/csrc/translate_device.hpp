@@ -344,9 +344,18 @@ struct Sink {
     }
     i64 sign = row ? 1 : -1;
     put(sign * (g.s - wpos));
-    for(i64 k = rlen(g) - 1; k > 0; --k) {
-      put(sign);
+    // the gap's remaining columns are +-1 each (_push_ones, m_delta_stream_writer.hh:6-11).  Counted
+    // arithmetically and written only inside the unit's slot, so a nonsensical gap length cannot stall a lane.
+    i64 ones = rlen(g) - 1;
+    if(EMIT) {
+      i64 at = n_off + pend;
+      i64 room = off_cap - at;
+      i64 n = ones < room ? ones : room;
+      for(i64 k = 0; k < n; ++k) {
+        off[off_base + at + k] = sign;
+      }
     }
+    pend += ones;
     wpos = g.e;
     last_start = g.s;
     last_row = row;
@@ -596,7 +605,7 @@ PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &
   m.b_restart(ref_start, query_start);
 
   // :612-618.  Same budget as oracle/pm_oracle.cc: far above any terminating run; every lane reaches it.
-  i64 budget = 4 * (i64)(m.rows.v0.n + m.rows.v1.n + m.delta.v0.n + m.delta.v1.n) + 2 * (cols.e - cols.s + 1) + 64;
+  i64 budget = 4 * (i64)(m.rows.v0.n + m.rows.v1.n + m.delta.v0.n + m.delta.v1.n) + 64;
   st = PM_ST_OK;
   while(!m.rows.done() || !m.delta.done()) {
     if(budget-- <= 0) {

@@ -449,6 +449,10 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   // Size the outputs once: the inputs of a job never change, so neither do its output sizes.
   JTRY(job_launch_count_scan(j, stream));
   JTRY(job_read_totals(j, stream));
+  if(j->n_entries < 0 || j->n_offsets < 0 || j->n_entries > ((i64)1 << 36) || j->n_offsets > ((i64)1 << 38)) {
+    pm_job_destroy(j);
+    return fail(PM_E_INVALID, "pm_job_create: implausible output size (inconsistent input tables)");
+  }
   j->ent_cap = j->n_entries;
   j->off_cap = j->n_offsets;
   JTRY(j->entries.alloc((size_t)j->ent_cap * sizeof(pm_entry_t)));
