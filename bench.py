@@ -202,7 +202,7 @@ def bench_dp(args, rank, world, local, torch, dist):
     # int32 VALU peak: every non-packed int32 VALU instruction measured at 4 cycles per wave64 instruction per
     # SIMD (tools/ubench/valu_rates.hip, profiles/r01_valu_rates.txt) -> 16 lanes/clk x 4 SIMDs x 256 CUs x 2.4 GHz
     valu_peak = 256 * 4 * 16 * 2.4e9
-    ops_per_cell = 16  # csrc/dp_kernels.hip: 3 dot2 + 3 E + 3 F + 6 H/flags + 1 (H - open)
+    ops_per_cell = 15  # csrc/dp_kernels.hip: 3 dot2 + 3 E + 3 F + 5 H/flags (max3) + 1 (H - open)
     out = {
         "metric": "profile-DP GCUPS (global affine-gap profile x profile alignment, scores + traceback)",
         "value": cells * world * args.steps / dt / 1e9,

@@ -26,7 +26,7 @@
 //   * stripe boundary (last column of a stripe, per row): written by lane 63, read back 64 rows at a time.
 // Algorithmic HBM traffic per cell: 0.5 byte of traceback written + (8 bytes per column of A per stripe +
 // 8 bytes per column of B) read, i.e. ~0.5 B/cell for kilobase profiles; the kernel is VALU-issue bound
-// (16 VALU ops per cell), not HBM bound.
+// (15 VALU ops per cell), not HBM bound.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -198,10 +198,9 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           f[c] = fv;
           // diagonal: (H~[i-1][j-1] - gop) + s(i,j) + gop + 2*ge
           const int d = dot2(a.x, w0[c], dot2(a.y, w1[c], dot2(a.z, w2[c], diag)));
-          const int m = max(e, fv);
-          acc = __builtin_amdgcn_alignbit(acc, d - m, 31);  // bit = not diagonal
+          const int h = max(d, max(e, fv));                 // one v_max3_i32
+          acc = __builtin_amdgcn_alignbit(acc, d - h, 31);  // bit = not diagonal: d < max(e, f)  <=>  d < h
           acc = __builtin_amdgcn_alignbit(acc, e - fv, 31); // bit = F beats E
-          const int h = max(d, m);
           diag = hop[c];
           ho_left = h - gop;
           hop[c] = ho_left;
