@@ -29,6 +29,7 @@
 // (15 VALU ops per cell), not HBM bound.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,7 +72,9 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
   return stripes * (la + 63) * 64 * (C / 8);
 }
 
-template <int C, bool TRACE>
+// DOT4: every count of A and every ACGT weight of B fits int8 (checked at batch creation), so the four base terms of
+// the column score are one v_dot4_i32_i8 instead of two v_dot2_i32_i16.
+template <int C, bool TRACE, bool DOT4>
 __global__ void __launch_bounds__(64)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, i64 first_pair, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
@@ -123,8 +126,14 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         }
         w[a] = acc;
       }
-      w0[c] = pack16(w[0], w[1]);
-      w1[c] = pack16(w[2], w[3]);
+      if(DOT4) {
+        w0[c] = (int)(((unsigned)w[0] & 0xffu) | (((unsigned)w[1] & 0xffu) << 8) | (((unsigned)w[2] & 0xffu) << 16) | ((unsigned)w[3] << 24));
+        w1[c] = 0;
+      }
+      else {
+        w0[c] = pack16(w[0], w[1]);
+        w1[c] = pack16(w[2], w[3]);
+      }
       w2[c] = pack16(w[4], in ? go + ge : 0); // A's third pair is (nGap, 1): the 1 picks up gop + 2*ge
       hop[c] = -2 * gop;                      // H~[0][j+1] - gop, H~[0][j] = -gop for j >= 1
       f[c] = DP_NEG_INF;
@@ -145,8 +154,13 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         int4 v = make_int4(0, 0, 0, 0);
         if(r < la) {
           const u64 col = A[r];
-          v.x = (int)(col & 0xff) | ((int)((col >> 8) & 0xff) << 16);
-          v.y = (int)((col >> 16) & 0xff) | ((int)((col >> 24) & 0xff) << 16);
+          if(DOT4) {
+            v.x = (int)(col & 0xffffffffull); // nA, nC, nG, nT as four int8
+          }
+          else {
+            v.x = (int)(col & 0xff) | ((int)((col >> 8) & 0xff) << 16);
+            v.y = (int)((col >> 16) & 0xff) | ((int)((col >> 24) & 0xff) << 16);
+          }
           v.z = (int)((col >> 32) & 0xff) | (1 << 16);
         }
         ring[r & 127] = v;
@@ -197,7 +211,8 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           const int fv = max(f[c], hop[c]);
           f[c] = fv;
           // diagonal: (H~[i-1][j-1] - gop) + s(i,j) + gop + 2*ge
-          const int d = dot2(a.x, w0[c], dot2(a.y, w1[c], dot2(a.z, w2[c], diag)));
+          const int d = DOT4 ? __builtin_amdgcn_sdot4(a.x, w0[c], dot2(a.z, w2[c], diag), false)
+                             : dot2(a.x, w0[c], dot2(a.y, w1[c], dot2(a.z, w2[c], diag)));
           const int h = max(d, max(e, fv));                 // one v_max3_i32
           acc = __builtin_amdgcn_alignbit(acc, d - h, 31);  // bit = not diagonal: d < max(e, f)  <=>  d < h
           acc = __builtin_amdgcn_alignbit(acc, e - fv, 31); // bit = F beats E
@@ -336,6 +351,7 @@ struct pm_dp_batch {
   DpParamsD params;
   i64 cells = 0;
   int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
+  bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
   hipStream_t last_stream = nullptr;
 };
 
@@ -393,6 +409,32 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   h->total_a = off_a[n_pairs];
   h->total_b = off_b[n_pairs];
   memcpy(h->params.sub, params->sub, sizeof h->params.sub);
+  {
+    // int8 path: counts of A <= 127 and |sum_b B[j][b] * sub[a][b]| <= (rows of B's column) * max|sub[a][.]| <= 127 for a in ACGT
+    int max_sub = 0;
+    for(int a = 0; a < 4; ++a) {
+      for(int b = 0; b < 5; ++b) {
+        max_sub = std::max(max_sub, std::abs(params->sub[a * 5 + b]));
+      }
+    }
+    int max_a = 0, max_colsum_b = 0;
+    for(int64_t k = 0; k < off_a[n_pairs]; ++k) {
+      for(int b = 0; b < 4; ++b) {
+        max_a = std::max(max_a, (int)cols_a[k * 8 + b]);
+      }
+    }
+    for(int64_t k = 0; k < off_b[n_pairs]; ++k) {
+      int sum = 0;
+      for(int b = 0; b < 5; ++b) {
+        sum += cols_b[k * 8 + b];
+      }
+      max_colsum_b = std::max(max_colsum_b, sum);
+    }
+    h->dot4 = max_a <= 127 && max_colsum_b * max_sub <= 127;
+    if(const char *e = getenv("PM_DP_DOT4")) {
+      h->dot4 = h->dot4 && atoi(e) != 0;
+    }
+  }
   h->params.go = params->gap_open;
   h->params.ge = params->gap_extend;
 #define DTRY(x)               \
@@ -469,26 +511,34 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
     if(timed) {
       PM_HIP(hipEventRecord(ev[0], stream));
     }
-#define DP_LAUNCH_FILL(CC, TR)                                                                                                     \
-  dp_fill_kernel<CC, TR><<<(unsigned)n, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p, \
-                                                         (const i64 *)h->d_off_b.p, first, tb_off, (unsigned *)h->tb.p, (int2 *)h->bnd.p, \
-                                                         (int *)h->scores.p, h->params)
+#define DP_LAUNCH_FILL(CC, TR, D4)                                                                                                     \
+  dp_fill_kernel<CC, TR, D4><<<(unsigned)n, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p, \
+                                                             (const i64 *)h->d_off_b.p, first, tb_off, (unsigned *)h->tb.p, (int2 *)h->bnd.p, \
+                                                             (int *)h->scores.p, h->params)
+#define DP_LAUNCH_FILL_D4(CC, TR) \
+  if(h->dot4) {                   \
+    DP_LAUNCH_FILL(CC, TR, true); \
+  }                               \
+  else {                          \
+    DP_LAUNCH_FILL(CC, TR, false); \
+  }
     if(h->cols_per_lane == 16) {
       if(traceback) {
-        DP_LAUNCH_FILL(16, true);
+        DP_LAUNCH_FILL_D4(16, true)
       }
       else {
-        DP_LAUNCH_FILL(16, false);
+        DP_LAUNCH_FILL_D4(16, false)
       }
     }
     else {
       if(traceback) {
-        DP_LAUNCH_FILL(8, true);
+        DP_LAUNCH_FILL_D4(8, true)
       }
       else {
-        DP_LAUNCH_FILL(8, false);
+        DP_LAUNCH_FILL_D4(8, false)
       }
     }
+#undef DP_LAUNCH_FILL_D4
 #undef DP_LAUNCH_FILL
     PM_HIP(hipGetLastError());
     if(timed) {
