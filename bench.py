@@ -202,7 +202,8 @@ def bench_dp(args, rank, world, local, torch, dist):
     # int32 VALU peak: every non-packed int32 VALU instruction measured at 4 cycles per wave64 instruction per
     # SIMD (tools/ubench/valu_rates.hip, profiles/r01_valu_rates.txt) -> 16 lanes/clk x 4 SIMDs x 256 CUs x 2.4 GHz
     valu_peak = 256 * 4 * 16 * 2.4e9
-    ops_per_cell = 15  # csrc/dp_kernels.hip: 3 dot2 + 3 E + 3 F + 5 H/flags (max3) + 1 (H - open)
+    variant = batch.variant()
+    ops_per_cell = variant["valu_ops_per_cell"]  # csrc/dp_kernels.hip: column score 2 or 3, E 3, F 3, H + flags 5, H - open 1
     out = {
         "metric": "profile-DP GCUPS (global affine-gap profile x profile alignment, scores + traceback)",
         "value": cells * world * args.steps / dt / 1e9,
@@ -211,7 +212,7 @@ def bench_dp(args, rank, world, local, torch, dist):
         "dtype": "int32",
         "config": {"workload": "%d synthetic %d-row x %d-column profile pairs per rank, int32 affine-gap scores, scores + full traceback"
                    % (n, rows, L), "pairs_per_rank": n, "rows": rows, "columns": L, "cells_per_step_per_rank": cells,
-                   "chunks": info["chunks"],
+                   "chunks": info["chunks"], "kernel_variant": variant,
                    "reference_counterpart": "none: the reference has no DP (SURVEY.md 0); specification and oracle are this repo's own"},
         "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_traceback_kernel": ms_tb},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

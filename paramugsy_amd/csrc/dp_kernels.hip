@@ -661,6 +661,23 @@ int pm_dp_batch_info(pm_dp_batch_t *h, int64_t *cells, int64_t *traceback_bytes_
   return PM_OK;
 }
 
+int pm_dp_batch_variant(pm_dp_batch_t *h, int32_t *cols_per_lane, int32_t *dot4, int32_t *valu_ops_per_cell) {
+  if(!h) {
+    return fail(PM_E_INVALID, "pm_dp_batch_variant: null batch");
+  }
+  if(cols_per_lane) {
+    *cols_per_lane = h->cols_per_lane;
+  }
+  if(dot4) {
+    *dot4 = h->dot4 ? 1 : 0;
+  }
+  if(valu_ops_per_cell) {
+    // per cell: column score (dot4 + dot2 = 2, or 3 x dot2), E 3, F 3, H + two decision bits 5, H - open 1
+    *valu_ops_per_cell = (h->dot4 ? 2 : 3) + 3 + 3 + 5 + 1;
+  }
+  return PM_OK;
+}
+
 void pm_dp_batch_destroy(pm_dp_batch_t *h) {
   if(!h) {
     return;

@@ -63,6 +63,7 @@ def _lib():
         l.pm_dp_batch_run_profiled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.pm_dp_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_dp_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        l.pm_dp_batch_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.pm_dp_batch_destroy.argtypes = [C.c_void_p]
         l.pm_dp_batch_destroy.restype = None
         l._dp_bound = True
@@ -113,6 +114,11 @@ class DpBatch:
         cells, tb, inp, chunks = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         capi.check(_lib().pm_dp_batch_info(self._h, C.byref(cells), C.byref(tb), C.byref(inp), C.byref(chunks)))
         return {"cells": cells.value, "traceback_bytes": tb.value, "input_bytes": inp.value, "chunks": chunks.value}
+
+    def variant(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(_lib().pm_dp_batch_variant(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"cols_per_lane": a.value, "dot4": bool(b.value), "valu_ops_per_cell": c.value}
 
     def fetch(self, with_paths: bool = True):
         n = len(self._oa) - 1
