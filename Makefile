@@ -5,7 +5,7 @@ ARCH     ?= gfx950
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 CSRC      = paramugsy_amd/csrc
 LIB       = paramugsy_amd/libparamugsy_amd.so
-LIB_SRCS  = $(CSRC)/pm_common.hip $(CSRC)/translate_job.hip $(CSRC)/translate_host.cc $(CSRC)/side_tools.hip $(CSRC)/profiles_make.hip $(wildcard $(CSRC)/dp_*.hip)
+LIB_SRCS  = $(CSRC)/pm_common.hip $(CSRC)/translate_job.hip $(CSRC)/translate_host.cc $(CSRC)/side_tools.hip $(CSRC)/profiles_make.hip $(CSRC)/untranslate.hip $(wildcard $(CSRC)/dp_*.hip)
 LIB_HDRS  = $(wildcard $(CSRC)/*.hpp) include/paramugsy_amd.h
 
 .PHONY: all lib cli oracle clean

@@ -51,6 +51,7 @@ extern "C" {
 #define PM_ST_STEP_LIMIT 7               /* merge did not terminate within its step budget */
 #define PM_ST_OFFSET_ORDER 8             /* builder gaps not in writer order: result would differ, so refuse */
 #define PM_ST_MALFORMED_INPUT 9          /* unit touches a row / entry whose gap list is not ascending+disjoint */
+#define PM_ST_TEXT_RANGE 10              /* untranslate: String.sub / expand_text index outside a row's text (Invalid_argument) */
 
 /* ---- batch description (host pointers; copied to the device by pm_job_create) ---- */
 
@@ -166,6 +167,11 @@ int pm_maf_analyzer(const char *maf_path, const char *out_path, int device);
  * per block, m_make.ml:15-45).  <dir> must exist.  Restated from the OCaml source, which cannot be run in this build
  * image: see the header of csrc/profiles_make.hip. */
 int pm_profiles_make(const char *in_maf, const char *out_dir, const char *basename, int device);
+/* `mugsy_profiles untranslate -profile_paths_list <file of dirs> -in_maf <maf> -out_maf <maf>`
+ * (lib/profiles/m_untranslate.ml:206-221): rewrites a MAF whose `s` lines name profile blocks into one over the real
+ * genomes.  profile_dirs: the directories the list file names, in order.  Restated from the OCaml source (see
+ * csrc/untranslate.hip). */
+int pm_untranslate(const char *const *profile_dirs, int n_dirs, const char *in_maf, const char *out_maf, int device);
 
 /* ------------------------------------------------------------------------------------------------------
  * Profile x profile DP (BASELINE.json's GCUPS metric).  NO REFERENCE COUNTERPART: the reference has no DP, no

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libparamugsy_amd.so")
 PM_OK = 0
 PM_E_INVALID, PM_E_NO_DEVICE, PM_E_HIP, PM_E_IO, PM_E_PARSE, PM_E_UNIT, PM_E_MALFORMED = -1, -2, -3, -4, -5, -6, -7
 (PM_ST_OK, PM_ST_SEQ_IDX_OUT_OF_RANGE, PM_ST_PROFILE_IDX_OUT_OF_RANGE, PM_ST_IS_NONE, PM_ST_ASSERT_GAP_BEHIND,
- PM_ST_ASSERT_SUB_LENGTHS, PM_ST_ALREADY_UNNEXT, PM_ST_STEP_LIMIT, PM_ST_OFFSET_ORDER, PM_ST_MALFORMED_INPUT) = range(10)
+ PM_ST_ASSERT_SUB_LENGTHS, PM_ST_ALREADY_UNNEXT, PM_ST_STEP_LIMIT, PM_ST_OFFSET_ORDER, PM_ST_MALFORMED_INPUT,
+ PM_ST_TEXT_RANGE) = range(11)
 
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
@@ -52,7 +53,7 @@ EXPORTS = [
     "pm_job_create", "pm_job_run", "pm_job_run_profiled", "pm_job_sizes", "pm_job_fetch", "pm_job_algorithmic_bytes", "pm_job_destroy",
     "pm_rows_profile_idx_of_seq_idx_batch", "pm_rows_seq_idx_of_profile_idx_batch",
     "pm_workload_load", "pm_workload_tables", "pm_workload_row_name", "pm_workload_destroy",
-    "pm_translate_files", "pm_sort_delta", "pm_maf_analyzer", "pm_profiles_make",
+    "pm_translate_files", "pm_sort_delta", "pm_maf_analyzer", "pm_profiles_make", "pm_untranslate",
     "pm_dp_batch_create", "pm_dp_batch_run", "pm_dp_batch_run_profiled", "pm_dp_batch_fetch", "pm_dp_batch_info", "pm_dp_batch_variant", "pm_dp_batch_destroy",
 ]
 
@@ -96,6 +97,7 @@ def lib() -> C.CDLL:
         l.pm_sort_delta.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         l.pm_maf_analyzer.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         l.pm_profiles_make.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        l.pm_untranslate.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int]
         _lib = l
     return _lib
 

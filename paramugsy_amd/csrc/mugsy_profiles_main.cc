@@ -4,7 +4,8 @@
 //   mugsy_profiles make -in_maf <maf> -out_dir <dir> -basename <name>            (lib/profiles/m_make.ml:66-93)
 //   mugsy_profiles translate -profiles_left <dir> -profiles_right <dir> -nucmer_list <file> -out_delta <file>
 //                                                                                (lib/profiles/m_translate.ml:780-851)
-// The other commands (untranslate, maf_to_xmfa, fasta_to_maf) are not implemented here and exit 2.
+//   mugsy_profiles untranslate -profile_paths_list <file> -in_maf <maf> -out_maf <maf>   (lib/profiles/m_untranslate.ml:168-221)
+// The other commands (maf_to_xmfa, fasta_to_maf) are format converters outside the path; they exit 2 here.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,7 +34,7 @@ static void mkdir_p(const std::string &path) { // Shell.mkdir ~p:(), m_make.ml:9
 
 int main(int argc, char **argv) {
   if(argc < 2) {
-    fprintf(stderr, "usage: mugsy_profiles {make|translate} <flags>\n");
+    fprintf(stderr, "usage: mugsy_profiles {make|translate|untranslate} <flags>\n");
     return 1;
   }
   std::string cmd = argv[1];
@@ -69,6 +70,23 @@ int main(int argc, char **argv) {
     }
     rc = pm_translate_files(flag["-profiles_left"].c_str(), flag["-profiles_right"].c_str(), cpaths.data(), (int)cpaths.size(),
                             flag["-out_delta"].c_str(), device);
+  }
+  else if(cmd == "untranslate") {
+    if(flag["-profile_paths_list"].empty() || flag["-in_maf"].empty() || flag["-out_maf"].empty()) {
+      fprintf(stderr, "Must provide -profile_paths_list, -in_maf and -out_maf\n"); // m_untranslate.ml:183-188
+      return 2;
+    }
+    std::vector<std::string> dirs;
+    std::ifstream list(flag["-profile_paths_list"].c_str());
+    std::string line;
+    while(std::getline(list, line)) {
+      dirs.push_back(line);
+    }
+    std::vector<const char *> cdirs;
+    for(size_t k = 0; k < dirs.size(); ++k) {
+      cdirs.push_back(dirs[k].c_str());
+    }
+    rc = pm_untranslate(cdirs.data(), (int)cdirs.size(), flag["-in_maf"].c_str(), flag["-out_maf"].c_str(), device);
   }
   else {
     fprintf(stderr, "mugsy_profiles: command '%s' is not implemented by this build\n", cmd.c_str());

@@ -24,6 +24,7 @@
 
 #include "pm_internal.hpp"
 #include "translate_device.hpp"
+#include "translate_store.hpp"
 
 namespace pm {
 
@@ -174,22 +175,6 @@ __global__ void s2p_batch_kernel(RowsD rows, i64 n, const int *row, const i64 *p
 
 // ------------------------------------------------------------------ device-resident tables
 
-struct RowsStore {
-  DevBuf range, length, gap_off, gaps, pre, bad, raw_s, raw_e, raw_gs, raw_ge;
-  i64 n = 0, G = 0;
-  RowsD view() const {
-    RowsD d;
-    d.n = n;
-    d.range = (const R2 *)range.p;
-    d.length = (const i64 *)length.p;
-    d.gap_off = (const i64 *)gap_off.p;
-    d.gaps = (const R2 *)gaps.p;
-    d.pre = (const i64 *)pre.p;
-    d.bad = (const int *)bad.p;
-    return d;
-  }
-};
-
 static int check_csr(const int64_t *off, int64_t n, const char *what) {
   if(n < 0) {
     return fail(PM_E_INVALID, std::string(what) + ": negative count");
@@ -211,7 +196,7 @@ static int check_csr(const int64_t *off, int64_t n, const char *what) {
   return PM_OK;
 }
 
-static int upload_rows(const pm_rows_t *h, RowsStore &s, hipStream_t stream) {
+int upload_rows(const pm_rows_t *h, RowsStore &s, hipStream_t stream) {
   if(!h || h->n < 0 || (h->n > 0 && (!h->start || !h->end || !h->length))) {
     return fail(PM_E_INVALID, "rows: null array");
   }
