@@ -96,8 +96,10 @@ __global__ void prepare_deltas_kernel(i64 n, const i64 *rs, const i64 *re, const
   }
 }
 
+// amdgpu_waves_per_eu(4): keep the register allocation at <= 128 VGPRs (4 waves per SIMD); the kernel is bound by the
+// latency of dependent loads, so resident waves matter more than a few spare registers.
 template <bool EMIT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                  int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off, const i64 *off_off, pm_entry_t *entries,
                  i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow) {
