@@ -74,15 +74,23 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 
 // DOT4: every count of A and every ACGT weight of B fits int8 (checked at batch creation), so the four base terms of
 // the column score are one v_dot4_i32_i8 instead of two v_dot2_i32_i16.
-template <int C, bool TRACE, bool DOT4>
-__global__ void __launch_bounds__(64)
+// NW: wavefronts per pair.  NW = 1 is the mapping described above.  NW > 1 (used when a launch has too few pairs to
+// fill the chip with one wave each) gives the pair a workgroup of NW waves; wave w runs stripes w, w+NW, ... and a
+// stripe may start a 64-row block as soon as the stripe to its left has published those rows of its boundary:
+// a pipeline of stripes, synchronised through one progress word per wave in LDS.  Waits are bounded (a timeout sets
+// *pipe_error and lets the wave run on, so the grid always drains).
+template <int C, bool TRACE, bool DOT4, int NW>
+__global__ void __launch_bounds__(64 * NW)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, i64 first_pair, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
-               int2 *__restrict__ bnd, int *__restrict__ scores, DpParamsD P) {
+               int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P) {
   static_assert(C % 8 == 0, "whole traceback words per lane per step");
   constexpr int TBW = C / 8;
-  __shared__ int4 ring[128];
-  const int lane = threadIdx.x;
+  __shared__ int4 ring_all[NW][128];
+  __shared__ int progress[NW]; // per wave: rows of boundary published so far, cumulated over the wave's stripes
+  const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  int4 *ring = ring_all[wv];
   const i64 pair = first_pair + blockIdx.x;
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
@@ -103,8 +111,14 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     }
     return;
   }
+  if(NW > 1) {
+    if(lane == 0) {
+      progress[wv] = 0;
+    }
+    __syncthreads();
+  }
 
-  for(int s = 0; s < n_stripes; ++s) {
+  for(int s = wv; s < n_stripes; s += NW) {
     const int j0 = s * W + lane * C; // this lane's first column of B (0-based)
     int w0[C], w1[C], w2[C], hop[C], f[C];
 #pragma unroll
@@ -164,6 +178,22 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           v.z = (int)((col >> 32) & 0xff) | (1 << 16);
         }
         ring[r & 127] = v;
+        if(NW > 1 && s > 0) {
+          // rows [t0, t0+63] of the left stripe's boundary must have been published by its wave
+          const int need = ((s - 1) / NW) * la + min(t0 + 64, la);
+          volatile int *word = &progress[(s - 1) % NW];
+          int spins = 0;
+          while(*word < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if(++spins > (1 << 22)) {
+              if(lane == 0) {
+                atomicOr(pipe_error, 1);
+              }
+              break;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         if(s > 0) {
           int2 b = make_int2(0, DP_NEG_INF);
           if(r < la) {
@@ -237,6 +267,13 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         }
       }
       }
+      if(NW > 1) {
+        // lane 63 has stored the boundary of rows < t1 - 63: publish the count (cumulated over this wave's stripes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if(lane == 0) {
+          *(volatile int *)&progress[wv] = (s / NW) * la + max(0, min(t1 - 63, la));
+        }
+      }
     }
     if(s == n_stripes - 1) {
       const int jj = lb - 1 - s * W;
@@ -249,7 +286,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       result = __builtin_amdgcn_readlane(hv, jj / C) + gop - (la + lb) * ge; // un-skew
     }
   }
-  if(lane == 0) {
+  if(lane == 0 && wv == (n_stripes - 1) % NW) {
     scores[pair] = result;
   }
 }
@@ -352,6 +389,8 @@ struct pm_dp_batch {
   i64 cells = 0;
   int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
   bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
+  int waves_override = 0; // PM_DP_WAVES=1|4 forces the waves-per-pair choice
+  DevBuf pipe_error;
   hipStream_t last_stream = nullptr;
 };
 
@@ -400,6 +439,9 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
     return fail(PM_E_INVALID, "out of host memory");
   }
   h->device = device;
+  if(const char *e = getenv("PM_DP_WAVES")) {
+    h->waves_override = atoi(e);
+  }
   if(const char *e = getenv("PM_DP_COLS")) {
     h->cols_per_lane = atoi(e) == 8 ? 8 : 16;
   }
@@ -452,6 +494,11 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   DTRY(h->d_off_b.upload(off_b, (size_t)(n_pairs + 1) * 8, stream));
   DTRY(h->bnd.alloc((size_t)h->total_a * 8));
   DTRY(h->scores.alloc((size_t)n_pairs * 4));
+  DTRY(h->pipe_error.alloc(4));
+  if(hipMemset(h->pipe_error.p, 0, 4) != hipSuccess) {
+    pm_dp_batch_destroy(h);
+    return fail(PM_E_HIP, "hipMemset failed");
+  }
   DTRY(h->n_ops.alloc((size_t)n_pairs * 4));
   DTRY(h->ops.alloc((size_t)(h->total_a + h->total_b)));
   // chunks: consecutive pairs whose traceback fits the budget; the buffer is reused chunk after chunk
@@ -511,31 +558,58 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
     if(timed) {
       PM_HIP(hipEventRecord(ev[0], stream));
     }
-#define DP_LAUNCH_FILL(CC, TR, D4)                                                                                                     \
-  dp_fill_kernel<CC, TR, D4><<<(unsigned)n, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p, \
-                                                             (const i64 *)h->d_off_b.p, first, tb_off, (unsigned *)h->tb.p, (int2 *)h->bnd.p, \
-                                                             (int *)h->scores.p, h->params)
-#define DP_LAUNCH_FILL_D4(CC, TR) \
-  if(h->dot4) {                   \
-    DP_LAUNCH_FILL(CC, TR, true); \
-  }                               \
-  else {                          \
-    DP_LAUNCH_FILL(CC, TR, false); \
+    // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
+    // have several stripes to pipeline
+    int nw = 1;
+    {
+      i64 max_stripes = 0, max_la = 0;
+      for(i64 k = first; k < first + n; ++k) {
+        i64 lbk = h->off_b[k + 1] - h->off_b[k];
+        max_stripes = std::max(max_stripes, (lbk + 64 * h->cols_per_lane - 1) / (64 * h->cols_per_lane));
+        max_la = std::max(max_la, h->off_a[k + 1] - h->off_a[k]);
+      }
+      bool fits = (max_stripes / 4 + 2) * max_la < ((i64)1 << 30); // the progress word is an int
+      if(h->cols_per_lane == 16 && fits && max_stripes >= 2 && n < 4096) {
+        nw = 4;
+      }
+      if(h->waves_override == 1 || (h->waves_override == 4 && h->cols_per_lane == 16 && fits)) {
+        nw = h->waves_override;
+      }
+    }
+#define DP_LAUNCH_FILL(CC, TR, D4, NWV)                                                                                                   \
+  dp_fill_kernel<CC, TR, D4, NWV><<<(unsigned)n, 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,             \
+                                                                        (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p, first, tb_off, \
+                                                                        (unsigned *)h->tb.p, (int2 *)h->bnd.p, (int *)h->scores.p,         \
+                                                                        (int *)h->pipe_error.p, h->params)
+#define DP_LAUNCH_FILL_D4(CC, TR, NWV) \
+  if(h->dot4) {                        \
+    DP_LAUNCH_FILL(CC, TR, true, NWV);  \
+  }                                    \
+  else {                               \
+    DP_LAUNCH_FILL(CC, TR, false, NWV); \
   }
-    if(h->cols_per_lane == 16) {
+    if(h->cols_per_lane == 16 && nw == 4) {
       if(traceback) {
-        DP_LAUNCH_FILL_D4(16, true)
+        DP_LAUNCH_FILL_D4(16, true, 4)
       }
       else {
-        DP_LAUNCH_FILL_D4(16, false)
+        DP_LAUNCH_FILL_D4(16, false, 4)
+      }
+    }
+    else if(h->cols_per_lane == 16) {
+      if(traceback) {
+        DP_LAUNCH_FILL_D4(16, true, 1)
+      }
+      else {
+        DP_LAUNCH_FILL_D4(16, false, 1)
       }
     }
     else {
       if(traceback) {
-        DP_LAUNCH_FILL_D4(8, true)
+        DP_LAUNCH_FILL_D4(8, true, 1)
       }
       else {
-        DP_LAUNCH_FILL_D4(8, false)
+        DP_LAUNCH_FILL_D4(8, false, 1)
       }
     }
 #undef DP_LAUNCH_FILL_D4
@@ -619,6 +693,13 @@ int pm_dp_batch_fetch(pm_dp_batch_t *h, int32_t *scores, uint8_t *ops, int32_t *
     return rc;
   }
   PM_HIP(hipStreamSynchronize(h->last_stream));
+  {
+    int perr = 0;
+    PM_HIP(hipMemcpy(&perr, h->pipe_error.p, 4, hipMemcpyDeviceToHost));
+    if(perr) {
+      return fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
+    }
+  }
   if(scores && h->n_pairs > 0) {
     PM_HIP(hipMemcpy(scores, h->scores.p, (size_t)h->n_pairs * 4, hipMemcpyDeviceToHost));
   }
