@@ -73,6 +73,24 @@ def test_chunked_workspace_gives_same_results(oracle_build):
     assert np.array_equal(s1, s2) and all(np.array_equal(a, b) for a, b in zip(p1, p2))
 
 
+@pytest.mark.parametrize("waves", ["1", "4"])
+@pytest.mark.parametrize("cols", ["8", "16"])
+@pytest.mark.parametrize("dot4", ["0", "1"])
+def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, oracle_build, monkeypatch):
+    """One wave per pair and the 4-wave stripe pipeline, 8 and 16 columns per lane, int8 and int16 column scores: all
+    must give the oracle's scores and paths on pairs that span several stripes (B up to 2 600 columns)."""
+    monkeypatch.setenv("PM_DP_WAVES", waves)
+    monkeypatch.setenv("PM_DP_COLS", cols)
+    monkeypatch.setenv("PM_DP_DOT4", dot4)
+    rng = np.random.default_rng(int(waves) * 100 + int(cols) + int(dot4))
+    la = [700, 64, 1300, 129, 2000, 5]
+    lb = [2600, 1025, 1024, 2049, 513, 1100]
+    cols_of = lambda n: np.concatenate([rng.integers(0, 3, size=(n, 5)).astype(np.uint8), np.zeros((n, 3), np.uint8)], axis=1)
+    inputs = dp.DpInputs(np.concatenate([cols_of(n) for n in la]), np.concatenate([[0], np.cumsum(la)]).astype(np.int64),
+                         np.concatenate([cols_of(n) for n in lb]), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+    run_and_compare(inputs, dp.make_params(4, 4))
+
+
 def test_general_substitution_matrix_and_zero_penalties(oracle_build):
     rng = np.random.default_rng(8)
     inputs = dp.synth_pairs(79, 10, 5, 250, vary_length=True)
