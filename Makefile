@@ -14,8 +14,20 @@ all: lib cli
 
 lib: $(LIB)
 
-$(LIB): $(LIB_SRCS) $(LIB_HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_SRCS)
+# one object per source so that `make -j` compiles them side by side (dp_kernels.hip alone is most of the build)
+OBJDIR    = build/obj
+LIB_OBJS  = $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(LIB_SRCS))
+
+$(OBJDIR)/%.hip.o: $(CSRC)/%.hip $(LIB_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(OBJDIR)/%.cc.o: $(CSRC)/%.cc $(LIB_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(LIB_OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIB_OBJS)
 
 cli: bin/m_translate bin/m_sort_delta bin/maf_analyzer bin/mugsy_profiles
 
@@ -37,5 +49,6 @@ oracle:
 	if [ -d /root/reference/lib ]; then $(MAKE) -C oracle ref; fi
 
 clean:
+	rm -rf build
 	rm -f $(LIB) bin/m_translate bin/m_sort_delta bin/maf_analyzer bin/mugsy_profiles
 	$(MAKE) -C oracle clean
