@@ -111,12 +111,13 @@ int pm_device_info(int dev, char *name, int cap, int *compute_units, int64_t *hb
 /* Upload a batch, build the per-gap prefix tables and validate the gap lists on the device. */
 int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
                   int device, pm_job_t **out);
-/* One pass of the hot path over every unit: count, scan, emit.  Asynchronous on `hip_stream`
+/* One pass of the hot path over every unit: filter, count, scan, emit.  Asynchronous on `hip_stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  Inputs and outputs stay in HBM. */
 int pm_job_run(pm_job_t *job, void *hip_stream);
-/* The same pass with HIP events recorded on `hip_stream` between its three phases; waits for completion and
- * reports each phase's device time in milliseconds (measurement aid for bench.py; any pointer may be NULL). */
-int pm_job_run_profiled(pm_job_t *job, void *hip_stream, float *ms_count, float *ms_scan, float *ms_emit);
+/* The same pass with HIP events recorded on `hip_stream` between its four phases (filter + compaction of the units
+ * that survive the first overlap test, count pass, offset scans, emit pass); waits for completion and reports each
+ * phase's device time in milliseconds (measurement aid for bench.py; any pointer may be NULL). */
+int pm_job_run_profiled(pm_job_t *job, void *hip_stream, float *ms_filter, float *ms_count, float *ms_scan, float *ms_emit);
 /* Wait for the last run and report the output sizes. */
 int pm_job_sizes(pm_job_t *job, int64_t *n_entries, int64_t *n_offsets);
 /* Copy results to host arrays sized from pm_job_sizes.  unit_entry_off has units.n + 1 elements: unit u owns

@@ -80,7 +80,7 @@ def lib() -> C.CDLL:
         l.pm_job_create.argtypes = [C.POINTER(PmRows), C.POINTER(PmRows), C.POINTER(PmDeltas), C.POINTER(PmUnits), C.c_int,
                                     C.POINTER(C.c_void_p)]
         l.pm_job_run.argtypes = [C.c_void_p, C.c_void_p]
-        l.pm_job_run_profiled.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.pm_job_run_profiled.argtypes = [C.c_void_p, C.c_void_p] + [C.POINTER(C.c_float)] * 4
         l.pm_job_sizes.argtypes = [C.c_void_p, _i64p, _i64p]
         l.pm_job_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_job_algorithmic_bytes.argtypes = [C.c_void_p, _i64p]

@@ -524,15 +524,17 @@ PM_HD __forceinline__ PV row_view(const RowsD &rows, int r) {
   return p;
 }
 
-// One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
-template <bool EMIT>
-PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r,
-                               Sink<EMIT> &sink) {
+// First part of a unit, up to the test that ends most of them (m_translate.cc:636-639 and :496-513): the
+// overlap of the entry with both rows, the entry's two rows as profiles over its own columns, and the window of
+// columns both rows cover.  `live` = the unit goes on to the subset/merge part.
+PM_HD inline int unit_prefix(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r, PV &lp, PV &rp, PV &dr,
+                             PV &dq, R2 &cols, bool &live) {
+  live = false;
   if(left.bad[l] | right.bad[r] | ds.bad[d]) {
     return PM_ST_MALFORMED_INPUT;
   }
-  PV lp = row_view(left, l);
-  PV rp = row_view(right, r);
+  lp = row_view(left, l);
+  rp = row_view(right, r);
   R2 de_ref = ds.ref[d], de_qry = ds.qry[d];
   R2 ref_seq, query_seq;
   if(!overlap(de_ref, lp.range, ref_seq) || !overlap(de_qry, rp.range, query_seq)) {
@@ -544,7 +546,6 @@ PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &
     de_qry = R2{de_qry.e, de_qry.s};
   }
   // the entry's two rows as profiles over its own columns (:496-506)
-  PV dr, dq;
   i64 ro = ds.ref_off[d], qo = ds.qry_off[d];
   dr.range = de_ref;
   dr.n = (int)(ds.ref_off[d + 1] - ro);
@@ -558,13 +559,25 @@ PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &
   dq.len = rlen(de_qry) + dq.pre[dq.n];
 
   int st;
-  R2 d_ref_cols, d_query_cols, cols;
+  R2 d_ref_cols, d_query_cols;
   if((st = profile_idx_of_seq_idx(dr, ref_seq.s, d_ref_cols.s))) return st; // :508-511
   if((st = profile_idx_of_seq_idx(dr, ref_seq.e, d_ref_cols.e))) return st;
   if((st = profile_idx_of_seq_idx(dq, query_seq.s, d_query_cols.s))) return st;
   if((st = profile_idx_of_seq_idx(dq, query_seq.e, d_query_cols.e))) return st;
-  if(!overlap(d_ref_cols, d_query_cols, cols)) {
-    return PM_ST_OK; // :513
+  live = overlap(d_ref_cols, d_query_cols, cols); // :513
+  return PM_ST_OK;
+}
+
+// One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
+template <bool EMIT>
+PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r,
+                               Sink<EMIT> &sink) {
+  PV lp, rp, dr, dq;
+  R2 cols;
+  bool live;
+  int st = unit_prefix(left, right, ds, d, l, r, lp, rp, dr, dq, cols, live);
+  if(st || !live) {
+    return st;
   }
   Merge<EMIT> m;
   m.sink = sink;

@@ -96,25 +96,53 @@ __global__ void prepare_deltas_kernel(i64 n, const i64 *rs, const i64 *re, const
   }
 }
 
+// Filter pass: most (entry, left row, right row) triples the reference's loops visit end at the first overlap test
+// (m_translate.cc:513).  One lane per unit runs just that prefix; the survivors ("live" units) are compacted so that
+// the count and emit passes run on dense wavefronts instead of waiting for the few long lanes of every wavefront.
+__global__ void __launch_bounds__(64)
+translate_filter_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
+                        int *status, i64 *cnt_ent, i64 *cnt_off, int *live_flag) {
+  i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(u >= n_units) {
+    return;
+  }
+  PV lp, rp, dr, dq;
+  R2 cols;
+  bool live;
+  int st = unit_prefix(left, right, ds, u_delta[u], u_left[u], u_right[u], lp, rp, dr, dq, cols, live);
+  status[u] = st;
+  cnt_ent[u] = 0;
+  cnt_off[u] = 0;
+  live_flag[u] = (!st && live) ? 1 : 0;
+}
+
+__global__ void scatter_live_kernel(i64 n_units, const int *live_flag, const int *live_pos, int *live_units) {
+  i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(u < n_units && live_flag[u]) {
+    live_units[live_pos[u]] = (int)u;
+  }
+}
+
 // amdgpu_waves_per_eu(4): keep the register allocation at <= 128 VGPRs (4 waves per SIMD); the kernel is bound by the
 // latency of dependent loads, so resident waves matter more than a few spare registers.
 template <bool EMIT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
-                 int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off, const i64 *off_off, pm_entry_t *entries,
-                 i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow) {
-  i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+                 const int *live_units, const int *live_pos, int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off,
+                 const i64 *off_off, pm_entry_t *entries, i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow) {
+  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(EMIT) {
     if(ent_off[n_units] > ent_cap || off_off[n_units] > off_cap) { // uniform: buffers sized by an older run
-      if(u == 0) {
+      if(k == 0) {
         *overflow = 1;
       }
       return;
     }
   }
-  if(u >= n_units) {
+  if(k >= live_pos[n_units]) { // the grid covers all units; only the live ones (compacted by the filter pass) have a lane
     return;
   }
+  const i64 u = live_units[k];
   if(EMIT) {
     if(ent_off[u + 1] == ent_off[u] && off_off[u + 1] == off_off[u]) {
       return; // the count pass found nothing to write for this unit (most left x right pairs of an entry)
@@ -318,6 +346,8 @@ struct pm_job {
   DevBuf u_delta, u_left, u_right;
   i64 n_units = 0;
   DevBuf status, cnt_ent, cnt_off, ent_off, off_off, entries, offsets, overflow, scan_tmp;
+  DevBuf live_flag, live_pos, live_units, scan_tmp32;
+  size_t scan_tmp32_bytes = 0;
   size_t scan_tmp_bytes = 0;
   i64 ent_cap = 0, off_cap = 0;
   i64 n_entries = 0, n_offsets = 0;
@@ -326,34 +356,63 @@ struct pm_job {
   bool ran = false;
 };
 
-static int job_launch_count_scan(pm_job *j, hipStream_t stream) {
+// The four phases of one pass; `ev` (5 events) brackets them when the pass is being timed.
+static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t *ev) {
   i64 U = j->n_units;
   unsigned blocks = (unsigned)((U + 63) / 64);
+  unsigned blocks256 = (unsigned)((U + 255) / 256);
+  if(ev) {
+    PM_HIP(hipEventRecord(ev[0], stream));
+  }
+  // 1. filter + compaction of the live units
   if(U > 0) {
-    translate_kernel<false><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
-                                                       (const int *)j->u_left.p, (const int *)j->u_right.p, (int *)j->status.p,
-                                                       (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, 0, 0,
-                                                       nullptr);
+    translate_filter_kernel<<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
+                                                      (const int *)j->u_left.p, (const int *)j->u_right.p, (int *)j->status.p,
+                                                      (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, (int *)j->live_flag.p);
     PM_HIP(hipGetLastError());
   }
+  size_t tmp32 = j->scan_tmp32_bytes;
+  PM_HIP(rocprim::exclusive_scan(j->scan_tmp32.p, tmp32, (int *)j->live_flag.p, (int *)j->live_pos.p, 0, (size_t)(U + 1),
+                                 rocprim::plus<int>(), stream));
+  if(U > 0) {
+    scatter_live_kernel<<<blocks256, 256, 0, stream>>>(U, (const int *)j->live_flag.p, (const int *)j->live_pos.p, (int *)j->live_units.p);
+    PM_HIP(hipGetLastError());
+  }
+  if(ev) {
+    PM_HIP(hipEventRecord(ev[1], stream));
+  }
+  // 2. count pass over the live units
+  if(U > 0) {
+    translate_kernel<false><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
+                                                       (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,
+                                                       (const int *)j->live_pos.p, (int *)j->status.p, (i64 *)j->cnt_ent.p,
+                                                       (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr);
+    PM_HIP(hipGetLastError());
+  }
+  if(ev) {
+    PM_HIP(hipEventRecord(ev[2], stream));
+  }
+  // 3. output offsets
   size_t tmp = j->scan_tmp_bytes;
   PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off.p, (i64)0, (size_t)(U + 1),
                                  rocprim::plus<i64>(), stream));
   tmp = j->scan_tmp_bytes;
   PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_off.p, (i64 *)j->off_off.p, (i64)0, (size_t)(U + 1),
                                  rocprim::plus<i64>(), stream));
-  return PM_OK;
-}
-
-static int job_launch_emit(pm_job *j, hipStream_t stream) {
-  i64 U = j->n_units;
-  unsigned blocks = (unsigned)((U + 63) / 64);
-  if(U > 0) {
+  if(ev) {
+    PM_HIP(hipEventRecord(ev[3], stream));
+  }
+  // 4. emit pass over the live units
+  if(emit && U > 0) {
     translate_kernel<true><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
-                                                      (const int *)j->u_left.p, (const int *)j->u_right.p, nullptr, nullptr, nullptr,
-                                                      (const i64 *)j->ent_off.p, (const i64 *)j->off_off.p, (pm_entry_t *)j->entries.p,
-                                                      (i64 *)j->offsets.p, j->ent_cap, j->off_cap, (int *)j->overflow.p);
+                                                      (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,
+                                                      (const int *)j->live_pos.p, nullptr, nullptr, nullptr, (const i64 *)j->ent_off.p,
+                                                      (const i64 *)j->off_off.p, (pm_entry_t *)j->entries.p, (i64 *)j->offsets.p, j->ent_cap,
+                                                      j->off_cap, (int *)j->overflow.p);
     PM_HIP(hipGetLastError());
+  }
+  if(ev) {
+    PM_HIP(hipEventRecord(ev[4], stream));
   }
   return PM_OK;
 }
@@ -419,6 +478,13 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   JTRY(j->ent_off.alloc((size_t)(U + 1) * 8));
   JTRY(j->off_off.alloc((size_t)(U + 1) * 8));
   JTRY(j->overflow.alloc(4));
+  JTRY(j->live_flag.alloc((size_t)(U + 1) * 4));
+  JTRY(j->live_pos.alloc((size_t)(U + 1) * 4));
+  JTRY(j->live_units.alloc((size_t)(U + 1) * 4));
+  if(hipMemsetAsync(j->live_flag.p, 0, (size_t)(U + 1) * 4, stream) != hipSuccess) {
+    pm_job_destroy(j);
+    return fail(PM_E_HIP, "hipMemsetAsync failed");
+  }
   if(hipMemsetAsync(j->cnt_ent.p, 0, (size_t)(U + 1) * 8, stream) != hipSuccess ||
      hipMemsetAsync(j->cnt_off.p, 0, (size_t)(U + 1) * 8, stream) != hipSuccess ||
      hipMemsetAsync(j->overflow.p, 0, 4, stream) != hipSuccess) {
@@ -432,9 +498,19 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
     return fail(PM_E_HIP, "rocprim scan sizing failed");
   }
   j->scan_tmp_bytes = tmp;
+  {
+    size_t tmp32 = 0;
+    if(rocprim::exclusive_scan(nullptr, tmp32, (int *)j->live_flag.p, (int *)j->live_pos.p, 0, (size_t)(U + 1), rocprim::plus<int>(), stream) !=
+       hipSuccess) {
+      pm_job_destroy(j);
+      return fail(PM_E_HIP, "rocprim scan sizing failed");
+    }
+    j->scan_tmp32_bytes = tmp32;
+    JTRY(j->scan_tmp32.alloc(tmp32 ? tmp32 : 8));
+  }
   JTRY(j->scan_tmp.alloc(tmp ? tmp : 8));
   // Size the outputs once: the inputs of a job never change, so neither do its output sizes.
-  JTRY(job_launch_count_scan(j, stream));
+  JTRY(job_launch_pass(j, stream, false, nullptr));
   JTRY(job_read_totals(j, stream));
   if(j->n_entries < 0 || j->n_offsets < 0 || j->n_entries > ((i64)1 << 36) || j->n_offsets > ((i64)1 << 38)) {
     pm_job_destroy(j);
@@ -473,14 +549,13 @@ int pm_job_run(pm_job_t *j, void *hip_stream) {
     return rc;
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  PM_TRY(job_launch_count_scan(j, stream));
-  PM_TRY(job_launch_emit(j, stream));
+  PM_TRY(job_launch_pass(j, stream, true, nullptr));
   j->last_stream = stream;
   j->ran = true;
   return PM_OK;
 }
 
-int pm_job_run_profiled(pm_job_t *j, void *hip_stream, float *ms_count, float *ms_scan, float *ms_emit) {
+int pm_job_run_profiled(pm_job_t *j, void *hip_stream, float *ms_filter, float *ms_count, float *ms_scan, float *ms_emit) {
   if(!j) {
     return fail(PM_E_INVALID, "pm_job_run_profiled: null job");
   }
@@ -489,45 +564,24 @@ int pm_job_run_profiled(pm_job_t *j, void *hip_stream, float *ms_count, float *m
     return rc;
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  hipEvent_t ev[4];
-  for(int k = 0; k < 4; ++k) {
+  hipEvent_t ev[5];
+  for(int k = 0; k < 5; ++k) {
     PM_HIP(hipEventCreate(&ev[k]));
   }
-  i64 U = j->n_units;
-  unsigned blocks = (unsigned)((U + 63) / 64);
-  PM_HIP(hipEventRecord(ev[0], stream));
-  if(U > 0) {
-    translate_kernel<false><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
-                                                       (const int *)j->u_left.p, (const int *)j->u_right.p, (int *)j->status.p,
-                                                       (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, 0, 0,
-                                                       nullptr);
-  }
-  PM_HIP(hipEventRecord(ev[1], stream));
-  size_t tmp = j->scan_tmp_bytes;
-  PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off.p, (i64)0, (size_t)(U + 1),
-                                 rocprim::plus<i64>(), stream));
-  tmp = j->scan_tmp_bytes;
-  PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_off.p, (i64 *)j->off_off.p, (i64)0, (size_t)(U + 1),
-                                 rocprim::plus<i64>(), stream));
-  PM_HIP(hipEventRecord(ev[2], stream));
-  PM_TRY(job_launch_emit(j, stream));
-  PM_HIP(hipEventRecord(ev[3], stream));
-  PM_HIP(hipEventSynchronize(ev[3]));
-  float ms[3] = {0, 0, 0};
-  for(int k = 0; k < 3; ++k) {
+  PM_TRY(job_launch_pass(j, stream, true, ev));
+  PM_HIP(hipEventSynchronize(ev[4]));
+  float ms[4] = {0, 0, 0, 0};
+  for(int k = 0; k < 4; ++k) {
     PM_HIP(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
   }
-  for(int k = 0; k < 4; ++k) {
+  for(int k = 0; k < 5; ++k) {
     (void)hipEventDestroy(ev[k]);
   }
-  if(ms_count) {
-    *ms_count = ms[0];
-  }
-  if(ms_scan) {
-    *ms_scan = ms[1];
-  }
-  if(ms_emit) {
-    *ms_emit = ms[2];
+  float *outp[4] = {ms_filter, ms_count, ms_scan, ms_emit};
+  for(int k = 0; k < 4; ++k) {
+    if(outp[k]) {
+      *outp[k] = ms[k];
+    }
   }
   j->last_stream = stream;
   j->ran = true;

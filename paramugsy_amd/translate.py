@@ -110,10 +110,10 @@ class TranslateJob:
         capi.check(capi.lib().pm_job_run(self._h, C.c_void_p(stream)))
 
     def run_profiled(self, stream: int = 0):
-        """One pass with HIP events between the phases -> (ms_count, ms_scan, ms_emit); waits for completion."""
-        a, b, c = C.c_float(), C.c_float(), C.c_float()
-        capi.check(capi.lib().pm_job_run_profiled(self._h, C.c_void_p(stream), C.byref(a), C.byref(b), C.byref(c)))
-        return a.value, b.value, c.value
+        """One pass with HIP events between the phases -> (ms_filter, ms_count, ms_scan, ms_emit); waits for completion."""
+        f, a, b, c = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        capi.check(capi.lib().pm_job_run_profiled(self._h, C.c_void_p(stream), C.byref(f), C.byref(a), C.byref(b), C.byref(c)))
+        return f.value, a.value, b.value, c.value
 
     def sizes(self):
         ne, no = C.c_int64(), C.c_int64()
