@@ -528,8 +528,9 @@ PM_HD __forceinline__ PV row_view(const RowsD &rows, int r) {
 // overlap of the entry with both rows, the entry's two rows as profiles over its own columns, and the window of
 // columns both rows cover.  `live` = the unit goes on to the subset/merge part.
 PM_HD inline int unit_prefix(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r, PV &lp, PV &rp, PV &dr,
-                             PV &dq, R2 &cols, bool &live) {
+                             PV &dq, R2 &cols, bool &live, int &orientation) {
   live = false;
+  orientation = 0;
   if(left.bad[l] | right.bad[r] | ds.bad[d]) {
     return PM_ST_MALFORMED_INPUT;
   }
@@ -541,6 +542,7 @@ PM_HD inline int unit_prefix(const RowsD &left, const RowsD &right, const Deltas
     return PM_ST_OK; // :636-639
   }
   int o = fwd(de_ref) != fwd(lp.range) ? 1 : 0; // :210-217
+  orientation = o;
   if(o) {
     de_ref = R2{de_ref.e, de_ref.s};
     de_qry = R2{de_qry.e, de_qry.s};
@@ -568,19 +570,21 @@ PM_HD inline int unit_prefix(const RowsD &left, const RowsD &right, const Deltas
   return PM_ST_OK;
 }
 
-// One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
+// What the merge of a unit starts from, as plain numbers: enough to rebuild the Merge without redoing the ~20 binary
+// searches of the set-up.  The count pass saves it per live unit, the emit pass restores it.
+struct UnitState {
+  int lo[4], n[4];   // kept gaps of: left row, right row, entry's reference row, entry's query row
+  i64 ws[4], we[4];  // their clip windows
+  i64 ref_start, query_start, column, last_column, query_columns;
+  int orientation;   // 1: the entry is used reversed (m_translate.cc:210-217)
+  int mirrored;      // the right row is walked backwards (:557)
+};
+
+// Set-up of a unit that passed unit_prefix (m_translate.cc:527-610): `proceed` = the merge has to run.
 template <bool EMIT>
-PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r,
-                               Sink<EMIT> &sink) {
-  PV lp, rp, dr, dq;
-  R2 cols;
-  bool live;
-  int st = unit_prefix(left, right, ds, d, l, r, lp, rp, dr, dq, cols, live);
-  if(st || !live) {
-    return st;
-  }
-  Merge<EMIT> m;
-  m.sink = sink;
+PM_HD inline int unit_setup(const PV &lp, const PV &rp, const PV &dr, const PV &dq, R2 cols, Merge<EMIT> &m, bool &proceed) {
+  proceed = false;
+  int st;
   R2 d_ref_seq, d_query_seq, l_seq, r_seq;
   bool none_r, none_q;
   if((st = subset_profile(dr, cols.s, cols.e, m.delta.v0, d_ref_seq, none_r))) return st;   // :527-529
@@ -616,10 +620,16 @@ PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &
   m.mirrored = mirrored;
   m.query_columns = rp.len;
   m.b_restart(ref_start, query_start);
+  proceed = true;
+  return PM_ST_OK;
+}
 
-  // :612-618.  Same budget as oracle/pm_oracle.cc: far above any terminating run; every lane reaches it.
+// The merge loop itself (m_translate.cc:612-618).  Same step budget as oracle/pm_oracle.cc: far above any
+// terminating run; every lane reaches it.
+template <bool EMIT>
+PM_HD inline int unit_merge(Merge<EMIT> &m) {
   i64 budget = 4 * (i64)(m.rows.v0.n + m.rows.v1.n + m.delta.v0.n + m.delta.v1.n) + 64;
-  st = PM_ST_OK;
+  int st = PM_ST_OK;
   while(!m.rows.done() || !m.delta.done()) {
     if(budget-- <= 0) {
       st = PM_ST_STEP_LIMIT;
@@ -633,6 +643,76 @@ PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &
   if(!st) {
     st = m.step();
   }
+  return st;
+}
+
+template <bool EMIT>
+PM_HD inline void unit_save(const Merge<EMIT> &m, int orientation, UnitState &s) {
+  const GapView *v[4] = {&m.rows.v0, &m.rows.v1, &m.delta.v0, &m.delta.v1};
+  for(int k = 0; k < 4; ++k) {
+    s.lo[k] = v[k]->lo;
+    s.n[k] = v[k]->n;
+    s.ws[k] = v[k]->ws;
+    s.we[k] = v[k]->we;
+  }
+  s.ref_start = m.ref_pos;
+  s.query_start = m.query_pos;
+  s.column = m.column;
+  s.last_column = m.last_column;
+  s.query_columns = m.query_columns;
+  s.orientation = orientation;
+  s.mirrored = m.mirrored ? 1 : 0;
+}
+
+template <bool EMIT>
+PM_HD inline void unit_restore(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r, const UnitState &s,
+                               Merge<EMIT> &m) {
+  const R2 *g[4] = {left.gaps + left.gap_off[l], right.gaps + right.gap_off[r], ds.ref_gaps[s.orientation] + ds.ref_off[d],
+                    ds.qry_gaps[s.orientation] + ds.qry_off[d]};
+  GapView *v[4] = {&m.rows.v0, &m.rows.v1, &m.delta.v0, &m.delta.v1};
+  for(int k = 0; k < 4; ++k) {
+    v[k]->g = g[k];
+    v[k]->lo = s.lo[k];
+    v[k]->n = s.n[k];
+    v[k]->ws = s.ws[k];
+    v[k]->we = s.we[k];
+    v[k]->mirror = false;
+    v[k]->L = 0;
+  }
+  m.rows.v1.mirror = s.mirrored != 0;
+  m.rows.v1.L = s.query_columns;
+  m.rows.at0 = m.rows.at1 = m.delta.at0 = m.delta.at1 = 0;
+  m.rows.held0 = m.rows.held1 = m.delta.held0 = m.delta.held1 = false;
+  m.rows.hold0 = m.rows.hold1 = m.delta.hold0 = m.delta.hold1 = R2{0, 0};
+  m.ref_pos = s.ref_start;
+  m.query_pos = s.query_start;
+  m.column = s.column;
+  m.last_column = s.last_column;
+  m.mirrored = s.mirrored != 0;
+  m.query_columns = s.query_columns;
+  m.b_restart(s.ref_start, s.query_start);
+}
+
+// One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
+template <bool EMIT>
+PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r,
+                               Sink<EMIT> &sink) {
+  PV lp, rp, dr, dq;
+  R2 cols;
+  bool live;
+  int orientation;
+  int st = unit_prefix(left, right, ds, d, l, r, lp, rp, dr, dq, cols, live, orientation);
+  if(st || !live) {
+    return st;
+  }
+  Merge<EMIT> m;
+  m.sink = sink;
+  bool proceed;
+  st = unit_setup<EMIT>(lp, rp, dr, dq, cols, m, proceed);
+  if(st || !proceed) {
+    return st;
+  }
+  st = unit_merge<EMIT>(m);
   sink = m.sink;
   return st;
 }

@@ -109,7 +109,8 @@ translate_filter_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const 
   PV lp, rp, dr, dq;
   R2 cols;
   bool live;
-  int st = unit_prefix(left, right, ds, u_delta[u], u_left[u], u_right[u], lp, rp, dr, dq, cols, live);
+  int orientation;
+  int st = unit_prefix(left, right, ds, u_delta[u], u_left[u], u_right[u], lp, rp, dr, dq, cols, live, orientation);
   status[u] = st;
   cnt_ent[u] = 0;
   cnt_off[u] = 0;
@@ -129,7 +130,7 @@ template <bool EMIT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                  const int *live_units, const int *live_pos, int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off,
-                 const i64 *off_off, pm_entry_t *entries, i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow) {
+                 const i64 *off_off, pm_entry_t *entries, i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow, UnitState *states) {
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(EMIT) {
     if(ent_off[n_units] > ent_cap || off_off[n_units] > off_cap) { // uniform: buffers sized by an older run
@@ -161,8 +162,35 @@ translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_
     sink.off_base = off_off[u];
     sink.off_cap = off_off[u + 1] - off_off[u];
   }
-  int st = run_unit<EMIT>(left, right, ds, u_delta[u], u_left[u], u_right[u], sink);
-  if(!EMIT) {
+  const int d = u_delta[u], l = u_left[u], r = u_right[u];
+  if constexpr(EMIT) {
+    // the count pass left this unit's merge start in states[k]: no set-up to redo
+    Merge<EMIT> m;
+    m.sink = sink;
+    const UnitState s = states[k];
+    unit_restore<EMIT>(left, right, ds, d, l, r, s, m);
+    (void)unit_merge<EMIT>(m);
+  }
+  else {
+    PV lp, rp, dr, dq;
+    R2 cols;
+    bool live, proceed = false;
+    int orientation;
+    Merge<EMIT> m;
+    m.sink = sink;
+    int st = unit_prefix(left, right, ds, d, l, r, lp, rp, dr, dq, cols, live, orientation);
+    if(!st && live) {
+      st = unit_setup<EMIT>(lp, rp, dr, dq, cols, m, proceed);
+      if(!st && proceed) {
+        if(states) { // null only in the sizing pass of pm_job_create
+          UnitState s;
+          unit_save<EMIT>(m, orientation, s);
+          states[k] = s;
+        }
+        st = unit_merge<EMIT>(m);
+        sink = m.sink;
+      }
+    }
     status[u] = st;
     cnt_ent[u] = sink.n_ent;
     cnt_off[u] = sink.n_off;
@@ -347,6 +375,7 @@ struct pm_job {
   i64 n_units = 0;
   DevBuf status, cnt_ent, cnt_off, ent_off, off_off, entries, offsets, overflow, scan_tmp;
   DevBuf live_flag, live_pos, live_units, scan_tmp32;
+  DevBuf states; // UnitState per live unit (null during the sizing pass of pm_job_create)
   size_t scan_tmp32_bytes = 0;
   size_t scan_tmp_bytes = 0;
   i64 ent_cap = 0, off_cap = 0;
@@ -386,7 +415,7 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
     translate_kernel<false><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
                                                        (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,
                                                        (const int *)j->live_pos.p, (int *)j->status.p, (i64 *)j->cnt_ent.p,
-                                                       (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr);
+                                                       (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, (UnitState *)j->states.p);
     PM_HIP(hipGetLastError());
   }
   if(ev) {
@@ -408,7 +437,7 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
                                                       (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,
                                                       (const int *)j->live_pos.p, nullptr, nullptr, nullptr, (const i64 *)j->ent_off.p,
                                                       (const i64 *)j->off_off.p, (pm_entry_t *)j->entries.p, (i64 *)j->offsets.p, j->ent_cap,
-                                                      j->off_cap, (int *)j->overflow.p);
+                                                      j->off_cap, (int *)j->overflow.p, (UnitState *)j->states.p);
     PM_HIP(hipGetLastError());
   }
   if(ev) {
@@ -518,6 +547,14 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   }
   j->ent_cap = j->n_entries;
   j->off_cap = j->n_offsets;
+  {
+    int n_live = 0;
+    if(hipMemcpy(&n_live, (int *)j->live_pos.p + U, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      pm_job_destroy(j);
+      return fail(PM_E_HIP, "hipMemcpy failed");
+    }
+    JTRY(j->states.alloc((size_t)(n_live > 0 ? n_live : 1) * sizeof(UnitState)));
+  }
   JTRY(j->entries.alloc((size_t)j->ent_cap * sizeof(pm_entry_t)));
   JTRY(j->offsets.alloc((size_t)j->off_cap * 8));
   // free the SoA staging copies
