@@ -126,6 +126,9 @@ int pm_job_sizes(pm_job_t *job, int64_t *n_entries, int64_t *n_offsets);
 int pm_job_fetch(pm_job_t *job, int32_t *unit_status, int64_t *unit_entry_off, pm_entry_t *entries, int64_t *offsets);
 /* Algorithmic bytes one pm_job_run moves (inputs read + outputs written), for roofline accounting. */
 int pm_job_algorithmic_bytes(pm_job_t *job, int64_t *bytes);
+/* Algorithmic bytes of the two heavy kernels separately (count pass, emit pass) and the number of live units (those
+ * that pass the first overlap test), for per-kernel roofline accounting. */
+int pm_job_kernel_bytes(pm_job_t *job, int64_t *count_bytes, int64_t *emit_bytes, int64_t *n_live);
 void pm_job_destroy(pm_job_t *job);
 
 /* Batched coordinate conversions on one side's rows (a3/a4).  `row` selects the row per query; results and

@@ -695,6 +695,27 @@ int pm_job_algorithmic_bytes(pm_job_t *j, int64_t *bytes) {
   return PM_OK;
 }
 
+int pm_job_kernel_bytes(pm_job_t *j, int64_t *count_bytes, int64_t *emit_bytes, int64_t *n_live) {
+  if(!j) {
+    return fail(PM_E_INVALID, "pm_job_kernel_bytes: null job");
+  }
+  int live = 0;
+  PM_HIP(hipMemcpy(&live, (int *)j->live_pos.p + j->n_units, 4, hipMemcpyDeviceToHost));
+  // count pass: the tables once, the live list, status + two counts per live unit, one UnitState per live unit
+  if(count_bytes) {
+    *count_bytes = j->input_bytes + (int64_t)live * (4 + 4 + 16 + (int64_t)sizeof(UnitState));
+  }
+  // emit pass: the live list and the saved states, the gap lists again, output offsets, entries and offsets written
+  if(emit_bytes) {
+    *emit_bytes = (int64_t)live * (4 + 32 + (int64_t)sizeof(UnitState)) + (j->left.G + j->right.G + j->deltas.Gr + j->deltas.Gq) * 16 +
+                  j->ent_cap * (int64_t)sizeof(pm_entry_t) + j->off_cap * 8;
+  }
+  if(n_live) {
+    *n_live = live;
+  }
+  return PM_OK;
+}
+
 void pm_job_destroy(pm_job_t *j) {
   if(!j) {
     return;

@@ -125,6 +125,12 @@ class TranslateJob:
         capi.check(capi.lib().pm_job_algorithmic_bytes(self._h, C.byref(b)))
         return b.value
 
+    def kernel_bytes(self):
+        """(count pass bytes, emit pass bytes, live units) -- algorithmic, for per-kernel roofline accounting."""
+        a, b, n = C.c_int64(), C.c_int64(), C.c_int64()
+        capi.check(capi.lib().pm_job_kernel_bytes(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def fetch(self) -> JobResult:
         ne, no = self.sizes()
         status = np.zeros(self.n_units, dtype=np.int32)
