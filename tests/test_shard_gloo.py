@@ -81,3 +81,39 @@ def test_two_gloo_ranks_reproduce_the_single_process_bytes(n_deltas, oracle_buil
         out = str(tmp_path / "ref.delta")
         subprocess.run([ref, w.left_dir, w.right_dir, w.list_path, out], check=True)
         assert open(merged, "rb").read() == open(out, "rb").read()
+
+
+GPU_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from paramugsy_amd import shard
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[3], rank=rank, world_size=world)
+paths = [p for p in open(sys.argv[6]).read().split("\n") if p]
+shard.translate_sharded(sys.argv[4], sys.argv[5], paths, sys.argv[7], rank, world, dist=dist, device=0)  # the HIP path
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_reproduce_the_single_process_bytes(oracle_build, tmp_path):
+    """The real N>1 path: two processes, each translating its slice of the delta-file list on the GPU (both on device 0
+    here: the box has one), host-side gather over gloo, merged bytes equal one upstream/oracle run over the whole list."""
+    w = synth.make_workload(str(tmp_path / "job"), 77, n_left=2, n_right=2, genome_len=60000, n_blocks=40, n_deltas=5,
+                            entries_per_delta=60, mean_len=1200)
+    ref = os.path.join(ROOT, "oracle", "_ref", "m_translate")
+    cpu = ref if os.path.exists(ref) else os.path.join(oracle_build, "oracle_m_translate")
+    single = str(tmp_path / "single.delta")
+    assert subprocess.run([cpu, w.left_dir, w.right_dir, w.list_path, single]).returncode == 0
+    merged = str(tmp_path / "merged.delta")
+    script = tmp_path / "worker.py"
+    script.write_text(GPU_WORKER.format(root=ROOT))
+    port = str(free_port())
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, w.left_dir, w.right_dir, w.list_path, merged])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    assert open(merged, "rb").read() == open(single, "rb").read()
+    assert os.path.getsize(merged) > 5000
