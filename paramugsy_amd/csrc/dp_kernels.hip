@@ -472,6 +472,14 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
       }
       max_colsum_b = std::max(max_colsum_b, sum);
     }
+    int max_sub_all = 0;
+    for(int k = 0; k < 25; ++k) {
+      max_sub_all = std::max(max_sub_all, std::abs(params->sub[k]));
+    }
+    if((int64_t)max_colsum_b * max_sub_all > 32767) { // the column weights are int16 lanes of v_dot2_i32_i16
+      pm_dp_batch_destroy(h);
+      return fail(PM_E_INVALID, "pm_dp_batch_create: (rows of a column of B) x max|sub| exceeds 32767");
+    }
     h->dot4 = max_a <= 127 && max_colsum_b * max_sub <= 127;
     if(const char *e = getenv("PM_DP_DOT4")) {
       h->dot4 = h->dot4 && atoi(e) != 0;

@@ -91,6 +91,40 @@ def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, oracle_bu
     run_and_compare(inputs, dp.make_params(4, 4))
 
 
+@pytest.mark.parametrize("rows,expect_dot4", [(25, True), (26, False), (200, False)])
+def test_int8_path_selection_at_its_boundary(rows, expect_dot4, oracle_build):
+    """rows x max|sub| = 125 fits int8 (dot4 path), 130 does not (int16 path); 200-row columns exercise counts above
+    127 on the int16 path.  Both must equal the oracle."""
+    rng = np.random.default_rng(rows)
+    n, L = 6, 150
+    def cols():
+        c = np.zeros((n * L, 8), dtype=np.uint8)
+        pick = rng.integers(0, 5, size=(n * L, rows))
+        for s in range(5):
+            c[:, s] = (pick == s).sum(axis=1)
+        c[::7, :5] = 0
+        c[::7, rng.integers(0, 4)] = rows  # whole columns of one base: the extreme weights
+        return c
+    off = np.arange(n + 1, dtype=np.int64) * L
+    inputs = dp.DpInputs(cols(), off, cols(), off.copy())
+    params = dp.make_params(1, 1, open_per_pair=40 * rows, extend_per_pair=3 * rows)
+    batch = dp.DpBatch(inputs, params)
+    assert batch.variant()["dot4"] == expect_dot4
+    batch.close()
+    run_and_compare(inputs, params)
+
+
+def test_weights_beyond_int16_are_refused():
+    from paramugsy_amd import capi
+    cols = np.zeros((4, 8), dtype=np.uint8)
+    cols[:, :5] = 255
+    off = np.array([0, 4], dtype=np.int64)
+    p = dp.make_params(1, 1, match=127, mismatch=-127)
+    with pytest.raises(capi.PmError) as e:
+        dp.DpBatch(dp.DpInputs(cols, off, cols.copy(), off.copy()), p)
+    assert e.value.code == capi.PM_E_INVALID
+
+
 def test_general_substitution_matrix_and_zero_penalties(oracle_build):
     rng = np.random.default_rng(8)
     inputs = dp.synth_pairs(79, 10, 5, 250, vary_length=True)
