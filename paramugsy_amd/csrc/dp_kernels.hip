@@ -60,16 +60,99 @@ __device__ __forceinline__ int dot2(int a, int b, int acc) {
 
 __device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)lo & 0xffffu) | ((unsigned)hi << 16)); }
 
+// One cell of the recurrence, hand-scheduled (int8 weights).  The compiler's version of the same cell spends a 15th
+// VALU op on a register copy (the old H of the row above must survive as the next cell's diagonal while the new H is
+// written); here the next cell's diagonal term is folded into its score (dn = hop + gap-row dot) BEFORE hop is
+// overwritten, so the cell is 14 ops and every per-column register is updated in place.
+//   dp   in : diag + dot2(gap row)  for this cell          dn  out: the same for the next cell (unless LAST)
+//   hl       : H~ - gop of the cell to the left            hop in/out: H~ - gop of the row above / of this cell
+// gfx950 needs 3 independent instructions between a dot op and a different op that reads its result: the order
+// below keeps >= 3 everywhere (dot4c -> max3, dot2 -> the next cell's dot4c).
+template <bool TRACE, bool LAST>
+__device__ __forceinline__ void cell_dot4(int &dp, int &dn, int &e, int &f, int &hop, unsigned &acc, int hl, int ax, int az,
+                                          int w0, int w2n, int gop) {
+  int t, h;
+  if(TRACE) {
+    if(LAST) {
+      asm volatile("v_sub_u32 %[t], %[hl], %[e]\n\t"
+                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+                   "v_max_i32 %[e], %[e], %[hl]\n\t"
+                   "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
+                   "v_sub_u32 %[t], %[hop], %[f]\n\t"
+                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+                   "v_max_i32 %[f], %[f], %[hop]\n\t"
+                   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
+                   "v_sub_u32 %[t], %[dp], %[h]\n\t"
+                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+                   "v_sub_u32 %[t], %[e], %[f]\n\t"
+                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+                   "v_subrev_u32 %[hop], %[gop], %[h]\n\t"
+                   "s_nop 1"
+                   : [dp] "+v"(dp), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t), [h] "=&v"(h)
+                   : [hl] "v"(hl), [ax] "v"(ax), [w0] "v"(w0), [gop] "s"(gop));
+    }
+    else {
+      asm volatile("v_sub_u32 %[t], %[hl], %[e]\n\t"
+                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+                   "v_max_i32 %[e], %[e], %[hl]\n\t"
+                   "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
+                   "v_sub_u32 %[t], %[hop], %[f]\n\t"
+                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+                   "v_max_i32 %[f], %[f], %[hop]\n\t"
+                   "v_dot2_i32_i16 %[dn], %[az], %[w2n], %[hop]\n\t"
+                   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
+                   "v_sub_u32 %[t], %[dp], %[h]\n\t"
+                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+                   "v_sub_u32 %[t], %[e], %[f]\n\t"
+                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+                   "v_subrev_u32 %[hop], %[gop], %[h]"
+                   : [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t),
+                     [h] "=&v"(h)
+                   : [hl] "v"(hl), [ax] "v"(ax), [az] "v"(az), [w0] "v"(w0), [w2n] "v"(w2n), [gop] "s"(gop));
+    }
+  }
+  else {
+    if(LAST) {
+      asm volatile("v_max_i32 %[e], %[e], %[hl]\n\t"
+                   "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
+                   "v_max_i32 %[f], %[f], %[hop]\n\t"
+                   "s_nop 1\n\t"
+                   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
+                   "v_subrev_u32 %[hop], %[gop], %[h]\n\t"
+                   "s_nop 1"
+                   : [dp] "+v"(dp), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [h] "=&v"(h)
+                   : [hl] "v"(hl), [ax] "v"(ax), [w0] "v"(w0), [gop] "s"(gop));
+    }
+    else {
+      // score only: 6 ops; the dot ops are 3 instructions ahead of their readers (dn is read by the next cell's
+      // dot4c after max3, subrev and that cell's first max)
+      asm volatile("v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
+                   "v_max_i32 %[e], %[e], %[hl]\n\t"
+                   "v_max_i32 %[f], %[f], %[hop]\n\t"
+                   "v_dot2_i32_i16 %[dn], %[az], %[w2n], %[hop]\n\t"
+                   "s_nop 0\n\t"
+                   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
+                   "v_subrev_u32 %[hop], %[gop], %[h]\n\t"
+                   "s_nop 0"
+                   : [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [h] "=&v"(h)
+                   : [hl] "v"(hl), [ax] "v"(ax), [az] "v"(az), [w0] "v"(w0), [w2n] "v"(w2n), [gop] "s"(gop));
+    }
+  }
+}
+
 // lane l takes lane l-1's value; lane 0 takes `lane0`.  Needs all 64 lanes enabled.
 __device__ __forceinline__ int from_left(int lane0, int v) {
   return __builtin_amdgcn_update_dpp(lane0, v, DPP_WAVE_SHR1, 0xf, 0xf, false);
 }
 
-// Words of traceback one pair needs: stripes x (la + 63) steps x 64 lanes (C = 8: one word per lane per step).
+// Words of traceback one pair needs.  Layout tb[stripe][tile][lane][4 steps][C/8 words]: a tile is four consecutive
+// steps; a lane's words of one tile are contiguous (16 or 32 bytes), so the backward walk, which follows one lane
+// through consecutive steps, finds four cells' decisions in one place instead of in four 256/512-byte rows.
 __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
   i64 W = 64 * C;
   i64 stripes = (lb + W - 1) / W;
-  return stripes * (la + 63) * 64 * (C / 8);
+  i64 tiles = (la + 63 + 3) / 4;
+  return stripes * tiles * 64 * 4 * (C / 8);
 }
 
 // DOT4: every count of A and every ACGT weight of B fits int8 (checked at batch creation), so the four base terms of
@@ -88,9 +171,11 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   constexpr int TBW = C / 8;
   __shared__ int4 ring_all[NW][128];
   __shared__ int progress[NW]; // per wave: rows of boundary published so far, cumulated over the wave's stripes
+  __shared__ unsigned tbstage_all[NW][4][64 * TBW]; // the decisions of the current tile (4 steps), per wave
   const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   int4 *ring = ring_all[wv];
+  unsigned(*tbstage)[64 * TBW] = tbstage_all[wv];
   const i64 pair = first_pair + blockIdx.x;
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
@@ -103,6 +188,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   constexpr int W = 64 * C;
   const int n_stripes = (lb + W - 1) / W;
   const int steps = la + 63;
+  const int tiles = (steps + 3) / 4;
   int result = 0;
   if(la == 0 || lb == 0) { // one profile empty: a single gap run
     int n = la + lb;
@@ -230,6 +316,23 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         for(int k = 0; k < TBW; ++k) {
           accw[k] = 0;
         }
+        if(DOT4) {
+          int dd[2];
+          asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(a.z), "v"(w2[0]), "v"(diag));
+#pragma unroll
+          for(int c = 0; c < C; ++c) {
+            const int hl = c == 0 ? ho_in : hop[c == 0 ? 0 : c - 1];
+            if(c == C - 1) {
+              cell_dot4<TRACE, true>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.z, w0[c], 0, gop);
+            }
+            else {
+              cell_dot4<TRACE, false>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.z, w0[c],
+                                      w2[c + 1 < C ? c + 1 : c], gop);
+            }
+          }
+          ho_left = hop[C - 1];
+        }
+        else {
 #pragma unroll
         for(int c = 0; c < C; ++c) {
           unsigned &acc = accw[c / 8];
@@ -250,13 +353,11 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           ho_left = h - gop;
           hop[c] = ho_left;
         }
-        if(TRACE) {
-          const i64 at = ((i64)s * steps + t) * 64 + lane;
-          if(TBW == 1) {
-            tbp[at] = accw[0];
-          }
-          else {
-            reinterpret_cast<uint2 *>(tbp)[at] = make_uint2(accw[0], accw[TBW - 1]);
+        }
+        if(TRACE) { // into this lane's slot of the tile being assembled in LDS
+#pragma unroll
+          for(int k = 0; k < TBW; ++k) {
+            tbstage[t & 3][lane * TBW + k] = accw[k];
           }
         }
         ho_last = ho_left;
@@ -264,6 +365,18 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         diag_in = ho_in;
         if(lane == 63 && s + 1 < n_stripes) {
           bp[ii] = make_int2(ho_left, e);
+        }
+      }
+      if(TRACE && ((t & 3) == 3 || t == steps - 1)) {
+        // tile complete (or the stripe's last, partial tile): every lane writes its own 4 x TBW words, contiguously;
+        // the wave's store covers one contiguous 1-2 KiB tile
+        unsigned *dst = tbp + (((i64)s * tiles + (t >> 2)) * 64 + lane) * (4 * TBW);
+#pragma unroll
+        for(int q = 0; q < 4; ++q) {
+#pragma unroll
+          for(int k = 0; k < TBW; ++k) {
+            dst[q * TBW + k] = tbstage[q][lane * TBW + k];
+          }
         }
       }
       }
@@ -306,7 +419,7 @@ dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b
   const unsigned *tbp = tb + tb_off[blockIdx.x];
   unsigned char *out = ops + off_a[pair] + off_b[pair];
   constexpr int W = 64 * C;
-  const i64 steps = la + 63;
+  const i64 tiles = (la + 63 + 3) / 4;
   int i = la, j = lb, state = 0; // wave-uniform
   int at = la + lb;
   int guard = 2 * (la + lb) + 8; // every iteration but a state switch consumes a cell; a switch is followed by one
@@ -318,7 +431,8 @@ dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b
     if(valid) {
       const int jj = cj - 1;
       const int s = jj / W, l = (jj % W) / C, c = jj % C;
-      const unsigned word = tbp[(((i64)s * steps + (ci - 1 + l)) * 64 + l) * (C / 8) + c / 8];
+      const int t = ci - 1 + l; // the step at which lane l was on row ci
+      const unsigned word = tbp[(((i64)s * tiles + (t >> 2)) * 64 + l) * (4 * (C / 8)) + (t & 3) * (C / 8) + c / 8];
       nib = (word >> (4 * (7 - (c & 7)))) & 15u;
     }
     // a lane continues the run when its cell keeps the walk going in the same direction and state
