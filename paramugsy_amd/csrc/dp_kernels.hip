@@ -189,6 +189,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const int n_stripes = (lb + W - 1) / W;
   const int steps = la + 63;
   const int tiles = (steps + 3) / 4;
+  const int la16 = la * 16;
   int result = 0;
   if(la == 0 || lb == 0) { // one profile empty: a single gap run
     int n = la + lb;
@@ -239,7 +240,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       f[c] = DP_NEG_INF;
     }
     int diag_in = (j0 == 0 ? 0 : -gop) - gop; // H~[0][j0] - gop
-    int ho_last = 0, e_last = DP_NEG_INF;
+    int e = DP_NEG_INF; // the running E of this lane's row; between steps: what the lane hands to its right neighbour
     int bin_ho = 0, bin_e = DP_NEG_INF;
     if(s > 0) {
       // lane 63's stores of the previous stripe must be visible to every lane's loads
@@ -259,9 +260,9 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           }
           else {
             v.x = (int)(col & 0xff) | ((int)((col >> 8) & 0xff) << 16);
-            v.y = (int)((col >> 16) & 0xff) | ((int)((col >> 24) & 0xff) << 16);
+            v.z = (int)((col >> 16) & 0xff) | ((int)((col >> 24) & 0xff) << 16);
           }
-          v.z = (int)((col >> 32) & 0xff) | (1 << 16);
+          v.y = (int)((col >> 32) & 0xff) | (1 << 16); // (nGap, 1): next to x, so that the int8 path reads 8 bytes
         }
         ring[r & 127] = v;
         if(NW > 1 && s > 0) {
@@ -294,7 +295,8 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       const int t1 = min(t0 + 64, steps);
-      for(int t = t0; t < t1; ++t) {
+      int ii16 = (t0 - lane) * 16; // 16 x this lane's row of A (0-based): the byte offset of the row in the LDS ring
+      for(int t = t0; t < t1; ++t, ii16 += 16) {
       // what the column left of the stripe hands to lane 0 for row t
       int b_ho, b_e;
       if(s == 0) {
@@ -305,28 +307,33 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         b_ho = __builtin_amdgcn_readlane(bin_ho, t & 63);
         b_e = __builtin_amdgcn_readlane(bin_e, t & 63);
       }
-      const int ho_in = from_left(b_ho, ho_last);
-      const int e_in = from_left(b_e, e_last);
-      const int ii = t - lane; // this lane's row of A (0-based)
-      if(ii >= 0 && ii < la) {
-        const int4 a = ring[ii & 127];
-        int ho_left = ho_in, e = e_in, diag = diag_in;
+      // hop[C-1] and e change only in the steps the lane is on a row, so they are what the right neighbour needs
+      const int ho_in = from_left(b_ho, hop[C - 1]);
+      // e moves one lane to the right in place; lane 0 takes the boundary's
+      asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_writelane_b32 %0, %1, 0"
+                   : "+v"(e)
+                   : "s"(b_e));
+      const int tq = t & 3;
+      if((unsigned)ii16 < (unsigned)la16) {
+        const int4 a = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(ring) + (ii16 & 0x7f0));
+        int ho_left = ho_in, diag = diag_in;
         unsigned accw[TBW];
 #pragma unroll
         for(int k = 0; k < TBW; ++k) {
-          accw[k] = 0;
+          asm volatile("" : "=v"(accw[k])); // no initial value needed: 8 cells x 4 bits shift every old bit out
         }
         if(DOT4) {
           int dd[2];
-          asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(a.z), "v"(w2[0]), "v"(diag));
+          asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(a.y), "v"(w2[0]), "v"(diag));
 #pragma unroll
           for(int c = 0; c < C; ++c) {
             const int hl = c == 0 ? ho_in : hop[c == 0 ? 0 : c - 1];
             if(c == C - 1) {
-              cell_dot4<TRACE, true>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.z, w0[c], 0, gop);
+              cell_dot4<TRACE, true>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, w0[c], 0, gop);
             }
             else {
-              cell_dot4<TRACE, false>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.z, w0[c],
+              cell_dot4<TRACE, false>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, w0[c],
                                       w2[c + 1 < C ? c + 1 : c], gop);
             }
           }
@@ -344,8 +351,8 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           const int fv = max(f[c], hop[c]);
           f[c] = fv;
           // diagonal: (H~[i-1][j-1] - gop) + s(i,j) + gop + 2*ge
-          const int d = DOT4 ? __builtin_amdgcn_sdot4(a.x, w0[c], dot2(a.z, w2[c], diag), false)
-                             : dot2(a.x, w0[c], dot2(a.y, w1[c], dot2(a.z, w2[c], diag)));
+          const int d = DOT4 ? __builtin_amdgcn_sdot4(a.x, w0[c], dot2(a.y, w2[c], diag), false)
+                             : dot2(a.x, w0[c], dot2(a.z, w1[c], dot2(a.y, w2[c], diag)));
           const int h = max(d, max(e, fv));                 // one v_max3_i32
           acc = __builtin_amdgcn_alignbit(acc, d - h, 31);  // bit = not diagonal: d < max(e, f)  <=>  d < h
           acc = __builtin_amdgcn_alignbit(acc, e - fv, 31); // bit = F beats E
@@ -357,17 +364,15 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         if(TRACE) { // into this lane's slot of the tile being assembled in LDS
 #pragma unroll
           for(int k = 0; k < TBW; ++k) {
-            tbstage[t & 3][lane * TBW + k] = accw[k];
+            tbstage[tq][lane * TBW + k] = accw[k];
           }
         }
-        ho_last = ho_left;
-        e_last = e;
         diag_in = ho_in;
         if(lane == 63 && s + 1 < n_stripes) {
-          bp[ii] = make_int2(ho_left, e);
+          bp[ii16 >> 4] = make_int2(ho_left, e);
         }
       }
-      if(TRACE && ((t & 3) == 3 || t == steps - 1)) {
+      if(TRACE && (tq == 3 || t == steps - 1)) {
         // tile complete (or the stripe's last, partial tile): every lane writes its own 4 x TBW words, contiguously;
         // the wave's store covers one contiguous 1-2 KiB tile
         unsigned *dst = tbp + (((i64)s * tiles + (t >> 2)) * 64 + lane) * (4 * TBW);
