@@ -60,82 +60,68 @@ __device__ __forceinline__ int dot2(int a, int b, int acc) {
 
 __device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)lo & 0xffffu) | ((unsigned)hi << 16)); }
 
-// One cell of the recurrence, hand-scheduled (int8 weights).  The compiler's version of the same cell spends a 15th
-// VALU op on a register copy (the old H of the row above must survive as the next cell's diagonal while the new H is
-// written); here the next cell's diagonal term is folded into its score (dn = hop + gap-row dot) BEFORE hop is
-// overwritten, so the cell is 14 ops and every per-column register is updated in place.
+// One cell of the recurrence, hand-scheduled.  The compiler's version of the same cell spends one more VALU op on
+// a register copy (the old H of the row above must survive as the next cell's diagonal while the new H is written);
+// here the next cell's diagonal term is folded into its score (dn = hop + gap-row dot) BEFORE hop is overwritten, so
+// every per-column register is updated in place: 14 ops with int8 weights (DOT4), 15 with int16.
 //   dp   in : diag + dot2(gap row)  for this cell          dn  out: the same for the next cell (unless LAST)
 //   hl       : H~ - gop of the cell to the left            hop in/out: H~ - gop of the row above / of this cell
-// gfx950 needs 3 independent instructions between a dot op and a different op that reads its result: the order
-// below keeps >= 3 everywhere (dot4c -> max3, dot2 -> the next cell's dot4c).
-template <bool TRACE, bool LAST>
-__device__ __forceinline__ void cell_dot4(int &dp, int &dn, int &e, int &f, int &hop, unsigned &acc, int hl, int ax, int az,
-                                          int w0, int w2n, int gop) {
+//   ax, az   : A's base counts (four int8, or two int16 pairs), ay : A's (nGap, 1)
+// gfx950 needs 3 independent instructions between a dot op and a different op that reads its result: the orders
+// below keep >= 3 everywhere (score -> max3, dot2 -> the next cell's score).
+#define PM_CELL_E_T "v_sub_u32 %[t], %[hl], %[e]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\tv_max_i32 %[e], %[e], %[hl]\n\t"
+#define PM_CELL_F_T "v_sub_u32 %[t], %[hop], %[f]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\tv_max_i32 %[f], %[f], %[hop]\n\t"
+#define PM_CELL_E "v_max_i32 %[e], %[e], %[hl]\n\t"
+#define PM_CELL_F "v_max_i32 %[f], %[f], %[hop]\n\t"
+#define PM_CELL_SCORE4 "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
+#define PM_CELL_SCORE2 "v_dot2_i32_i16 %[dp], %[ax], %[w0], %[dp]\n\tv_dot2_i32_i16 %[dp], %[az], %[w1], %[dp]\n\t"
+#define PM_CELL_NEXT "v_dot2_i32_i16 %[dn], %[ay], %[w2n], %[hop]\n\t"
+#define PM_CELL_H "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
+#define PM_CELL_H_T                                                                                                    \
+  "v_max3_i32 %[h], %[dp], %[e], %[f]\n\tv_sub_u32 %[t], %[dp], %[h]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"   \
+  "v_sub_u32 %[t], %[e], %[f]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+#define PM_CELL_OUT "v_subrev_u32 %[hop], %[gop], %[h]"
+#define PM_CELL_OPERANDS                                                                                               \
+  [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t), [h] "=&v"(h)  \
+      : [hl] "v"(hl), [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az), [w0] "v"(w0), [w1] "v"(w1), [w2n] "v"(w2n), [gop] "s"(gop)
+template <bool TRACE, bool LAST, bool DOT4>
+__device__ __forceinline__ void dp_cell(int &dp, int &dn, int &e, int &f, int &hop, unsigned &acc, int hl, int ax, int ay,
+                                        int az, int w0, int w1, int w2n, int gop) {
   int t, h;
   if(TRACE) {
-    if(LAST) {
-      asm volatile("v_sub_u32 %[t], %[hl], %[e]\n\t"
-                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-                   "v_max_i32 %[e], %[e], %[hl]\n\t"
-                   "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
-                   "v_sub_u32 %[t], %[hop], %[f]\n\t"
-                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-                   "v_max_i32 %[f], %[f], %[hop]\n\t"
-                   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
-                   "v_sub_u32 %[t], %[dp], %[h]\n\t"
-                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-                   "v_sub_u32 %[t], %[e], %[f]\n\t"
-                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-                   "v_subrev_u32 %[hop], %[gop], %[h]\n\t"
-                   "s_nop 1"
-                   : [dp] "+v"(dp), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t), [h] "=&v"(h)
-                   : [hl] "v"(hl), [ax] "v"(ax), [w0] "v"(w0), [gop] "s"(gop));
+    if(LAST) { // the trailing s_nop keeps hop two wait states away from the DPP read that follows the step
+      if(DOT4) {
+        asm volatile(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+      }
+      else {
+        asm volatile(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+      }
     }
     else {
-      asm volatile("v_sub_u32 %[t], %[hl], %[e]\n\t"
-                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-                   "v_max_i32 %[e], %[e], %[hl]\n\t"
-                   "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
-                   "v_sub_u32 %[t], %[hop], %[f]\n\t"
-                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-                   "v_max_i32 %[f], %[f], %[hop]\n\t"
-                   "v_dot2_i32_i16 %[dn], %[az], %[w2n], %[hop]\n\t"
-                   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
-                   "v_sub_u32 %[t], %[dp], %[h]\n\t"
-                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-                   "v_sub_u32 %[t], %[e], %[f]\n\t"
-                   "v_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-                   "v_subrev_u32 %[hop], %[gop], %[h]"
-                   : [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t),
-                     [h] "=&v"(h)
-                   : [hl] "v"(hl), [ax] "v"(ax), [az] "v"(az), [w0] "v"(w0), [w2n] "v"(w2n), [gop] "s"(gop));
+      if(DOT4) {
+        asm volatile(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT : PM_CELL_OPERANDS);
+      }
+      else {
+        asm volatile(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT : PM_CELL_OPERANDS);
+      }
     }
   }
-  else {
+  else { // score only: 6 (7) ops; s_nops stand in for the decision ops that separate the dot ops from their readers
     if(LAST) {
-      asm volatile("v_max_i32 %[e], %[e], %[hl]\n\t"
-                   "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
-                   "v_max_i32 %[f], %[f], %[hop]\n\t"
-                   "s_nop 1\n\t"
-                   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
-                   "v_subrev_u32 %[hop], %[gop], %[h]\n\t"
-                   "s_nop 1"
-                   : [dp] "+v"(dp), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [h] "=&v"(h)
-                   : [hl] "v"(hl), [ax] "v"(ax), [w0] "v"(w0), [gop] "s"(gop));
+      if(DOT4) {
+        asm volatile(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+      }
+      else {
+        asm volatile(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+      }
     }
     else {
-      // score only: 6 ops; the dot ops are 3 instructions ahead of their readers (dn is read by the next cell's
-      // dot4c after max3, subrev and that cell's first max)
-      asm volatile("v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
-                   "v_max_i32 %[e], %[e], %[hl]\n\t"
-                   "v_max_i32 %[f], %[f], %[hop]\n\t"
-                   "v_dot2_i32_i16 %[dn], %[az], %[w2n], %[hop]\n\t"
-                   "s_nop 0\n\t"
-                   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
-                   "v_subrev_u32 %[hop], %[gop], %[h]\n\t"
-                   "s_nop 0"
-                   : [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [h] "=&v"(h)
-                   : [hl] "v"(hl), [ax] "v"(ax), [az] "v"(az), [w0] "v"(w0), [w2n] "v"(w2n), [gop] "s"(gop));
+      if(DOT4) {
+        asm volatile(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT : PM_CELL_OPERANDS);
+      }
+      else {
+        asm volatile(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT : PM_CELL_OPERANDS);
+      }
     }
   }
 }
@@ -317,49 +303,26 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       const int tq = t & 3;
       if((unsigned)ii16 < (unsigned)la16) {
         const int4 a = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(ring) + (ii16 & 0x7f0));
-        int ho_left = ho_in, diag = diag_in;
         unsigned accw[TBW];
 #pragma unroll
         for(int k = 0; k < TBW; ++k) {
           asm volatile("" : "=v"(accw[k])); // no initial value needed: 8 cells x 4 bits shift every old bit out
         }
-        if(DOT4) {
+        {
           int dd[2];
-          asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(a.y), "v"(w2[0]), "v"(diag));
+          asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(a.y), "v"(w2[0]), "v"(diag_in));
 #pragma unroll
           for(int c = 0; c < C; ++c) {
             const int hl = c == 0 ? ho_in : hop[c == 0 ? 0 : c - 1];
             if(c == C - 1) {
-              cell_dot4<TRACE, true>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, w0[c], 0, gop);
+              dp_cell<TRACE, true, DOT4>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, DOT4 ? a.x : a.z,
+                                         w0[c], DOT4 ? w0[c] : w1[c], 0, gop);
             }
             else {
-              cell_dot4<TRACE, false>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, w0[c],
-                                      w2[c + 1 < C ? c + 1 : c], gop);
+              dp_cell<TRACE, false, DOT4>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, DOT4 ? a.x : a.z,
+                                          w0[c], DOT4 ? w0[c] : w1[c], w2[c + 1 < C ? c + 1 : c], gop);
             }
           }
-          ho_left = hop[C - 1];
-        }
-        else {
-#pragma unroll
-        for(int c = 0; c < C; ++c) {
-          unsigned &acc = accw[c / 8];
-          // E: horizontal gap.  ties -> open
-          acc = __builtin_amdgcn_alignbit(acc, ho_left - e, 31); // bit = E extended
-          e = max(e, ho_left);
-          // F: vertical gap.  ties -> open
-          acc = __builtin_amdgcn_alignbit(acc, hop[c] - f[c], 31); // bit = F extended
-          const int fv = max(f[c], hop[c]);
-          f[c] = fv;
-          // diagonal: (H~[i-1][j-1] - gop) + s(i,j) + gop + 2*ge
-          const int d = DOT4 ? __builtin_amdgcn_sdot4(a.x, w0[c], dot2(a.y, w2[c], diag), false)
-                             : dot2(a.x, w0[c], dot2(a.z, w1[c], dot2(a.y, w2[c], diag)));
-          const int h = max(d, max(e, fv));                 // one v_max3_i32
-          acc = __builtin_amdgcn_alignbit(acc, d - h, 31);  // bit = not diagonal: d < max(e, f)  <=>  d < h
-          acc = __builtin_amdgcn_alignbit(acc, e - fv, 31); // bit = F beats E
-          diag = hop[c];
-          ho_left = h - gop;
-          hop[c] = ho_left;
-        }
         }
         if(TRACE) { // into this lane's slot of the tile being assembled in LDS
 #pragma unroll
@@ -369,7 +332,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         }
         diag_in = ho_in;
         if(lane == 63 && s + 1 < n_stripes) {
-          bp[ii16 >> 4] = make_int2(ho_left, e);
+          bp[ii16 >> 4] = make_int2(hop[C - 1], e);
         }
       }
       if(TRACE && (tq == 3 || t == steps - 1)) {
