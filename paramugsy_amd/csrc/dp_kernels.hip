@@ -14,19 +14,20 @@
 //     v_mov_b32_dpp wave_shr:1 each;
 //   * A's packed columns are loaded 64 at a time (one coalesced 512-byte load per 64 steps), expanded to
 //     int16 pairs and staged in a 128-row LDS ring; each lane reads its row with one ds_read_b128;
-//   * the column score is sum-of-pairs = 3 x v_dot2c_i32_i16 accumulating onto the diagonal (the last half
-//     lane of the third dot carries gap_open so that the stored H-gap_open needs no correction);
+//   * the column score is sum-of-pairs = v_dot4_i32_i8 + v_dot2_i32_i16 (or 3 x v_dot2_i32_i16) accumulating onto
+//     the diagonal (the last half lane of the gap-row dot carries gap_open so that the stored H-gap_open needs no
+//     correction);
 //   * max-plus recurrence in int32 VALU (no MFMA: nothing to contract), carried in SKEWED coordinates
 //     V~[i][j] = V[i][j] + (i+j)*gap_extend for V in {H,E,F}: extending a gap then costs nothing
 //     (E~[i][j] = max(E~[i][j-1], H~[i][j-1] - (gap_open-gap_extend))), which removes the two "- gap_extend"
 //     subtractions per cell; every comparison is between values of one cell, so all decisions are unchanged, and
 //     the score is un-skewed once at the end;
-//   * traceback: 4 decision bits per cell, shifted into a word with v_alignbit_b32 (one op per bit), one
-//     coalesced 256-byte store per step: tb[stripe][step][lane];
+//   * traceback: 4 decision bits per cell, shifted into a word with v_alignbit_b32 (one op per bit); four steps'
+//     words are staged in LDS and leave as one contiguous tile: tb[stripe][tile][lane][4 steps][C/8 words];
 //   * stripe boundary (last column of a stripe, per row): written by lane 63, read back 64 rows at a time.
 // Algorithmic HBM traffic per cell: 0.5 byte of traceback written + (8 bytes per column of A per stripe +
 // 8 bytes per column of B) read, i.e. ~0.5 B/cell for kilobase profiles; the kernel is VALU-issue bound
-// (15 VALU ops per cell), not HBM bound.
+// (14 VALU ops per cell with int8 weights, 15 with int16: dp_cell below), not HBM bound.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the default bench line, rocprofv3 kernel stats and the three PMC passes.
 # Outputs land in gpurun_out/refresh/; tools/summarize_prof.py condenses them into profiles/ afterwards.
+# Delete the local gpurun_out/refresh/ before the call: gpurun merges new files into it and older runs would linger.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O

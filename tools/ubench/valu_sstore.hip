@@ -35,6 +35,33 @@ __global__ void __launch_bounds__(64) k(unsigned *out, int iters, int *sink) {
   asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   if(a + b + c + d == 0x12345678) sink[0] = a;
 }
+// as k<16> but the same 256 B per step leave as 32 s_store_dwordx2 whose data operands the compiler allocates
+__global__ void __launch_bounds__(64) k2(unsigned *out, int iters, int *sink) {
+  __shared__ int lds[64];
+  lds[threadIdx.x] = threadIdx.x;
+  unsigned long long base = (unsigned long long)out + (unsigned long long)blockIdx.x * (unsigned long long)iters * 256ull;
+  int a = threadIdx.x, b = blockIdx.x, c = 3, d = 7;
+  for(int it = 0; it < iters; ++it) {
+    int l = lds[(threadIdx.x + it) & 63];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    a += l;
+    unsigned long long p = base + (unsigned long long)it * 256ull;
+#pragma unroll
+    for(int g = 0; g < 16; ++g) {
+      unsigned long long m0, m1;
+      asm volatile("v_max_i32 %0, %0, %1\n\tv_add_u32 %1, %1, %2\n\tv_max_i32 %2, %2, %3\n\tv_add_u32 %3, %3, %0\n\t"
+                   "v_max_i32 %0, %0, %1\n\tv_add_u32 %1, %1, %2\n\tv_max_i32 %2, %2, %3\n\tv_add_u32 %3, %3, %0\n\t"
+                   "v_max_i32 %0, %0, %1\n\tv_add_u32 %1, %1, %2\n\tv_max_i32 %2, %2, %3\n\tv_add_u32 %3, %3, %0\n\t"
+                   "v_cmp_gt_i32 %4, %0, %1\n\tv_cmp_gt_i32 %5, %1, %0\n\t"
+                   "s_store_dwordx2 %4, %6, %7\n\ts_store_dwordx2 %5, %6, %8"
+                   : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1)
+                   : "s"(p), "i"(g * 8), "i"(128 + g * 8)
+                   : "memory");
+    }
+  }
+  asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  if(a + b + c + d == 0x12345678) sink[0] = a;
+}
 template <int NST> void run(unsigned *d, int *sink, int blocks, int iters) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   k<NST><<<blocks, 64>>>(d, 10, sink);
@@ -54,5 +81,16 @@ int main() {
   run<8>(d, sink, blocks, iters);
   run<16>(d, sink, blocks, iters);
   run<4>(d, sink, blocks, iters);
+  {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k2<<<blocks, 64>>>(d, 10, sink);
+    (void)hipEventRecord(e0);
+    k2<<<blocks, 64>>>(d, iters, sink);
+    (void)hipEventRecord(e1);
+    hipError_t err = hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("32 x s_store_dwordx2 per step (256 B): err=%d %.3f ms  %.2f T lane-ops/s  scalar-store %.1f GB/s\n", (int)err, ms,
+           (double)blocks * iters * (16.0 * 14 + 1) * 64 / (ms * 1e-3) / 1e12, (double)blocks * iters * 256 / (ms * 1e-3) / 1e9);
+  }
   return 0;
 }
