@@ -80,7 +80,9 @@ struct PV {
 // a3, m_profile.cc:91-112.  The scan adds gap k while gap[k].s <= offset + pre[k] and stops at the first
 // failure; gap[k].s - pre[k] is non-decreasing on ascending disjoint lists, so that first failure is a
 // lower bound.
-PM_HD inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out) {
+// `at` = the lower bound itself: the gaps before index `at` lie wholly before the returned column, gap `at` (if any)
+// starts after it.
+PM_HD inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out, int &at) {
   R2 f = fwd_of(p.range);
   if(!(f.s <= si && si <= f.e)) {
     return PM_ST_SEQ_IDX_OUT_OF_RANGE;
@@ -98,7 +100,13 @@ PM_HD inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out) {
     }
   }
   out = p.pre[lo] + offset;
+  at = lo;
   return PM_ST_OK;
+}
+
+PM_HD inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out) {
+  int at;
+  return profile_idx_of_seq_idx(p, si, out, at);
 }
 
 // a4, m_profile.cc:114-149.  First gap whose end is >= pi decides: inside it -> none, else the gaps
@@ -218,23 +226,42 @@ PM_HD inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, 
   return PM_ST_OK;
 }
 
-// m_profile.cc:208-212
+// m_profile.cc:208-212: subset_profile(profile_idx_of_seq_idx(s), profile_idx_of_seq_idx(e)).  The two conversions
+// already hold everything subset_profile would search for, because their results are columns that carry a
+// sequence position (never a gap column).  With ps = pre[a] + offset from the lower bound a (ascending disjoint
+// gaps, pre[k+1] = pre[k] + length of gap k):
+//   * gaps k < a have g[k].s <= offset + pre[k], so g[k].e = g[k].s + len_k - 1 <= offset + pre[a] - 1 < ps;
+//     gap a has g[a].s - pre[a] > offset, so g[a].s > ps: "first gap with end >= ps" is a, "first gap with start
+//     > ps" is a as well;
+//   * hence the kept gaps of [min(ps,pe), max(ps,pe)] are the index range between the two lower bounds, none of
+//     them touches an end of the window (no trimming at :182-193, never the empty option), and
+//     seq_idx_of_profile_idx of either end finds gap a starting after it and returns range.s +- (offset - 1),
+//     which is the sequence index the column came from.
+// What remains of subset_profile are its range checks.
 PM_HD inline int subset_seq(const PV &p, i64 s, i64 e, GapView &v, R2 &seq) {
   i64 ps, pe;
-  int st = profile_idx_of_seq_idx(p, s, ps);
+  int as, ae;
+  int st = profile_idx_of_seq_idx(p, s, ps, as);
   if(st) {
     return st;
   }
-  st = profile_idx_of_seq_idx(p, e, pe);
+  st = profile_idx_of_seq_idx(p, e, pe, ae);
   if(st) {
     return st;
   }
-  bool none;
-  st = subset_profile(p, ps, pe, v, seq, none);
-  if(st) {
-    return st;
+  if(ps <= 0 || p.len < ps || pe <= 0 || p.len < pe) { // m_profile.cc:163-166
+    return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
   }
-  return none ? PM_ST_IS_NONE : PM_ST_OK;
+  const bool swap = ps > pe;
+  v.g = p.g;
+  v.lo = swap ? ae : as;
+  v.n = (swap ? as : ae) - v.lo;
+  v.ws = swap ? pe : ps;
+  v.we = swap ? ps : pe;
+  v.mirror = false;
+  v.L = 0;
+  seq = swap ? R2{e, s} : R2{s, e};
+  return PM_ST_OK;
 }
 
 // a11, m_translate.cc:24-139: two gap lists, one push-back slot each.  Row 0 = reference, 1 = query.
@@ -600,16 +627,10 @@ PM_HD inline int unit_setup(const PV &lp, const PV &rp, const PV &dr, const PV &
   bool mirrored = fwd(rp.range) != fwd(dq.range); // :557
   m.rows.v1.mirror = mirrored;
   m.rows.v1.L = rp.len;
-  i64 ref_start, query_start;
-  if((st = profile_idx_of_seq_idx(lp, l_seq.s, ref_start))) return st; // :572
-  if(mirrored) {                                                        // :575-581
-    i64 t;
-    if((st = profile_idx_of_seq_idx(rp, r_seq.e, t))) return st;
-    query_start = rp.len - t + 1;
-  }
-  else {
-    if((st = profile_idx_of_seq_idx(rp, r_seq.s, query_start))) return st;
-  }
+  // :572-581 convert l_seq.s and r_seq.s (r_seq.e when mirrored) back to columns: those are the ends of the windows
+  // subset_seq has just derived them from (see there), so no search is repeated
+  const i64 ref_start = m.rows.v0.ws;
+  const i64 query_start = mirrored ? rp.len - m.rows.v1.we + 1 : m.rows.v1.ws;
   m.rows.at0 = m.rows.at1 = m.delta.at0 = m.delta.at1 = 0;
   m.rows.held0 = m.rows.held1 = m.delta.held0 = m.delta.held1 = false;
   m.rows.hold0 = m.rows.hold1 = m.delta.hold0 = m.delta.hold1 = R2{0, 0};
