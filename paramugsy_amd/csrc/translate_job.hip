@@ -124,6 +124,48 @@ __global__ void scatter_live_kernel(i64 n_units, const int *live_flag, const int
   }
 }
 
+// The saved merge states live in HBM field by field (13 int64 arrays, then 10 int arrays, each n_live long), so that
+// the 64 lanes of a wavefront, which hold consecutive live units, store and load every field as one contiguous run
+// instead of 64 separate 144-byte records.
+static_assert(sizeof(UnitState) == 13 * 8 + 10 * 4, "state_store/state_load lay UnitState out as 13 int64 + 10 int fields");
+__device__ __forceinline__ void state_store(UnitState *base, i64 n, i64 k, const UnitState &s) {
+  i64 *w = reinterpret_cast<i64 *>(base);
+  int *iw = reinterpret_cast<int *>(w + 13 * n);
+#pragma unroll
+  for(int q = 0; q < 4; ++q) {
+    w[(0 + q) * n + k] = s.ws[q];
+    w[(4 + q) * n + k] = s.we[q];
+    iw[(0 + q) * n + k] = s.lo[q];
+    iw[(4 + q) * n + k] = s.n[q];
+  }
+  w[8 * n + k] = s.ref_start;
+  w[9 * n + k] = s.query_start;
+  w[10 * n + k] = s.column;
+  w[11 * n + k] = s.last_column;
+  w[12 * n + k] = s.query_columns;
+  iw[8 * n + k] = s.orientation;
+  iw[9 * n + k] = s.mirrored;
+}
+
+__device__ __forceinline__ void state_load(const UnitState *base, i64 n, i64 k, UnitState &s) {
+  const i64 *w = reinterpret_cast<const i64 *>(base);
+  const int *iw = reinterpret_cast<const int *>(w + 13 * n);
+#pragma unroll
+  for(int q = 0; q < 4; ++q) {
+    s.ws[q] = w[(0 + q) * n + k];
+    s.we[q] = w[(4 + q) * n + k];
+    s.lo[q] = iw[(0 + q) * n + k];
+    s.n[q] = iw[(4 + q) * n + k];
+  }
+  s.ref_start = w[8 * n + k];
+  s.query_start = w[9 * n + k];
+  s.column = w[10 * n + k];
+  s.last_column = w[11 * n + k];
+  s.query_columns = w[12 * n + k];
+  s.orientation = iw[8 * n + k];
+  s.mirrored = iw[9 * n + k];
+}
+
 // amdgpu_waves_per_eu(4): keep the register allocation at <= 128 VGPRs (4 waves per SIMD); the kernel is bound by the
 // latency of dependent loads, so resident waves matter more than a few spare registers.
 template <bool EMIT>
@@ -140,7 +182,8 @@ translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_
       return;
     }
   }
-  if(k >= live_pos[n_units]) { // the grid covers all units; only the live ones (compacted by the filter pass) have a lane
+  const i64 n_live = live_pos[n_units];
+  if(k >= n_live) { // the grid covers all units; only the live ones (compacted by the filter pass) have a lane
     return;
   }
   const i64 u = live_units[k];
@@ -167,7 +210,8 @@ translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_
     // the count pass left this unit's merge start in states[k]: no set-up to redo
     Merge<EMIT> m;
     m.sink = sink;
-    const UnitState s = states[k];
+    UnitState s;
+    state_load(states, n_live, k, s);
     unit_restore<EMIT>(left, right, ds, d, l, r, s, m);
     (void)unit_merge<EMIT>(m);
   }
@@ -185,7 +229,7 @@ translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_
         if(states) { // null only in the sizing pass of pm_job_create
           UnitState s;
           unit_save<EMIT>(m, orientation, s);
-          states[k] = s;
+          state_store(states, n_live, k, s);
         }
         st = unit_merge<EMIT>(m);
         sink = m.sink;
