@@ -472,7 +472,7 @@ struct pm_dp_batch {
   i64 cells = 0;
   int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
   bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
-  int waves_override = 0; // PM_DP_WAVES=1|4 forces the waves-per-pair choice
+  int waves_override = 0; // PM_DP_WAVES=1|4|8 forces the waves-per-pair choice
   DevBuf pipe_error;
   hipStream_t last_stream = nullptr;
 };
@@ -662,8 +662,11 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
       bool fits = (max_stripes / 4 + 2) * max_la < ((i64)1 << 30); // the progress word is an int
       if(h->cols_per_lane == 16 && fits && max_stripes >= 2 && n < 4096) {
         nw = 4;
+        if(max_stripes >= 8 && n < 1024) { // deep pairs, very few of them: eight stripes in flight per pair
+          nw = 8;
+        }
       }
-      if(h->waves_override == 1 || (h->waves_override == 4 && h->cols_per_lane == 16 && fits)) {
+      if(h->waves_override == 1 || ((h->waves_override == 4 || h->waves_override == 8) && h->cols_per_lane == 16 && fits)) {
         nw = h->waves_override;
       }
     }
@@ -679,7 +682,15 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
   else {                               \
     DP_LAUNCH_FILL(CC, TR, false, NWV); \
   }
-    if(h->cols_per_lane == 16 && nw == 4) {
+    if(h->cols_per_lane == 16 && nw == 8) {
+      if(traceback) {
+        DP_LAUNCH_FILL_D4(16, true, 8)
+      }
+      else {
+        DP_LAUNCH_FILL_D4(16, false, 8)
+      }
+    }
+    else if(h->cols_per_lane == 16 && nw == 4) {
       if(traceback) {
         DP_LAUNCH_FILL_D4(16, true, 4)
       }

@@ -73,11 +73,11 @@ def test_chunked_workspace_gives_same_results(oracle_build):
     assert np.array_equal(s1, s2) and all(np.array_equal(a, b) for a, b in zip(p1, p2))
 
 
-@pytest.mark.parametrize("waves", ["1", "4"])
+@pytest.mark.parametrize("waves", ["1", "4", "8"])
 @pytest.mark.parametrize("cols", ["8", "16"])
 @pytest.mark.parametrize("dot4", ["0", "1"])
 def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, oracle_build, monkeypatch):
-    """One wave per pair and the 4-wave stripe pipeline, 8 and 16 columns per lane, int8 and int16 column scores: all
+    """One wave per pair and the 4- and 8-wave stripe pipelines, 8 and 16 columns per lane, int8 and int16 column scores: all
     must give the oracle's scores and paths on pairs that span several stripes (B up to 2 600 columns)."""
     monkeypatch.setenv("PM_DP_WAVES", waves)
     monkeypatch.setenv("PM_DP_COLS", cols)
