@@ -24,71 +24,97 @@ namespace pm {
 
 typedef long long i64;
 
-struct __attribute__((aligned(16))) R2 {
-  i64 s;
-  i64 e;
+// Everything below is a template over the coordinate type I.  I = long long is the reference's `long` and always
+// valid.  I = int is the fast path the job takes when every number in its tables is below 2^25 in magnitude
+// (bacterial genomes, the reference's domain, are a few Mbp): half the registers per lane, so nearly twice the
+// resident wavefronts for a kernel that lives on latency hiding, and half the instructions.  It computes the same
+// values as long as no intermediate leaves int: the searches and conversions only add or subtract a few table
+// values, and the merge, which accumulates, checks what it carries after every step (Merge::narrow_overflow) and
+// reports PM_ST_NARROW if anything leaves +-2^26; a job that sees PM_ST_NARROW anywhere is redone with
+// I = long long (pm_job_create).
+#define PM_ST_NARROW 100 /* internal: never leaves the library */
+#define PM_NARROW_INPUT_LIMIT (1 << 25)
+
+template <typename I>
+struct alignas(2 * sizeof(I)) R2T {
+  I s;
+  I e;
 };
+typedef R2T<i64> R2;
 
 // Rows of one side, device resident.
-struct RowsD {
+template <typename I>
+struct RowsT {
   i64 n;
-  const R2 *range;    // [n]
-  const i64 *length;  // [n]
-  const i64 *gap_off; // [n+1]
-  const R2 *gaps;     // [gap_off[n]]
-  const i64 *pre;     // [gap_off[n] + n]: row r owns pre[gap_off[r] + r .. + n_r], pre[k] = gap columns before gap k, last = total
-  const int *bad;     // [n] 1 when the row's gap list is not ascending+disjoint
+  const R2T<I> *range; // [n]
+  const I *length;     // [n]
+  const i64 *gap_off;  // [n+1]
+  const R2T<I> *gaps;  // [gap_off[n]]
+  const I *pre;        // [gap_off[n] + n]: row r owns pre[gap_off[r] + r .. + n_r], pre[k] = gap columns before gap k, last = total
+  const int *bad;      // [n] 1 when the row's gap list is not ascending+disjoint
 };
+typedef RowsT<i64> RowsD;
 
 // Delta entries, device resident, in both orientations (o = 0 as read, 1 = M_delta_entry::reverse, m_delta.cc:94-146).
-struct DeltasD {
+template <typename I>
+struct DeltasT {
   i64 n;
-  const R2 *ref;      // [n] as read
-  const R2 *qry;      // [n]
+  const R2T<I> *ref;  // [n] as read
+  const R2T<I> *qry;  // [n]
   const i64 *ref_off; // [n+1]
   const i64 *qry_off; // [n+1]
-  const R2 *ref_gaps[2];
-  const i64 *ref_pre[2]; // same indexing rule as RowsD::pre
-  const R2 *qry_gaps[2];
-  const i64 *qry_pre[2];
+  const R2T<I> *ref_gaps[2];
+  const I *ref_pre[2]; // same indexing rule as RowsT::pre
+  const R2T<I> *qry_gaps[2];
+  const I *qry_pre[2];
   const int *bad;
 };
+typedef DeltasT<i64> DeltasD;
 
-PM_HD __forceinline__ i64 rlen(R2 r) { return (r.s <= r.e ? r.e - r.s : r.s - r.e) + 1; } // m_range.hh:34
-PM_HD __forceinline__ bool fwd(R2 r) { return r.s <= r.e; }                               // m_range.hh:36
-PM_HD __forceinline__ R2 fwd_of(R2 r) { return fwd(r) ? r : R2{r.e, r.s}; }
-PM_HD __forceinline__ i64 imax(i64 a, i64 b) { return a > b ? a : b; }
-PM_HD __forceinline__ i64 imin(i64 a, i64 b) { return a < b ? a : b; }
+template <typename I>
+PM_HD __forceinline__ I rlen(R2T<I> r) { return (r.s <= r.e ? r.e - r.s : r.s - r.e) + 1; } // m_range.hh:34
+template <typename I>
+PM_HD __forceinline__ bool fwd(R2T<I> r) { return r.s <= r.e; }                               // m_range.hh:36
+template <typename I>
+PM_HD __forceinline__ R2T<I> fwd_of(R2T<I> r) { return fwd(r) ? r : R2T<I>{r.e, r.s}; }
+template <typename I>
+PM_HD __forceinline__ I imax(I a, I b) { return a > b ? a : b; }
+template <typename I>
+PM_HD __forceinline__ I imin(I a, I b) { return a < b ? a : b; }
 
 // m_range.hh:80-94
-PM_HD __forceinline__ bool overlap(R2 a, R2 b, R2 &o) {
-  R2 fa = fwd_of(a), fb = fwd_of(b);
+template <typename I>
+PM_HD __forceinline__ bool overlap(R2T<I> a, R2T<I> b, R2T<I> &o) {
+  R2T<I> fa = fwd_of(a), fb = fwd_of(b);
   o.s = imax(fa.s, fb.s);
   o.e = imin(fa.e, fb.e);
   return o.e - o.s >= 0;
 }
 
 // A profile as the conversions see it: range, p_length, gap list + prefix table.
-struct PV {
-  R2 range;
-  i64 len;
-  const R2 *g;
-  const i64 *pre; // n+1 entries
+template <typename I>
+struct PVT {
+  R2T<I> range;
+  I len;
+  const R2T<I> *g;
+  const I *pre; // n+1 entries
   int n;
 };
+typedef PVT<i64> PV;
 
 // a3, m_profile.cc:91-112.  The scan adds gap k while gap[k].s <= offset + pre[k] and stops at the first
 // failure; gap[k].s - pre[k] is non-decreasing on ascending disjoint lists, so that first failure is a
 // lower bound.
 // `at` = the lower bound itself: the gaps before index `at` lie wholly before the returned column, gap `at` (if any)
 // starts after it.
-PM_HD inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out, int &at) {
-  R2 f = fwd_of(p.range);
+template <typename I>
+PM_HD inline int profile_idx_of_seq_idx(const PVT<I> &p, I si, I &out, int &at) {
+  R2T<I> f = fwd_of(p.range);
   if(!(f.s <= si && si <= f.e)) {
     return PM_ST_SEQ_IDX_OUT_OF_RANGE;
   }
-  i64 d = p.range.s - si;
-  i64 offset = (d < 0 ? -d : d) + 1;
+  I d = p.range.s - si;
+  I offset = (d < 0 ? -d : d) + 1;
   int lo = 0, hi = p.n;
   while(lo < hi) {
     int mid = (lo + hi) >> 1;
@@ -104,14 +130,16 @@ PM_HD inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out, int &at) 
   return PM_ST_OK;
 }
 
-PM_HD inline int profile_idx_of_seq_idx(const PV &p, i64 si, i64 &out) {
+template <typename I>
+PM_HD inline int profile_idx_of_seq_idx(const PVT<I> &p, I si, I &out) {
   int at;
   return profile_idx_of_seq_idx(p, si, out, at);
 }
 
 // a4, m_profile.cc:114-149.  First gap whose end is >= pi decides: inside it -> none, else the gaps
 // before it are skipped.
-PM_HD inline int seq_idx_of_profile_idx(const PV &p, i64 pi, i64 &out, bool &none) {
+template <typename I>
+PM_HD inline int seq_idx_of_profile_idx(const PVT<I> &p, I pi, I &out, bool &none) {
   none = false;
   if(!(pi < p.len + 1)) {
     return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
@@ -130,40 +158,44 @@ PM_HD inline int seq_idx_of_profile_idx(const PV &p, i64 pi, i64 &out, bool &non
     none = true;
     return PM_ST_OK;
   }
-  i64 offset = pi - p.pre[lo] - 1;
+  I offset = pi - p.pre[lo] - 1;
   out = fwd(p.range) ? p.range.s + offset : p.range.s - offset;
   return PM_ST_OK;
 }
 
 // The kept gaps of subset_profile as a view on the parent list.
-struct GapView {
-  const R2 *g; // parent list
+template <typename I>
+struct GapViewT {
+  const R2T<I> *g; // parent list
   int lo;      // first kept gap
   int n;       // kept gaps
-  i64 ws, we;  // clip window (the subset's s..e after ordering)
+  I ws, we;  // clip window (the subset's s..e after ordering)
   bool mirror; // walk backwards and map column c -> L - c + 1 (m_translate.cc:559-570)
-  i64 L;
+  I L;
 };
+typedef GapViewT<i64> GapView;
 
-PM_HD __forceinline__ R2 view_get(const GapView &v, int i) {
+template <typename I>
+PM_HD __forceinline__ R2T<I> view_get(const GapViewT<I> &v, int i) {
   if(!v.mirror) {
-    R2 r = v.g[v.lo + i];
-    return R2{imax(r.s, v.ws), imin(r.e, v.we)};
+    R2T<I> r = v.g[v.lo + i];
+    return R2T<I>{imax(r.s, v.ws), imin(r.e, v.we)};
   }
-  R2 r = v.g[v.lo + (v.n - 1 - i)];
-  r = R2{imax(r.s, v.ws), imin(r.e, v.we)};
-  return R2{v.L - r.e + 1, v.L - r.s + 1};
+  R2T<I> r = v.g[v.lo + (v.n - 1 - i)];
+  r = R2T<I>{imax(r.s, v.ws), imin(r.e, v.we)};
+  return R2T<I>{v.L - r.e + 1, v.L - r.s + 1};
 }
 
 // a5, m_profile.cc:160-206.  On an ascending disjoint list the gaps overlapping [s,e] are one index range.
 // Returns status; `none` mirrors the reference's empty option; seq = the sub profile's p_range.
-PM_HD inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, bool &none) {
+template <typename I>
+PM_HD inline int subset_profile(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I> &seq, bool &none) {
   none = false;
   if(s <= 0 || p.len < s || e <= 0 || p.len < e) {
     return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
   }
   if(s > e) {
-    i64 t = s;
+    I t = s;
     s = e;
     e = t;
   }
@@ -196,8 +228,8 @@ PM_HD inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, 
   v.mirror = false;
   v.L = 0;
   if(v.n > 0) {
-    R2 a = view_get(v, 0);
-    R2 b = view_get(v, v.n - 1);
+    R2T<I> a = view_get(v, 0);
+    R2T<I> b = view_get(v, v.n - 1);
     if(v.n == 1 && a.s == s && a.e == e) {
       none = true;
       return PM_ST_OK;
@@ -210,7 +242,7 @@ PM_HD inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, 
     }
   }
   bool n1, n2;
-  i64 ss = 0, se = 0;
+  I ss = 0, se = 0;
   int st = seq_idx_of_profile_idx(p, s, ss, n1);
   if(st) {
     return st;
@@ -222,7 +254,7 @@ PM_HD inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, 
   if(n1 || n2) {
     return PM_ST_IS_NONE;
   }
-  seq = R2{ss, se};
+  seq = R2T<I>{ss, se};
   return PM_ST_OK;
 }
 
@@ -238,8 +270,9 @@ PM_HD inline int subset_profile(const PV &p, i64 s, i64 e, GapView &v, R2 &seq, 
 //     seq_idx_of_profile_idx of either end finds gap a starting after it and returns range.s +- (offset - 1),
 //     which is the sequence index the column came from.
 // What remains of subset_profile are its range checks.
-PM_HD inline int subset_seq(const PV &p, i64 s, i64 e, GapView &v, R2 &seq) {
-  i64 ps, pe;
+template <typename I>
+PM_HD inline int subset_seq(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I> &seq) {
+  I ps, pe;
   int as, ae;
   int st = profile_idx_of_seq_idx(p, s, ps, as);
   if(st) {
@@ -260,20 +293,21 @@ PM_HD inline int subset_seq(const PV &p, i64 s, i64 e, GapView &v, R2 &seq) {
   v.we = swap ? ps : pe;
   v.mirror = false;
   v.L = 0;
-  seq = swap ? R2{e, s} : R2{s, e};
+  seq = swap ? R2T<I>{e, s} : R2T<I>{s, e};
   return PM_ST_OK;
 }
 
 // a11, m_translate.cc:24-139: two gap lists, one push-back slot each.  Row 0 = reference, 1 = query.
 // Kept as scalars (no runtime-indexed arrays: those would go to scratch).
-struct PairCursor {
-  GapView v0, v1;
+template <typename I>
+struct PairCursorT {
+  GapViewT<I> v0, v1;
   int at0, at1;
   bool held0, held1;
-  R2 hold0, hold1;
+  R2T<I> hold0, hold1;
 
   PM_HD __forceinline__ bool has(int r) const { return r ? (held1 || at1 < v1.n) : (held0 || at0 < v0.n); }
-  PM_HD __forceinline__ R2 front(int r) const {
+  PM_HD __forceinline__ R2T<I> front(int r) const {
     if(r) {
       return held1 ? hold1 : view_get(v1, at1);
     }
@@ -298,7 +332,7 @@ struct PairCursor {
       }
     }
   }
-  PM_HD __forceinline__ int push_back(int r, R2 g) {
+  PM_HD __forceinline__ int push_back(int r, R2T<I> g) {
     if(r ? held1 : held0) {
       return PM_ST_ALREADY_UNNEXT;
     }
@@ -313,12 +347,12 @@ struct PairCursor {
     return PM_ST_OK;
   }
   // m_translate.cc:34-62
-  PM_HD __forceinline__ int pick(i64 pos0, i64 pos1, bool &have, int &row, R2 &gap) const {
+  PM_HD __forceinline__ int pick(I pos0, I pos1, bool &have, int &row, R2T<I> &gap) const {
     bool h0 = has(0), h1 = has(1);
     have = h0 || h1;
     if(h0 && h1) {
-      R2 g0 = front(0), g1 = front(1);
-      i64 d0 = g0.s - pos0, d1 = g1.s - pos1;
+      R2T<I> g0 = front(0), g1 = front(1);
+      I d0 = g0.s - pos0, d1 = g1.s - pos1;
       if(d0 < 0 || d1 < 0) {
         return PM_ST_ASSERT_GAP_BEHIND;
       }
@@ -341,44 +375,44 @@ struct PairCursor {
 // The builder's two gap lists are never stored: each gap is turned into its signed offsets the moment it is
 // added, which equals deltas_of_gaps (m_delta_stream_writer.hh:14-53) as long as gaps arrive in that merge's
 // order; the order is checked per gap and a violation ends the unit in PM_ST_OFFSET_ORDER.
-template <bool EMIT>
+template <bool EMIT, typename I = i64>
 struct Sink {
-  i64 n_ent;     // committed entries
-  i64 n_off;     // committed offsets
-  i64 pend;      // offsets of the open segment
-  i64 wpos;      // deltas_of_gaps' running column
-  i64 last_start;
+  I n_ent;     // committed entries
+  I n_off;     // committed offsets
+  I pend;      // offsets of the open segment
+  I wpos;      // deltas_of_gaps' running column
+  I last_start;
   int last_row;
   pm_entry_t *ent; // EMIT: this unit's first entry slot
-  i64 *off;        // EMIT: whole offsets array
-  i64 off_base;    // EMIT: this unit's first offset index
-  i64 off_cap;     // EMIT: this unit's offset count (exact, from the COUNT pass)
-  i64 ent_cap;
+  i64 *off;      // EMIT: whole offsets array (always int64: the C ABI's type)
+  i64 off_base;  // EMIT: this unit's first offset index
+  I off_cap;     // EMIT: this unit's offset count (exact, from the COUNT pass)
+  I ent_cap;
 
-  PM_HD __forceinline__ void put(i64 v) {
+  PM_HD __forceinline__ void put(I v) {
     if(EMIT) {
-      i64 at = n_off + pend;
+      I at = n_off + pend;
       if(at < off_cap) { // offsets of a segment that is later dropped may run past the exact slot
         off[off_base + at] = v;
       }
     }
     ++pend;
   }
-  PM_HD __forceinline__ int gap(int row, R2 g) {
+  PM_HD __forceinline__ int gap(int row, R2T<I> g) {
     int st = PM_ST_OK;
     if(pend > 0 && (g.s < last_start || (g.s == last_start && last_row == 0 && row == 1))) {
       st = PM_ST_OFFSET_ORDER;
     }
-    i64 sign = row ? 1 : -1;
+    I sign = row ? 1 : -1;
     put(sign * (g.s - wpos));
     // the gap's remaining columns are +-1 each (_push_ones, m_delta_stream_writer.hh:6-11).  Counted
     // arithmetically and written only inside the unit's slot, so a nonsensical gap length cannot stall a lane.
-    i64 ones = rlen(g) - 1;
+    I ones = rlen(g) - 1;
     if(EMIT) {
-      i64 at = n_off + pend;
-      i64 room = off_cap - at;
-      i64 n = ones < room ? ones : room;
-      for(i64 k = 0; k < n; ++k) {
+      I at = n_off + pend;
+      I room = off_cap - at;
+      I n = ones < room ? ones : room;
+      for(I k = 0; k < n; ++k) {
         off[off_base + at + k] = sign;
       }
     }
@@ -392,7 +426,7 @@ struct Sink {
     pend = 0;
     wpos = 0;
   }
-  PM_HD __forceinline__ void commit(R2 ref, R2 qry) {
+  PM_HD __forceinline__ void commit(R2T<I> ref, R2T<I> qry) {
     put(0);
     if(EMIT) {
       if(n_ent < ent_cap) {
@@ -413,26 +447,26 @@ struct Sink {
 };
 
 // a9 + a12: builder and merge state of one unit, all in registers.
-template <bool EMIT>
+template <bool EMIT, typename I = i64>
 struct Merge {
-  PairCursor rows;  // gaps of the two row profiles
-  PairCursor delta; // gaps of the entry's own rows
-  i64 ref_pos, query_pos, column, last_column;
+  PairCursorT<I> rows;  // gaps of the two row profiles
+  PairCursorT<I> delta; // gaps of the entry's own rows
+  I ref_pos, query_pos, column, last_column;
   // builder (m_delta_builder.hh:9-87)
-  i64 b_ref_start, b_ref_pos, b_query_start, b_query_pos, b_sum0, b_sum1;
+  I b_ref_start, b_ref_pos, b_query_start, b_query_pos, b_sum0, b_sum1;
   bool mirrored;
-  i64 query_columns;
-  Sink<EMIT> sink;
+  I query_columns;
+  Sink<EMIT, I> sink;
 
-  PM_HD __forceinline__ void b_restart(i64 r, i64 q) {
+  PM_HD __forceinline__ void b_restart(I r, I q) {
     b_ref_start = b_ref_pos = r;
     b_query_start = b_query_pos = q;
     b_sum0 = b_sum1 = 0;
     sink.drop();
   }
-  PM_HD __forceinline__ int b_add_gap(int row, R2 d) { // m_delta_builder.hh:32-63
-    i64 walked = row ? (b_query_pos - b_query_start) + b_sum1 : (b_ref_pos - b_ref_start) + b_sum0;
-    R2 g{d.s + walked + 1, d.e + walked + 1};
+  PM_HD __forceinline__ int b_add_gap(int row, R2T<I> d) { // m_delta_builder.hh:32-63
+    I walked = row ? (b_query_pos - b_query_start) + b_sum1 : (b_ref_pos - b_ref_start) + b_sum0;
+    R2T<I> g{d.s + walked + 1, d.e + walked + 1};
     if(row) {
       b_sum1 += rlen(g);
       b_ref_pos += d.e + 1;
@@ -445,13 +479,13 @@ struct Merge {
     }
     return sink.gap(row, g);
   }
-  PM_HD __forceinline__ i64 qcol(i64 pi) const { return mirrored ? query_columns - pi + 1 : pi; }
+  PM_HD __forceinline__ I qcol(I pi) const { return mirrored ? query_columns - pi + 1 : pi; }
   PM_HD __forceinline__ void b_finish() { // m_delta_builder.cc:7-22
     if(b_ref_start != b_ref_pos && b_query_start != b_query_pos) {
-      sink.commit(R2{b_ref_start, b_ref_pos - 1}, R2{qcol(b_query_start), qcol(b_query_pos - 1)});
+      sink.commit(R2T<I>{b_ref_start, b_ref_pos - 1}, R2T<I>{qcol(b_query_start), qcol(b_query_pos - 1)});
     }
   }
-  PM_HD __forceinline__ void consume_delta_piece(int row, R2 d) { // m_translate.cc:220-231
+  PM_HD __forceinline__ void consume_delta_piece(int row, R2T<I> d) { // m_translate.cc:220-231
     if(row) {
       ref_pos += d.e + 1;
       query_pos += d.s;
@@ -462,7 +496,7 @@ struct Merge {
     }
     column += d.e + 1;
   }
-  PM_HD __forceinline__ void close_segment(int row, R2 g) { // m_translate.cc:309-316,436-443
+  PM_HD __forceinline__ void close_segment(int row, R2T<I> g) { // m_translate.cc:309-316,436-443
     b_ref_pos += g.s;
     b_query_pos += g.s;
     if(row) { // m_translate.cc:233-244
@@ -478,14 +512,49 @@ struct Merge {
     b_finish();
     b_restart(ref_pos, query_pos);
   }
-  PM_HD __forceinline__ R2 rel(int row, R2 g) const {
-    i64 base = row ? query_pos : ref_pos;
-    return R2{g.s - base, g.e - base};
+  PM_HD __forceinline__ R2T<I> rel(int row, R2T<I> g) const {
+    I base = row ? query_pos : ref_pos;
+    return R2T<I>{g.s - base, g.e - base};
+  }
+  // I = int only: has any value the merge carries from step to step left +-2^26?
+  // Why that proves the int merge computed what the int64 merge computes: every table value is below 2^25 in
+  // magnitude (checked when the job is prepared; derived table values -- an entry's column count, its mirrored gaps
+  // -- stay below 2^27).  With A = 2^26 and all carried values within +-A at the start of a step, the step's
+  // intermediates are bounded by: a gap relative to a position 3A; the piece of a split 9A; a builder gap 12A+1; its
+  // length, the largest of all, 24A+3; an accumulator after its update 25A+3 < 2^31.  Nothing wraps inside a step
+  // that starts in range, and this check re-establishes the range after every step.
+  PM_HD __forceinline__ bool narrow_overflow() const {
+    const unsigned bias = 1u << 26;
+    unsigned bad = 0;
+#define PM_NARROW_CHECK(x) bad |= (((unsigned)(x) + bias) >> 27)
+    PM_NARROW_CHECK(ref_pos);
+    PM_NARROW_CHECK(query_pos);
+    PM_NARROW_CHECK(column);
+    PM_NARROW_CHECK(b_ref_pos);
+    PM_NARROW_CHECK(b_query_pos);
+    PM_NARROW_CHECK(b_ref_start);
+    PM_NARROW_CHECK(b_query_start);
+    PM_NARROW_CHECK(b_sum0);
+    PM_NARROW_CHECK(b_sum1);
+    PM_NARROW_CHECK(sink.pend);
+    PM_NARROW_CHECK(sink.n_off);
+    PM_NARROW_CHECK(sink.wpos);
+    PM_NARROW_CHECK(sink.last_start);
+    PM_NARROW_CHECK(rows.hold0.s);
+    PM_NARROW_CHECK(rows.hold0.e);
+    PM_NARROW_CHECK(rows.hold1.s);
+    PM_NARROW_CHECK(rows.hold1.e);
+    PM_NARROW_CHECK(delta.hold0.s);
+    PM_NARROW_CHECK(delta.hold0.e);
+    PM_NARROW_CHECK(delta.hold1.s);
+    PM_NARROW_CHECK(delta.hold1.e);
+#undef PM_NARROW_CHECK
+    return bad != 0;
   }
   PM_HD inline int step() { // m_translate.cc:279-472
     bool have_p, have_d;
     int prow = 0, drow = 0;
-    R2 pgap{0, 0}, dgap{0, 0};
+    R2T<I> pgap{0, 0}, dgap{0, 0};
     int st = rows.pick(ref_pos, query_pos, have_p, prow, pgap);
     if(st) {
       return st;
@@ -495,8 +564,8 @@ struct Merge {
       return st;
     }
     if(have_p && have_d) {
-      R2 g = rel(prow, pgap);
-      R2 d{dgap.s - column, dgap.e - column};
+      R2T<I> g = rel(prow, pgap);
+      R2T<I> d{dgap.s - column, dgap.e - column};
       int other = prow ^ 1;
       bool other_within = rows.has(other) && rel(other, rows.front(other)).s <= d.e; // :246-268
       if(g.s <= d.s) {
@@ -509,9 +578,9 @@ struct Merge {
       }
       else {
         // split the entry's gap in front of the row gap it runs into (:368-386 same row, :395-401 other row)
-        i64 keep = prow == drow ? rel(other, rows.front(other)).s - d.s : g.s - d.s;
-        R2 piece{d.s, d.s + keep - 1};
-        R2 rest{dgap.s + keep, dgap.e};
+        I keep = prow == drow ? rel(other, rows.front(other)).s - d.s : g.s - d.s;
+        R2T<I> piece{d.s, d.s + keep - 1};
+        R2T<I> rest{dgap.s + keep, dgap.e};
         st = b_add_gap(drow, piece);
         consume_delta_piece(drow, piece);
         delta.pop(drow);
@@ -525,13 +594,13 @@ struct Merge {
       close_segment(prow, rel(prow, pgap));
     }
     else if(have_d) {
-      R2 d{dgap.s - column, dgap.e - column};
+      R2T<I> d{dgap.s - column, dgap.e - column};
       st = b_add_gap(drow, d);
       consume_delta_piece(drow, d);
       delta.pop(drow);
     }
     else if(column <= last_column) { // :464-470
-      i64 n = last_column - column + 1;
+      I n = last_column - column + 1;
       b_ref_pos += n;
       b_query_pos += n;
       b_finish();
@@ -540,8 +609,9 @@ struct Merge {
   }
 };
 
-PM_HD __forceinline__ PV row_view(const RowsD &rows, int r) {
-  PV p;
+template <typename I>
+PM_HD __forceinline__ PVT<I> row_view(const RowsT<I> &rows, int r) {
+  PVT<I> p;
   p.range = rows.range[r];
   p.len = rows.length[r];
   i64 o = rows.gap_off[r];
@@ -554,8 +624,9 @@ PM_HD __forceinline__ PV row_view(const RowsD &rows, int r) {
 // First part of a unit, up to the test that ends most of them (m_translate.cc:636-639 and :496-513): the
 // overlap of the entry with both rows, the entry's two rows as profiles over its own columns, and the window of
 // columns both rows cover.  `live` = the unit goes on to the subset/merge part.
-PM_HD inline int unit_prefix(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r, PV &lp, PV &rp, PV &dr,
-                             PV &dq, R2 &cols, bool &live, int &orientation) {
+template <typename I>
+PM_HD inline int unit_prefix(const RowsT<I> &left, const RowsT<I> &right, const DeltasT<I> &ds, int d, int l, int r, PVT<I> &lp, PVT<I> &rp, PVT<I> &dr,
+                             PVT<I> &dq, R2T<I> &cols, bool &live, int &orientation) {
   live = false;
   orientation = 0;
   if(left.bad[l] | right.bad[r] | ds.bad[d]) {
@@ -563,16 +634,16 @@ PM_HD inline int unit_prefix(const RowsD &left, const RowsD &right, const Deltas
   }
   lp = row_view(left, l);
   rp = row_view(right, r);
-  R2 de_ref = ds.ref[d], de_qry = ds.qry[d];
-  R2 ref_seq, query_seq;
+  R2T<I> de_ref = ds.ref[d], de_qry = ds.qry[d];
+  R2T<I> ref_seq, query_seq;
   if(!overlap(de_ref, lp.range, ref_seq) || !overlap(de_qry, rp.range, query_seq)) {
     return PM_ST_OK; // :636-639
   }
   int o = fwd(de_ref) != fwd(lp.range) ? 1 : 0; // :210-217
   orientation = o;
   if(o) {
-    de_ref = R2{de_ref.e, de_ref.s};
-    de_qry = R2{de_qry.e, de_qry.s};
+    de_ref = R2T<I>{de_ref.e, de_ref.s};
+    de_qry = R2T<I>{de_qry.e, de_qry.s};
   }
   // the entry's two rows as profiles over its own columns (:496-506)
   i64 ro = ds.ref_off[d], qo = ds.qry_off[d];
@@ -588,7 +659,7 @@ PM_HD inline int unit_prefix(const RowsD &left, const RowsD &right, const Deltas
   dq.len = rlen(de_qry) + dq.pre[dq.n];
 
   int st;
-  R2 d_ref_cols, d_query_cols;
+  R2T<I> d_ref_cols, d_query_cols;
   if((st = profile_idx_of_seq_idx(dr, ref_seq.s, d_ref_cols.s))) return st; // :508-511
   if((st = profile_idx_of_seq_idx(dr, ref_seq.e, d_ref_cols.e))) return st;
   if((st = profile_idx_of_seq_idx(dq, query_seq.s, d_query_cols.s))) return st;
@@ -599,20 +670,22 @@ PM_HD inline int unit_prefix(const RowsD &left, const RowsD &right, const Deltas
 
 // What the merge of a unit starts from, as plain numbers: enough to rebuild the Merge without redoing the ~20 binary
 // searches of the set-up.  The count pass saves it per live unit, the emit pass restores it.
-struct UnitState {
+template <typename I>
+struct UnitStateT {
   int lo[4], n[4];   // kept gaps of: left row, right row, entry's reference row, entry's query row
-  i64 ws[4], we[4];  // their clip windows
-  i64 ref_start, query_start, column, last_column, query_columns;
+  I ws[4], we[4];  // their clip windows
+  I ref_start, query_start, column, last_column, query_columns;
   int orientation;   // 1: the entry is used reversed (m_translate.cc:210-217)
   int mirrored;      // the right row is walked backwards (:557)
 };
+typedef UnitStateT<i64> UnitState;
 
 // Set-up of a unit that passed unit_prefix (m_translate.cc:527-610): `proceed` = the merge has to run.
-template <bool EMIT>
-PM_HD inline int unit_setup(const PV &lp, const PV &rp, const PV &dr, const PV &dq, R2 cols, Merge<EMIT> &m, bool &proceed) {
+template <bool EMIT, typename I>
+PM_HD inline int unit_setup(const PVT<I> &lp, const PVT<I> &rp, const PVT<I> &dr, const PVT<I> &dq, R2T<I> cols, Merge<EMIT, I> &m, bool &proceed) {
   proceed = false;
   int st;
-  R2 d_ref_seq, d_query_seq, l_seq, r_seq;
+  R2T<I> d_ref_seq, d_query_seq, l_seq, r_seq;
   bool none_r, none_q;
   if((st = subset_profile(dr, cols.s, cols.e, m.delta.v0, d_ref_seq, none_r))) return st;   // :527-529
   if((st = subset_profile(dq, cols.s, cols.e, m.delta.v1, d_query_seq, none_q))) return st; // :531-533
@@ -629,11 +702,11 @@ PM_HD inline int unit_setup(const PV &lp, const PV &rp, const PV &dr, const PV &
   m.rows.v1.L = rp.len;
   // :572-581 convert l_seq.s and r_seq.s (r_seq.e when mirrored) back to columns: those are the ends of the windows
   // subset_seq has just derived them from (see there), so no search is repeated
-  const i64 ref_start = m.rows.v0.ws;
-  const i64 query_start = mirrored ? rp.len - m.rows.v1.we + 1 : m.rows.v1.ws;
+  const I ref_start = m.rows.v0.ws;
+  const I query_start = mirrored ? rp.len - m.rows.v1.we + 1 : m.rows.v1.ws;
   m.rows.at0 = m.rows.at1 = m.delta.at0 = m.delta.at1 = 0;
   m.rows.held0 = m.rows.held1 = m.delta.held0 = m.delta.held1 = false;
-  m.rows.hold0 = m.rows.hold1 = m.delta.hold0 = m.delta.hold1 = R2{0, 0};
+  m.rows.hold0 = m.rows.hold1 = m.delta.hold0 = m.delta.hold1 = R2T<I>{0, 0};
   m.ref_pos = ref_start;
   m.query_pos = query_start;
   m.column = cols.s;
@@ -647,8 +720,8 @@ PM_HD inline int unit_setup(const PV &lp, const PV &rp, const PV &dr, const PV &
 
 // The merge loop itself (m_translate.cc:612-618).  Same step budget as oracle/pm_oracle.cc: far above any
 // terminating run; every lane reaches it.
-template <bool EMIT>
-PM_HD inline int unit_merge(Merge<EMIT> &m) {
+template <bool EMIT, typename I>
+PM_HD inline int unit_merge(Merge<EMIT, I> &m) {
   i64 budget = 4 * (i64)(m.rows.v0.n + m.rows.v1.n + m.delta.v0.n + m.delta.v1.n) + 64;
   int st = PM_ST_OK;
   while(!m.rows.done() || !m.delta.done()) {
@@ -660,16 +733,22 @@ PM_HD inline int unit_merge(Merge<EMIT> &m) {
     if(st) {
       break;
     }
+    if(sizeof(I) < 8 && m.narrow_overflow()) {
+      return PM_ST_NARROW;
+    }
   }
   if(!st) {
     st = m.step();
+    if(sizeof(I) < 8 && m.narrow_overflow()) {
+      return PM_ST_NARROW;
+    }
   }
   return st;
 }
 
-template <bool EMIT>
-PM_HD inline void unit_save(const Merge<EMIT> &m, int orientation, UnitState &s) {
-  const GapView *v[4] = {&m.rows.v0, &m.rows.v1, &m.delta.v0, &m.delta.v1};
+template <bool EMIT, typename I>
+PM_HD inline void unit_save(const Merge<EMIT, I> &m, int orientation, UnitStateT<I> &s) {
+  const GapViewT<I> *v[4] = {&m.rows.v0, &m.rows.v1, &m.delta.v0, &m.delta.v1};
   for(int k = 0; k < 4; ++k) {
     s.lo[k] = v[k]->lo;
     s.n[k] = v[k]->n;
@@ -685,12 +764,12 @@ PM_HD inline void unit_save(const Merge<EMIT> &m, int orientation, UnitState &s)
   s.mirrored = m.mirrored ? 1 : 0;
 }
 
-template <bool EMIT>
-PM_HD inline void unit_restore(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r, const UnitState &s,
-                               Merge<EMIT> &m) {
-  const R2 *g[4] = {left.gaps + left.gap_off[l], right.gaps + right.gap_off[r], ds.ref_gaps[s.orientation] + ds.ref_off[d],
+template <bool EMIT, typename I>
+PM_HD inline void unit_restore(const RowsT<I> &left, const RowsT<I> &right, const DeltasT<I> &ds, int d, int l, int r, const UnitStateT<I> &s,
+                               Merge<EMIT, I> &m) {
+  const R2T<I> *g[4] = {left.gaps + left.gap_off[l], right.gaps + right.gap_off[r], ds.ref_gaps[s.orientation] + ds.ref_off[d],
                     ds.qry_gaps[s.orientation] + ds.qry_off[d]};
-  GapView *v[4] = {&m.rows.v0, &m.rows.v1, &m.delta.v0, &m.delta.v1};
+  GapViewT<I> *v[4] = {&m.rows.v0, &m.rows.v1, &m.delta.v0, &m.delta.v1};
   for(int k = 0; k < 4; ++k) {
     v[k]->g = g[k];
     v[k]->lo = s.lo[k];
@@ -704,7 +783,7 @@ PM_HD inline void unit_restore(const RowsD &left, const RowsD &right, const Delt
   m.rows.v1.L = s.query_columns;
   m.rows.at0 = m.rows.at1 = m.delta.at0 = m.delta.at1 = 0;
   m.rows.held0 = m.rows.held1 = m.delta.held0 = m.delta.held1 = false;
-  m.rows.hold0 = m.rows.hold1 = m.delta.hold0 = m.delta.hold1 = R2{0, 0};
+  m.rows.hold0 = m.rows.hold1 = m.delta.hold0 = m.delta.hold1 = R2T<I>{0, 0};
   m.ref_pos = s.ref_start;
   m.query_pos = s.query_start;
   m.column = s.column;
@@ -715,18 +794,18 @@ PM_HD inline void unit_restore(const RowsD &left, const RowsD &right, const Delt
 }
 
 // One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
-template <bool EMIT>
-PM_HD inline int run_unit(const RowsD &left, const RowsD &right, const DeltasD &ds, int d, int l, int r,
-                               Sink<EMIT> &sink) {
-  PV lp, rp, dr, dq;
-  R2 cols;
+template <bool EMIT, typename I>
+PM_HD inline int run_unit(const RowsT<I> &left, const RowsT<I> &right, const DeltasT<I> &ds, int d, int l, int r,
+                               Sink<EMIT, I> &sink) {
+  PVT<I> lp, rp, dr, dq;
+  R2T<I> cols;
   bool live;
   int orientation;
   int st = unit_prefix(left, right, ds, d, l, r, lp, rp, dr, dq, cols, live, orientation);
   if(st || !live) {
     return st;
   }
-  Merge<EMIT> m;
+  Merge<EMIT, I> m;
   m.sink = sink;
   bool proceed;
   st = unit_setup<EMIT>(lp, rp, dr, dq, cols, m, proceed);

@@ -15,12 +15,14 @@ using namespace pm;
 
 namespace {
 
+template <typename I>
 struct HostRows {
-  std::vector<R2> range, gaps;
-  std::vector<i64> length, gap_off, pre;
+  std::vector<R2T<I>> range, gaps;
+  std::vector<I> length, pre;
+  std::vector<i64> gap_off;
   std::vector<int> bad;
-  RowsD view() const {
-    RowsD d;
+  RowsT<I> view() const {
+    RowsT<I> d;
     d.n = (i64)range.size();
     d.range = range.data();
     d.length = length.data();
@@ -33,22 +35,26 @@ struct HostRows {
 };
 
 // the same construction as prepare_rows_kernel
-void prepare_rows(const pm_rows_t *h, HostRows &s) {
+template <typename I>
+void prepare_rows(const pm_rows_t *h, HostRows<I> &s) {
   i64 n = h->n, G = h->gap_off[n];
   s.range.resize(n);
-  s.length.assign(h->length, h->length + n);
+  s.length.resize(n);
+  for(i64 r = 0; r < n; ++r) {
+    s.length[r] = (I)h->length[r];
+  }
   s.gap_off.assign(h->gap_off, h->gap_off + n + 1);
   s.gaps.resize(G + 1);
   s.pre.resize(G + n + 1);
   s.bad.resize(n + 1);
   for(i64 r = 0; r < n; ++r) {
-    s.range[r] = R2{h->start[r], h->end[r]};
+    s.range[r] = R2T<I>{(I)h->start[r], (I)h->end[r]};
     i64 o = h->gap_off[r], m = h->gap_off[r + 1] - o;
-    i64 *p = s.pre.data() + o + r;
-    i64 acc = 0, prev_end = 0;
+    I *p = s.pre.data() + o + r;
+    I acc = 0, prev_end = 0;
     int flag = 0;
     for(i64 k = 0; k < m; ++k) {
-      R2 g{h->gap_start[o + k], h->gap_end[o + k]};
+      R2T<I> g{(I)h->gap_start[o + k], (I)h->gap_end[o + k]};
       if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
         flag = 1;
       }
@@ -62,15 +68,18 @@ void prepare_rows(const pm_rows_t *h, HostRows &s) {
   }
 }
 
+template <typename I>
 struct HostDeltas {
-  std::vector<R2> ref, qry, rg[2], qg[2];
-  std::vector<i64> ref_off, qry_off, rp[2], qp[2];
+  std::vector<R2T<I>> ref, qry, rg[2], qg[2];
+  std::vector<i64> ref_off, qry_off;
+  std::vector<I> rp[2], qp[2];
   std::vector<int> bad;
 };
 
 // the same construction as prepare_deltas_kernel
+template <typename I>
 void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *off, const int64_t *gs, const int64_t *ge,
-                    std::vector<R2> &range, std::vector<R2> &gf, std::vector<i64> &pf, std::vector<R2> &gr, std::vector<i64> &pr,
+                    std::vector<R2T<I>> &range, std::vector<R2T<I>> &gf, std::vector<I> &pf, std::vector<R2T<I>> &gr, std::vector<I> &pr,
                     std::vector<int> &bad) {
   i64 G = off[n];
   range.resize(n);
@@ -79,12 +88,12 @@ void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *
   pf.resize(G + n + 1);
   pr.resize(G + n + 1);
   for(i64 d = 0; d < n; ++d) {
-    R2 rg{rs[d], re[d]};
+    R2T<I> rg{(I)rs[d], (I)re[d]};
     range[d] = rg;
     i64 o = off[d], m = off[d + 1] - o;
-    i64 acc = 0, prev_end = 0;
+    I acc = 0, prev_end = 0;
     for(i64 k = 0; k < m; ++k) {
-      R2 g{gs[o + k], ge[o + k]};
+      R2T<I> g{(I)gs[o + k], (I)ge[o + k]};
       if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
         bad[d] = 1;
       }
@@ -94,10 +103,10 @@ void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *
       acc += rlen(g);
     }
     pf[o + d + m] = acc;
-    i64 columns = rlen(rg) + acc, racc = 0;
+    I columns = rlen(rg) + acc, racc = 0;
     for(i64 k = 0; k < m; ++k) {
-      R2 g{gs[o + (m - 1 - k)], ge[o + (m - 1 - k)]};
-      R2 mg{columns - g.e + 1, columns - g.s + 1};
+      R2T<I> g{(I)gs[o + (m - 1 - k)], (I)ge[o + (m - 1 - k)]};
+      R2T<I> mg{columns - g.e + 1, columns - g.s + 1};
       gr[o + k] = mg;
       pr[o + d + k] = racc;
       racc += rlen(mg);
@@ -106,15 +115,14 @@ void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *
   }
 }
 
-} // namespace
-
-extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+template <typename I>
+int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
                              int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets, pm_entry_t *entries,
                              int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
-  HostRows L, R;
+  HostRows<I> L, R;
   prepare_rows(left, L);
   prepare_rows(right, R);
-  HostDeltas D;
+  HostDeltas<I> D;
   i64 n = deltas->n;
   D.bad.assign(n + 1, 0);
   D.ref_off.assign(deltas->ref_gap_off, deltas->ref_gap_off + n + 1);
@@ -123,7 +131,7 @@ extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, cons
                  D.rp[0], D.rg[1], D.rp[1], D.bad);
   prepare_strand(n, deltas->qry_start, deltas->qry_end, deltas->qry_gap_off, deltas->qry_gap_start, deltas->qry_gap_end, D.qry, D.qg[0],
                  D.qp[0], D.qg[1], D.qp[1], D.bad);
-  DeltasD dv;
+  DeltasT<I> dv;
   dv.n = n;
   dv.ref = D.ref.data();
   dv.qry = D.qry.data();
@@ -136,11 +144,11 @@ extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, cons
     dv.qry_pre[o] = D.qp[o].data();
   }
   dv.bad = D.bad.data();
-  RowsD lv = L.view(), rv = R.view();
+  RowsT<I> lv = L.view(), rv = R.view();
   i64 U = units->n;
   std::vector<i64> cnt_e(U + 1, 0), cnt_o(U + 1, 0);
   for(i64 u = 0; u < U; ++u) { // COUNT pass
-    Sink<false> sink;
+    Sink<false, I> sink;
     memset(&sink, 0, sizeof sink);
     status[u] = run_unit<false>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], sink);
     cnt_e[u] = sink.n_ent;
@@ -158,17 +166,33 @@ extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, cons
     return 1; // caller re-calls with bigger buffers
   }
   for(i64 u = 0; u < U; ++u) { // EMIT pass
-    Sink<true> sink;
+    Sink<true, I> sink;
     memset(&sink, 0, sizeof sink);
     sink.ent = entries + eo[u];
-    sink.ent_cap = eo[u + 1] - eo[u];
+    sink.ent_cap = (I)(eo[u + 1] - eo[u]);
     sink.off = (i64 *)offsets;
     sink.off_base = oo[u];
-    sink.off_cap = oo[u + 1] - oo[u];
+    sink.off_cap = (I)(oo[u + 1] - oo[u]);
     int st = run_unit<true>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], sink);
     if(st != status[u]) {
       return 2; // the two passes must agree
     }
   }
   return 0;
+}
+
+} // namespace
+
+extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+                             int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets, pm_entry_t *entries,
+                             int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
+  return run_all<i64>(left, right, deltas, units, status, unit_entry_off, n_entries, n_offsets, entries, entries_cap, offsets, offsets_cap);
+}
+
+// The int instantiation (the fast path of jobs whose tables are all below 2^25): same tables narrowed, same outputs.
+// A status of PM_ST_NARROW (100) means the merge's range check tripped and the library would redo the job in int64.
+extern "C" int unit_host_run_narrow(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+                                    int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets,
+                                    pm_entry_t *entries, int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
+  return run_all<int>(left, right, deltas, units, status, unit_entry_off, n_entries, n_offsets, entries, entries_cap, offsets, offsets_cap);
 }
