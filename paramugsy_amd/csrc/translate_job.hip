@@ -30,84 +30,111 @@ namespace pm {
 
 // ------------------------------------------------------------------ kernels
 
-// One thread per row: interleave the gap list, build the prefix table, validate ordering.
-__global__ void prepare_rows_kernel(i64 n, const i64 *start, const i64 *end, const i64 *gap_off, const i64 *gs, const i64 *ge,
-                                    R2 *range, R2 *gaps, i64 *pre, int *bad) {
+__device__ __forceinline__ unsigned long long mag(i64 v) { return (unsigned long long)(v < 0 ? -v : v); }
+
+// One thread per row: interleave the gap list, build the prefix table, validate ordering.  Instantiated for int64 (the
+// tables every job has; also validates and records the largest magnitude in the tables, which decides whether the
+// job may use the int tables) and for int (the same tables narrowed: range32/length32/gaps32/pre32).
+template <typename I>
+__global__ void prepare_rows_kernel(i64 n, const i64 *start, const i64 *end, const i64 *length, const i64 *gap_off, const i64 *gs,
+                                    const i64 *ge, R2T<I> *range, I *length_out, R2T<I> *gaps, I *pre, int *bad,
+                                    unsigned long long *maxabs) {
   i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(r >= n) {
     return;
   }
-  range[r] = R2{start[r], end[r]};
+  range[r] = R2T<I>{(I)start[r], (I)end[r]};
+  if(length_out) {
+    length_out[r] = (I)length[r];
+  }
   i64 o = gap_off[r], m = gap_off[r + 1] - o;
-  i64 *p = pre + o + r;
+  I *p = pre + o + r;
   i64 acc = 0, prev_end = 0;
   int flag = 0;
+  unsigned long long big = mag(start[r]) | mag(end[r]) | mag(length[r]);
   for(i64 k = 0; k < m; ++k) {
     R2 g{gs[o + k], ge[o + k]};
     if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
       flag = 1;
     }
     prev_end = g.e;
-    gaps[o + k] = g;
-    p[k] = acc;
+    big |= mag(g.s) | mag(g.e);
+    gaps[o + k] = R2T<I>{(I)g.s, (I)g.e};
+    p[k] = (I)acc;
     acc += rlen(g);
+    big |= mag(acc);
   }
-  p[m] = acc;
-  bad[r] = flag;
+  p[m] = (I)acc;
+  if(bad) {
+    bad[r] = flag;
+  }
+  if(maxabs) { // an OR of magnitudes is below 2^k exactly when every one of them is
+    atomicOr(maxabs, big);
+  }
 }
 
 // One thread per (entry, strand): both orientations of one gap list (m_delta.cc:94-146 for the reversed one).
+// Instantiated like prepare_rows_kernel (bad/maxabs only in the int64 run).
+template <typename I>
 __global__ void prepare_deltas_kernel(i64 n, const i64 *rs, const i64 *re, const i64 *gap_off, const i64 *gs, const i64 *ge,
-                                      R2 *range, R2 *g_fwd, i64 *pre_fwd, R2 *g_rev, i64 *pre_rev, int *bad) {
+                                      R2T<I> *range, R2T<I> *g_fwd, I *pre_fwd, R2T<I> *g_rev, I *pre_rev, int *bad,
+                                      unsigned long long *maxabs) {
   i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(d >= n) {
     return;
   }
   R2 rg{rs[d], re[d]};
-  range[d] = rg;
+  range[d] = R2T<I>{(I)rg.s, (I)rg.e};
   i64 o = gap_off[d], m = gap_off[d + 1] - o;
-  i64 *pf = pre_fwd + o + d;
-  i64 *pr = pre_rev + o + d;
+  I *pf = pre_fwd + o + d;
+  I *pr = pre_rev + o + d;
   i64 acc = 0, prev_end = 0;
   int flag = 0;
+  unsigned long long big = mag(rg.s) | mag(rg.e);
   for(i64 k = 0; k < m; ++k) {
     R2 g{gs[o + k], ge[o + k]};
     if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
       flag = 1;
     }
     prev_end = g.e;
-    g_fwd[o + k] = g;
-    pf[k] = acc;
+    big |= mag(g.s) | mag(g.e);
+    g_fwd[o + k] = R2T<I>{(I)g.s, (I)g.e};
+    pf[k] = (I)acc;
     acc += rlen(g);
+    big |= mag(acc);
   }
-  pf[m] = acc;
+  pf[m] = (I)acc;
   i64 columns = rlen(rg) + acc;
   i64 racc = 0;
   for(i64 k = 0; k < m; ++k) {
     R2 g{gs[o + (m - 1 - k)], ge[o + (m - 1 - k)]};
     R2 mg{columns - g.e + 1, columns - g.s + 1};
-    g_rev[o + k] = mg;
-    pr[k] = racc;
+    g_rev[o + k] = R2T<I>{(I)mg.s, (I)mg.e};
+    pr[k] = (I)racc;
     racc += rlen(mg);
   }
-  pr[m] = racc;
-  if(flag) {
+  pr[m] = (I)racc;
+  if(bad && flag) {
     atomicOr(bad + d, 1);
+  }
+  if(maxabs) {
+    atomicOr(maxabs, big);
   }
 }
 
 // Filter pass: most (entry, left row, right row) triples the reference's loops visit end at the first overlap test
 // (m_translate.cc:513).  One lane per unit runs just that prefix; the survivors ("live" units) are compacted so that
 // the count and emit passes run on dense wavefronts instead of waiting for the few long lanes of every wavefront.
+template <typename I>
 __global__ void __launch_bounds__(64)
-translate_filter_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
+translate_filter_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                         int *status, i64 *cnt_ent, i64 *cnt_off, int *live_flag) {
   i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(u >= n_units) {
     return;
   }
-  PV lp, rp, dr, dq;
-  R2 cols;
+  PVT<I> lp, rp, dr, dq;
+  R2T<I> cols;
   bool live;
   int orientation;
   int st = unit_prefix(left, right, ds, u_delta[u], u_left[u], u_right[u], lp, rp, dr, dq, cols, live, orientation);
@@ -124,12 +151,14 @@ __global__ void scatter_live_kernel(i64 n_units, const int *live_flag, const int
   }
 }
 
-// The saved merge states live in HBM field by field (13 int64 arrays, then 10 int arrays, each n_live long), so that
-// the 64 lanes of a wavefront, which hold consecutive live units, store and load every field as one contiguous run
-// instead of 64 separate 144-byte records.
-static_assert(sizeof(UnitState) == 13 * 8 + 10 * 4, "state_store/state_load lay UnitState out as 13 int64 + 10 int fields");
-__device__ __forceinline__ void state_store(UnitState *base, i64 n, i64 k, const UnitState &s) {
-  i64 *w = reinterpret_cast<i64 *>(base);
+// The saved merge states live in HBM field by field (13 coordinate arrays, then 10 int arrays, each n_live long), so
+// that the 64 lanes of a wavefront, which hold consecutive live units, store and load every field as one contiguous run
+// instead of 64 separate records.
+static_assert(sizeof(UnitStateT<i64>) == 13 * 8 + 10 * 4 && sizeof(UnitStateT<int>) == 23 * 4,
+              "state_store/state_load lay UnitState out as 13 coordinate + 10 int fields");
+template <typename I>
+__device__ __forceinline__ void state_store(void *base, i64 n, i64 k, const UnitStateT<I> &s) {
+  I *w = reinterpret_cast<I *>(base);
   int *iw = reinterpret_cast<int *>(w + 13 * n);
 #pragma unroll
   for(int q = 0; q < 4; ++q) {
@@ -147,8 +176,9 @@ __device__ __forceinline__ void state_store(UnitState *base, i64 n, i64 k, const
   iw[9 * n + k] = s.mirrored;
 }
 
-__device__ __forceinline__ void state_load(const UnitState *base, i64 n, i64 k, UnitState &s) {
-  const i64 *w = reinterpret_cast<const i64 *>(base);
+template <typename I>
+__device__ __forceinline__ void state_load(const void *base, i64 n, i64 k, UnitStateT<I> &s) {
+  const I *w = reinterpret_cast<const I *>(base);
   const int *iw = reinterpret_cast<const int *>(w + 13 * n);
 #pragma unroll
   for(int q = 0; q < 4; ++q) {
@@ -168,11 +198,14 @@ __device__ __forceinline__ void state_load(const UnitState *base, i64 n, i64 k, 
 
 // amdgpu_waves_per_eu(4): keep the register allocation at <= 128 VGPRs (4 waves per SIMD); the kernel is bound by the
 // latency of dependent loads, so resident waves matter more than a few spare registers.
-template <bool EMIT>
+// I = int (the narrow tables): about 70-80 VGPRs, 6-7 waves per SIMD.  `narrow_trip` is set when a unit's int merge
+// left its checked range (PM_ST_NARROW): pm_job_create then switches the job to the int64 tables.
+template <bool EMIT, typename I>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
-translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
+translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                  const int *live_units, const int *live_pos, int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off,
-                 const i64 *off_off, pm_entry_t *entries, i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow, UnitState *states) {
+                 const i64 *off_off, pm_entry_t *entries, i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow, void *states,
+                 int *narrow_trip) {
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(EMIT) {
     if(ent_off[n_units] > ent_cap || off_off[n_units] > off_cap) { // uniform: buffers sized by an older run
@@ -192,7 +225,7 @@ translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_
       return; // the count pass found nothing to write for this unit (most left x right pairs of an entry)
     }
   }
-  Sink<EMIT> sink;
+  Sink<EMIT, I> sink;
   sink.n_ent = sink.n_off = sink.pend = sink.wpos = sink.last_start = 0;
   sink.last_row = 0;
   sink.ent = nullptr;
@@ -200,40 +233,43 @@ translate_kernel(RowsD left, RowsD right, DeltasD ds, i64 n_units, const int *u_
   sink.off_base = sink.off_cap = sink.ent_cap = 0;
   if(EMIT) {
     sink.ent = entries + ent_off[u];
-    sink.ent_cap = ent_off[u + 1] - ent_off[u];
+    sink.ent_cap = (I)(ent_off[u + 1] - ent_off[u]);
     sink.off = offsets;
     sink.off_base = off_off[u];
-    sink.off_cap = off_off[u + 1] - off_off[u];
+    sink.off_cap = (I)(off_off[u + 1] - off_off[u]);
   }
   const int d = u_delta[u], l = u_left[u], r = u_right[u];
   if constexpr(EMIT) {
     // the count pass left this unit's merge start in states[k]: no set-up to redo
-    Merge<EMIT> m;
+    Merge<EMIT, I> m;
     m.sink = sink;
-    UnitState s;
-    state_load(states, n_live, k, s);
+    UnitStateT<I> s;
+    state_load<I>(states, n_live, k, s);
     unit_restore<EMIT>(left, right, ds, d, l, r, s, m);
     (void)unit_merge<EMIT>(m);
   }
   else {
-    PV lp, rp, dr, dq;
-    R2 cols;
+    PVT<I> lp, rp, dr, dq;
+    R2T<I> cols;
     bool live, proceed = false;
     int orientation;
-    Merge<EMIT> m;
+    Merge<EMIT, I> m;
     m.sink = sink;
     int st = unit_prefix(left, right, ds, d, l, r, lp, rp, dr, dq, cols, live, orientation);
     if(!st && live) {
       st = unit_setup<EMIT>(lp, rp, dr, dq, cols, m, proceed);
       if(!st && proceed) {
         if(states) { // null only in the sizing pass of pm_job_create
-          UnitState s;
+          UnitStateT<I> s;
           unit_save<EMIT>(m, orientation, s);
-          state_store(states, n_live, k, s);
+          state_store<I>(states, n_live, k, s);
         }
         st = unit_merge<EMIT>(m);
         sink = m.sink;
       }
+    }
+    if(sizeof(I) < 8 && st == PM_ST_NARROW) {
+      atomicOr(narrow_trip, 1);
     }
     status[u] = st;
     cnt_ent[u] = sink.n_ent;
@@ -298,7 +334,7 @@ static int check_csr(const int64_t *off, int64_t n, const char *what) {
   return PM_OK;
 }
 
-int upload_rows(const pm_rows_t *h, RowsStore &s, hipStream_t stream) {
+int upload_rows(const pm_rows_t *h, RowsStore &s, hipStream_t stream, unsigned long long *maxabs) {
   if(!h || h->n < 0 || (h->n > 0 && (!h->start || !h->end || !h->length))) {
     return fail(PM_E_INVALID, "rows: null array");
   }
@@ -322,11 +358,23 @@ int upload_rows(const pm_rows_t *h, RowsStore &s, hipStream_t stream) {
   PM_TRY(s.raw_e.upload(h->end, n8, stream));
   PM_TRY(s.raw_gs.upload(h->gap_start, g8, stream));
   PM_TRY(s.raw_ge.upload(h->gap_end, g8, stream));
+  if(maxabs) {
+    PM_TRY(s.range32.alloc(n8));
+    PM_TRY(s.length32.alloc(n8 / 2));
+    PM_TRY(s.gaps32.alloc(g8));
+    PM_TRY(s.pre32.alloc((g8 + n8) / 2));
+  }
   if(s.n > 0) {
     unsigned blocks = (unsigned)((s.n + 255) / 256);
-    prepare_rows_kernel<<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw_s.p, (const i64 *)s.raw_e.p, (const i64 *)s.gap_off.p,
-                                                    (const i64 *)s.raw_gs.p, (const i64 *)s.raw_ge.p, (R2 *)s.range.p, (R2 *)s.gaps.p,
-                                                    (i64 *)s.pre.p, (int *)s.bad.p);
+    prepare_rows_kernel<i64><<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw_s.p, (const i64 *)s.raw_e.p, (const i64 *)s.length.p,
+                                                         (const i64 *)s.gap_off.p, (const i64 *)s.raw_gs.p, (const i64 *)s.raw_ge.p,
+                                                         (R2 *)s.range.p, nullptr, (R2 *)s.gaps.p, (i64 *)s.pre.p, (int *)s.bad.p, maxabs);
+    if(maxabs) {
+      prepare_rows_kernel<int><<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw_s.p, (const i64 *)s.raw_e.p, (const i64 *)s.length.p,
+                                                           (const i64 *)s.gap_off.p, (const i64 *)s.raw_gs.p, (const i64 *)s.raw_ge.p,
+                                                           (R2T<int> *)s.range32.p, (int *)s.length32.p, (R2T<int> *)s.gaps32.p,
+                                                           (int *)s.pre32.p, nullptr, nullptr);
+    }
     PM_HIP(hipGetLastError());
   }
   return PM_OK;
@@ -335,6 +383,7 @@ int upload_rows(const pm_rows_t *h, RowsStore &s, hipStream_t stream) {
 struct DeltasStore {
   DevBuf ref, qry, ref_off, qry_off, bad;
   DevBuf ref_gaps[2], ref_pre[2], qry_gaps[2], qry_pre[2];
+  DevBuf ref32, qry32, ref_gaps32[2], ref_pre32[2], qry_gaps32[2], qry_pre32[2]; // the same tables as int
   DevBuf raw[8];
   i64 n = 0, Gr = 0, Gq = 0;
   DeltasD view() const {
@@ -353,9 +402,25 @@ struct DeltasStore {
     d.bad = (const int *)bad.p;
     return d;
   }
+  DeltasT<int> view32() const {
+    DeltasT<int> d;
+    d.n = n;
+    d.ref = (const R2T<int> *)ref32.p;
+    d.qry = (const R2T<int> *)qry32.p;
+    d.ref_off = (const i64 *)ref_off.p;
+    d.qry_off = (const i64 *)qry_off.p;
+    for(int o = 0; o < 2; ++o) {
+      d.ref_gaps[o] = (const R2T<int> *)ref_gaps32[o].p;
+      d.ref_pre[o] = (const int *)ref_pre32[o].p;
+      d.qry_gaps[o] = (const R2T<int> *)qry_gaps32[o].p;
+      d.qry_pre[o] = (const int *)qry_pre32[o].p;
+    }
+    d.bad = (const int *)bad.p;
+    return d;
+  }
 };
 
-static int upload_deltas(const pm_deltas_t *h, DeltasStore &s, hipStream_t stream) {
+static int upload_deltas(const pm_deltas_t *h, DeltasStore &s, hipStream_t stream, unsigned long long *maxabs) {
   if(!h || h->n < 0 || (h->n > 0 && (!h->ref_start || !h->ref_end || !h->qry_start || !h->qry_end))) {
     return fail(PM_E_INVALID, "deltas: null array");
   }
@@ -385,7 +450,13 @@ static int upload_deltas(const pm_deltas_t *h, DeltasStore &s, hipStream_t strea
     PM_TRY(s.ref_pre[o].alloc((size_t)s.Gr * 8 + n8));
     PM_TRY(s.qry_gaps[o].alloc((size_t)s.Gq * 16));
     PM_TRY(s.qry_pre[o].alloc((size_t)s.Gq * 8 + n8));
+    PM_TRY(s.ref_gaps32[o].alloc((size_t)s.Gr * 8));
+    PM_TRY(s.ref_pre32[o].alloc((size_t)s.Gr * 4 + n8 / 2));
+    PM_TRY(s.qry_gaps32[o].alloc((size_t)s.Gq * 8));
+    PM_TRY(s.qry_pre32[o].alloc((size_t)s.Gq * 4 + n8 / 2));
   }
+  PM_TRY(s.ref32.alloc(n8));
+  PM_TRY(s.qry32.alloc(n8));
   PM_TRY(s.raw[0].upload(h->ref_start, n8, stream));
   PM_TRY(s.raw[1].upload(h->ref_end, n8, stream));
   PM_TRY(s.raw[2].upload(h->qry_start, n8, stream));
@@ -396,12 +467,22 @@ static int upload_deltas(const pm_deltas_t *h, DeltasStore &s, hipStream_t strea
   PM_TRY(s.raw[7].upload(h->qry_gap_end, (size_t)s.Gq * 8, stream));
   if(s.n > 0) {
     unsigned blocks = (unsigned)((s.n + 255) / 256);
-    prepare_deltas_kernel<<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw[0].p, (const i64 *)s.raw[1].p, (const i64 *)s.ref_off.p,
-                                                      (const i64 *)s.raw[4].p, (const i64 *)s.raw[5].p, (R2 *)s.ref.p, (R2 *)s.ref_gaps[0].p,
-                                                      (i64 *)s.ref_pre[0].p, (R2 *)s.ref_gaps[1].p, (i64 *)s.ref_pre[1].p, (int *)s.bad.p);
-    prepare_deltas_kernel<<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw[2].p, (const i64 *)s.raw[3].p, (const i64 *)s.qry_off.p,
-                                                      (const i64 *)s.raw[6].p, (const i64 *)s.raw[7].p, (R2 *)s.qry.p, (R2 *)s.qry_gaps[0].p,
-                                                      (i64 *)s.qry_pre[0].p, (R2 *)s.qry_gaps[1].p, (i64 *)s.qry_pre[1].p, (int *)s.bad.p);
+    prepare_deltas_kernel<i64><<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw[0].p, (const i64 *)s.raw[1].p, (const i64 *)s.ref_off.p,
+                                                           (const i64 *)s.raw[4].p, (const i64 *)s.raw[5].p, (R2 *)s.ref.p,
+                                                           (R2 *)s.ref_gaps[0].p, (i64 *)s.ref_pre[0].p, (R2 *)s.ref_gaps[1].p,
+                                                           (i64 *)s.ref_pre[1].p, (int *)s.bad.p, maxabs);
+    prepare_deltas_kernel<i64><<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw[2].p, (const i64 *)s.raw[3].p, (const i64 *)s.qry_off.p,
+                                                           (const i64 *)s.raw[6].p, (const i64 *)s.raw[7].p, (R2 *)s.qry.p,
+                                                           (R2 *)s.qry_gaps[0].p, (i64 *)s.qry_pre[0].p, (R2 *)s.qry_gaps[1].p,
+                                                           (i64 *)s.qry_pre[1].p, (int *)s.bad.p, maxabs);
+    prepare_deltas_kernel<int><<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw[0].p, (const i64 *)s.raw[1].p, (const i64 *)s.ref_off.p,
+                                                           (const i64 *)s.raw[4].p, (const i64 *)s.raw[5].p, (R2T<int> *)s.ref32.p,
+                                                           (R2T<int> *)s.ref_gaps32[0].p, (int *)s.ref_pre32[0].p,
+                                                           (R2T<int> *)s.ref_gaps32[1].p, (int *)s.ref_pre32[1].p, nullptr, nullptr);
+    prepare_deltas_kernel<int><<<blocks, 256, 0, stream>>>(s.n, (const i64 *)s.raw[2].p, (const i64 *)s.raw[3].p, (const i64 *)s.qry_off.p,
+                                                           (const i64 *)s.raw[6].p, (const i64 *)s.raw[7].p, (R2T<int> *)s.qry32.p,
+                                                           (R2T<int> *)s.qry_gaps32[0].p, (int *)s.qry_pre32[0].p,
+                                                           (R2T<int> *)s.qry_gaps32[1].p, (int *)s.qry_pre32[1].p, nullptr, nullptr);
     PM_HIP(hipGetLastError());
   }
   return PM_OK;
@@ -420,6 +501,8 @@ struct pm_job {
   DevBuf status, cnt_ent, cnt_off, ent_off, off_off, entries, offsets, overflow, scan_tmp;
   DevBuf live_flag, live_pos, live_units, scan_tmp32;
   DevBuf states; // UnitState per live unit (null during the sizing pass of pm_job_create)
+  DevBuf maxabs, narrow_trip;
+  bool narrow = false; // the job runs on the int tables (every table value below PM_NARROW_INPUT_LIMIT, no PM_ST_NARROW seen)
   size_t scan_tmp32_bytes = 0;
   size_t scan_tmp_bytes = 0;
   i64 ent_cap = 0, off_cap = 0;
@@ -439,9 +522,18 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   }
   // 1. filter + compaction of the live units
   if(U > 0) {
-    translate_filter_kernel<<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
-                                                      (const int *)j->u_left.p, (const int *)j->u_right.p, (int *)j->status.p,
-                                                      (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, (int *)j->live_flag.p);
+    if(j->narrow) {
+      translate_filter_kernel<int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), U,
+                                                              (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p,
+                                                              (int *)j->status.p, (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p,
+                                                              (int *)j->live_flag.p);
+    }
+    else {
+      translate_filter_kernel<i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U,
+                                                              (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p,
+                                                              (int *)j->status.p, (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p,
+                                                              (int *)j->live_flag.p);
+    }
     PM_HIP(hipGetLastError());
   }
   size_t tmp32 = j->scan_tmp32_bytes;
@@ -456,10 +548,17 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   }
   // 2. count pass over the live units
   if(U > 0) {
-    translate_kernel<false><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
-                                                       (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,
-                                                       (const int *)j->live_pos.p, (int *)j->status.p, (i64 *)j->cnt_ent.p,
-                                                       (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, (UnitState *)j->states.p);
+#define PM_COUNT_ARGS                                                                                                              \
+  U, (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,                 \
+      (const int *)j->live_pos.p, (int *)j->status.p, (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, \
+      0, 0, nullptr, j->states.p, (int *)j->narrow_trip.p
+    if(j->narrow) {
+      translate_kernel<false, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_COUNT_ARGS);
+    }
+    else {
+      translate_kernel<false, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_COUNT_ARGS);
+    }
+#undef PM_COUNT_ARGS
     PM_HIP(hipGetLastError());
   }
   if(ev) {
@@ -477,11 +576,18 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   }
   // 4. emit pass over the live units
   if(emit && U > 0) {
-    translate_kernel<true><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U, (const int *)j->u_delta.p,
-                                                      (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,
-                                                      (const int *)j->live_pos.p, nullptr, nullptr, nullptr, (const i64 *)j->ent_off.p,
-                                                      (const i64 *)j->off_off.p, (pm_entry_t *)j->entries.p, (i64 *)j->offsets.p, j->ent_cap,
-                                                      j->off_cap, (int *)j->overflow.p, (UnitState *)j->states.p);
+#define PM_EMIT_ARGS                                                                                                              \
+  U, (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,                \
+      (const int *)j->live_pos.p, nullptr, nullptr, nullptr, (const i64 *)j->ent_off.p, (const i64 *)j->off_off.p,                 \
+      (pm_entry_t *)j->entries.p, (i64 *)j->offsets.p, j->ent_cap, j->off_cap, (int *)j->overflow.p, j->states.p,                  \
+      (int *)j->narrow_trip.p
+    if(j->narrow) {
+      translate_kernel<true, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS);
+    }
+    else {
+      translate_kernel<true, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS);
+    }
+#undef PM_EMIT_ARGS
     PM_HIP(hipGetLastError());
   }
   if(ev) {
@@ -538,9 +644,15 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
       return rc_;      \
     }                  \
   } while(0)
-  JTRY(upload_rows(left, j->left, stream));
-  JTRY(upload_rows(right, j->right, stream));
-  JTRY(upload_deltas(deltas, j->deltas, stream));
+  JTRY(j->maxabs.alloc(8));
+  JTRY(j->narrow_trip.alloc(4));
+  if(hipMemsetAsync(j->maxabs.p, 0, 8, stream) != hipSuccess || hipMemsetAsync(j->narrow_trip.p, 0, 4, stream) != hipSuccess) {
+    pm_job_destroy(j);
+    return fail(PM_E_HIP, "hipMemsetAsync failed");
+  }
+  JTRY(upload_rows(left, j->left, stream, (unsigned long long *)j->maxabs.p));
+  JTRY(upload_rows(right, j->right, stream, (unsigned long long *)j->maxabs.p));
+  JTRY(upload_deltas(deltas, j->deltas, stream, (unsigned long long *)j->maxabs.p));
   i64 U = j->n_units = units->n;
   JTRY(j->u_delta.upload(units->delta, (size_t)U * 4, stream));
   JTRY(j->u_left.upload(units->left, (size_t)U * 4, stream));
@@ -582,9 +694,31 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
     JTRY(j->scan_tmp32.alloc(tmp32 ? tmp32 : 8));
   }
   JTRY(j->scan_tmp.alloc(tmp ? tmp : 8));
+  // int or int64 tables?  int when every magnitude in the tables is below the limit (PM_TRANSLATE_WIDE=1 forces int64)
+  {
+    unsigned long long big = 0;
+    if(hipMemcpyAsync(&big, j->maxabs.p, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+      pm_job_destroy(j);
+      return fail(PM_E_HIP, "hipMemcpy failed");
+    }
+    const char *wide = getenv("PM_TRANSLATE_WIDE");
+    j->narrow = big < (unsigned long long)PM_NARROW_INPUT_LIMIT && !(wide && wide[0] == '1');
+  }
   // Size the outputs once: the inputs of a job never change, so neither do its output sizes.
   JTRY(job_launch_pass(j, stream, false, nullptr));
   JTRY(job_read_totals(j, stream));
+  if(j->narrow) {
+    int trip = 0;
+    if(hipMemcpy(&trip, j->narrow_trip.p, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      pm_job_destroy(j);
+      return fail(PM_E_HIP, "hipMemcpy failed");
+    }
+    if(trip) { // some unit's int merge left its checked range: this job runs on the int64 tables
+      j->narrow = false;
+      JTRY(job_launch_pass(j, stream, false, nullptr));
+      JTRY(job_read_totals(j, stream));
+    }
+  }
   if(j->n_entries < 0 || j->n_offsets < 0 || j->n_entries > ((i64)1 << 36) || j->n_offsets > ((i64)1 << 38)) {
     pm_job_destroy(j);
     return fail(PM_E_INVALID, "pm_job_create: implausible output size (inconsistent input tables)");
@@ -597,7 +731,7 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
       pm_job_destroy(j);
       return fail(PM_E_HIP, "hipMemcpy failed");
     }
-    JTRY(j->states.alloc((size_t)(n_live > 0 ? n_live : 1) * sizeof(UnitState)));
+    JTRY(j->states.alloc((size_t)(n_live > 0 ? n_live : 1) * sizeof(UnitState))); // the int layout needs less
   }
   JTRY(j->entries.alloc((size_t)j->ent_cap * sizeof(pm_entry_t)));
   JTRY(j->offsets.alloc((size_t)j->off_cap * 8));
@@ -614,8 +748,12 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
     j->deltas.raw[k].release();
   }
   // algorithmic input bytes: the tables the unit kernels can touch + unit triples
-  j->input_bytes = (j->left.n + j->right.n) * (16 + 8 + 8 + 4) + (j->left.G + j->right.G) * (16 + 8) +
-                   j->deltas.n * (32 + 16 + 4) + (j->deltas.Gr + j->deltas.Gq) * (16 + 8) + U * 12;
+  // (coordinates are 8 bytes each, or 4 when the job runs on the int tables)
+  {
+    const i64 c = j->narrow ? 4 : 8;
+    j->input_bytes = (j->left.n + j->right.n) * (2 * c + c + 8 + 4) + (j->left.G + j->right.G) * (2 * c + c) +
+                     j->deltas.n * (4 * c + 16 + 4) + (j->deltas.Gr + j->deltas.Gq) * (2 * c + c) + U * 12;
+  }
 #undef JTRY
   *out = j;
   return PM_OK;
@@ -745,18 +883,27 @@ int pm_job_kernel_bytes(pm_job_t *j, int64_t *count_bytes, int64_t *emit_bytes, 
   }
   int live = 0;
   PM_HIP(hipMemcpy(&live, (int *)j->live_pos.p + j->n_units, 4, hipMemcpyDeviceToHost));
+  const int64_t state_bytes = j->narrow ? (int64_t)sizeof(UnitStateT<int>) : (int64_t)sizeof(UnitState);
   // count pass: the tables once, the live list, status + two counts per live unit, one UnitState per live unit
   if(count_bytes) {
-    *count_bytes = j->input_bytes + (int64_t)live * (4 + 4 + 16 + (int64_t)sizeof(UnitState));
+    *count_bytes = j->input_bytes + (int64_t)live * (4 + 4 + 16 + state_bytes);
   }
   // emit pass: the live list and the saved states, the gap lists again, output offsets, entries and offsets written
   if(emit_bytes) {
-    *emit_bytes = (int64_t)live * (4 + 32 + (int64_t)sizeof(UnitState)) + (j->left.G + j->right.G + j->deltas.Gr + j->deltas.Gq) * 16 +
+    *emit_bytes = (int64_t)live * (4 + 32 + state_bytes) + (j->left.G + j->right.G + j->deltas.Gr + j->deltas.Gq) * (j->narrow ? 8 : 16) +
                   j->ent_cap * (int64_t)sizeof(pm_entry_t) + j->off_cap * 8;
   }
   if(n_live) {
     *n_live = live;
   }
+  return PM_OK;
+}
+
+int pm_job_coordinate_bits(pm_job_t *j, int *bits) {
+  if(!j || !bits) {
+    return fail(PM_E_INVALID, "pm_job_coordinate_bits: null argument");
+  }
+  *bits = j->narrow ? 32 : 64;
   return PM_OK;
 }
 

@@ -131,6 +131,12 @@ class TranslateJob:
         capi.check(capi.lib().pm_job_kernel_bytes(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
+    def coordinate_bits(self) -> int:
+        """32 when the job's kernels run on the int tables (every number in the tables below 2^25), else 64."""
+        b = C.c_int()
+        capi.check(capi.lib().pm_job_coordinate_bits(self._h, C.byref(b)))
+        return b.value
+
     def fetch(self) -> JobResult:
         ne, no = self.sizes()
         status = np.zeros(self.n_units, dtype=np.int32)

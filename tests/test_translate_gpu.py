@@ -13,6 +13,15 @@ from paramugsy_amd.translate import TranslateJob, Workload, translate, profile_i
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["int", "int64"])
+def coordinate_width(request, monkeypatch):
+    """Every test of this file runs twice: on the int tables a job takes when all its numbers are below 2^25 (all the
+    inputs here are), and with PM_TRANSLATE_WIDE=1, on the int64 tables."""
+    monkeypatch.setenv("PM_TRANSLATE_WIDE", "1" if request.param == "int64" else "0")
+    return request.param
+
+
 CASES = ["typical", "gappy", "reverse", "tiny_blocks", "empty"]
 
 
@@ -235,3 +244,27 @@ def test_full_size_job_bytes_equal_cpu_side(oracle_build, tmp_path):
     assert subprocess.run([os.path.join(ROOT, "bin", "m_translate"), w.left_dir, w.right_dir, w.list_path, b]).returncode == 0
     assert os.path.getsize(a) > 50_000_000
     assert filecmp.cmp(a, b, shallow=False)
+
+
+def test_coordinate_width_is_chosen_from_the_tables(coordinate_width, oracle_build, tmp_path):
+    """Numbers below 2^25 -> int kernels (unless PM_TRANSLATE_WIDE=1); one sequence coordinate at 2^25 or above ->
+    int64 kernels.  Either way the oracle's answer, also with coordinates just below the limit."""
+    import pyoracle
+    w = synth.make_workload(str(tmp_path / "job"), 5, **MODES["typical"])
+    for shift, bits_if_free in (((1 << 25) - 70000, 32), ((1 << 25) + 5, 64), ((1 << 40), 64)):
+        t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+        for side in (t.left, t.right):
+            side["start"] += shift
+            side["end"] += shift
+        for k in ("ref_start", "ref_end", "qry_start", "qry_end"):
+            t.deltas[k] += shift
+        job = TranslateJob(t)
+        try:
+            assert job.coordinate_bits() == (64 if coordinate_width == "int64" else bits_if_free)
+            job.run()
+            res = job.fetch()
+        finally:
+            job.close()
+        ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
+        assert_same_result(res, ora)
+        assert (res.status == 0).all() and len(res.entries) > 10
