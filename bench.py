@@ -137,7 +137,8 @@ def bench_translate(args, rank, world, local, torch, dist):
     # the dominant kernel is whichever of the two unit passes is longer; both read the same tables, the emit
     # pass also writes the entries and offsets
     dom_ms = max(ms_count, ms_emit)
-    dom_name = "translate_kernel<true>" if ms_emit >= ms_count else "translate_kernel<false>"
+    bits = job.coordinate_bits()
+    dom_name = "translate_kernel<%s, %s>" % ("true" if ms_emit >= ms_count else "false", "int" if bits == 32 else "long long")
     alg_bytes = emit_bytes if ms_emit >= ms_count else count_bytes  # algorithmic bytes of the dominant kernel's launch
     tr_key = "translate:%d:%d:%d:%d:%d" % (args.tr_genomes, args.tr_genome_len, args.tr_blocks, args.tr_deltas, args.tr_entries)
     out = {
@@ -145,10 +146,11 @@ def bench_translate(args, rank, world, local, torch, dist):
         "value": units * world * args.steps / dt,
         "unit": "units/s",
         "ms_per_step": dt / args.steps * 1e3,
-        "dtype": "int64",
+        "dtype": "int32" if bits == 32 else "int64",
         "config": {"workload": "Mugsy_profile node: %d+%d genomes x %d bp, %d blocks/side, %d delta files x %d entries per rank"
                    % (args.tr_genomes, args.tr_genomes, args.tr_genome_len, args.tr_blocks, args.tr_deltas, args.tr_entries),
-                   "units_per_rank": units, "live_units": n_live, "entries_out": n_ent, "offsets_out": n_off},
+                   "units_per_rank": units, "live_units": n_live, "entries_out": n_ent, "offsets_out": n_off,
+                   "coordinate_bits": bits},
         "kernel_ms": {"filter+compact": ms_filter, "translate_kernel<count>": ms_count, "rocprim_scan_x2": ms_scan,
                       "translate_kernel<emit>": ms_emit},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
