@@ -176,14 +176,35 @@ __global__ void untranslate_text_kernel(i64 n_bytes, i64 n_units, const i64 *uni
   if(g >= n_bytes) {
     return;
   }
-  i64 lo = 0, hi = n_units; // unit of this byte: last u with unit_text_off[u] <= g
+  // unit of this byte: last u with unit_text_off[u] <= g.  The search runs once per workgroup, for the group's first
+  // byte (wave-uniform addresses: scalar loads); a unit is hundreds of bytes, so a thread's own unit is that one or one
+  // of the next few, found by walking; a thread that would walk far searches the rest instead.
+  const i64 g0 = (i64)blockIdx.x * blockDim.x;
+  i64 lo = 0, hi = n_units;
   while(hi - lo > 1) {
     i64 mid = (lo + hi) >> 1;
-    if(unit_text_off[mid] <= g) {
+    if(unit_text_off[mid] <= g0) {
       lo = mid;
     }
     else {
       hi = mid;
+    }
+  }
+  int walked = 0;
+  while(lo + 1 < n_units && unit_text_off[lo + 1] <= g) {
+    ++lo;
+    if(++walked == 8) {
+      hi = n_units;
+      while(hi - lo > 1) {
+        i64 mid = (lo + hi) >> 1;
+        if(unit_text_off[mid] <= g) {
+          lo = mid;
+        }
+        else {
+          hi = mid;
+        }
+      }
+      break;
     }
   }
   const UnitOut o = units[lo];
