@@ -167,3 +167,34 @@ def test_big_profiles_8_rows_4k_columns(oracle_build):
         rc, s = pyoracle.dp_score_of_path(inputs, params, k, p)
         assert rc == 0 and s == scores[k]
     batch.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_shapes_random_scoring(seed, oracle_build, monkeypatch):
+    """Fuzz: 150 pairs of unrelated random lengths (1..2 300 x 1..2 300: zero to three stripe seams, every tile and
+    ring remainder), random 5x5 matrix and gap costs, random waves-per-pair choice.  Scores and paths equal the
+    oracle's full-matrix aligner."""
+    rng = np.random.default_rng(seed)
+    monkeypatch.setenv("PM_DP_WAVES", ["1", "4", "8"][seed % 3])
+    n = 150
+    la = rng.integers(1, 2300, size=n)
+    lb = rng.integers(1, 2300, size=n)
+    la[:6] = [1, 4, 63, 64, 65, 2299]
+    lb[:6] = [2299, 1025, 1024, 1023, 1, 4]
+    rows = int(rng.integers(1, 9))
+
+    def cols(total):
+        c = np.zeros((total, 8), dtype=np.uint8)
+        pick = rng.integers(0, 5, size=(total, rows))
+        for s in range(5):
+            c[:, s] = (pick == s).sum(axis=1)
+        return c
+
+    inputs = dp.DpInputs(cols(int(la.sum())), np.concatenate([[0], np.cumsum(la)]).astype(np.int64), cols(int(lb.sum())),
+                         np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+    p = dp.make_params(rows, rows)
+    for k in range(25):
+        p.sub[k] = int(rng.integers(-6, 7))
+    p.gap_open = int(rng.integers(0, 40)) * rows
+    p.gap_extend = int(rng.integers(0, 6)) * rows
+    run_and_compare(inputs, p)
