@@ -456,6 +456,34 @@ dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b
   }
 }
 
+// Largest ACGT count of any column (stats[0]) and largest row total of any column (stats[1]): what decides between
+// the int8 and the int16 weights.  One pass over the packed columns, grid-stride, one atomic per wavefront.
+__global__ void dp_column_stats_kernel(const u64 *cols, i64 n, int *stats) {
+  int max_base = 0, max_rows = 0;
+  for(i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) {
+    const u64 c = cols[k];
+    int sum = 0;
+#pragma unroll
+    for(int b = 0; b < 5; ++b) {
+      const int v = (int)((c >> (8 * b)) & 0xff);
+      sum += v;
+      if(b < 4) {
+        max_base = max(max_base, v);
+      }
+    }
+    max_rows = max(max_rows, sum);
+  }
+#pragma unroll
+  for(int d = 32; d >= 1; d >>= 1) {
+    max_base = max(max_base, __shfl_xor(max_base, d));
+    max_rows = max(max_rows, __shfl_xor(max_rows, d));
+  }
+  if((threadIdx.x & 63) == 0) {
+    atomicMax(stats + 0, max_base);
+    atomicMax(stats + 1, max_rows);
+  }
+}
+
 } // namespace pm
 
 using namespace pm;
@@ -534,6 +562,7 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   h->total_a = off_a[n_pairs];
   h->total_b = off_b[n_pairs];
   memcpy(h->params.sub, params->sub, sizeof h->params.sub);
+  int max_sub_acgt = 0, max_sub_all = 0;
   {
     // int8 path: counts of A <= 127 and |sum_b B[j][b] * sub[a][b]| <= (rows of B's column) * max|sub[a][.]| <= 127 for a in ACGT
     int max_sub = 0;
@@ -542,31 +571,10 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
         max_sub = std::max(max_sub, std::abs(params->sub[a * 5 + b]));
       }
     }
-    int max_a = 0, max_colsum_b = 0;
-    for(int64_t k = 0; k < off_a[n_pairs]; ++k) {
-      for(int b = 0; b < 4; ++b) {
-        max_a = std::max(max_a, (int)cols_a[k * 8 + b]);
-      }
-    }
-    for(int64_t k = 0; k < off_b[n_pairs]; ++k) {
-      int sum = 0;
-      for(int b = 0; b < 5; ++b) {
-        sum += cols_b[k * 8 + b];
-      }
-      max_colsum_b = std::max(max_colsum_b, sum);
-    }
-    int max_sub_all = 0;
     for(int k = 0; k < 25; ++k) {
       max_sub_all = std::max(max_sub_all, std::abs(params->sub[k]));
     }
-    if((int64_t)max_colsum_b * max_sub_all > 32767) { // the column weights are int16 lanes of v_dot2_i32_i16
-      pm_dp_batch_destroy(h);
-      return fail(PM_E_INVALID, "pm_dp_batch_create: (rows of a column of B) x max|sub| exceeds 32767");
-    }
-    h->dot4 = max_a <= 127 && max_colsum_b * max_sub <= 127;
-    if(const char *e = getenv("PM_DP_DOT4")) {
-      h->dot4 = h->dot4 && atoi(e) != 0;
-    }
+    max_sub_acgt = max_sub;
   }
   h->params.go = params->gap_open;
   h->params.ge = params->gap_extend;
@@ -583,6 +591,35 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   DTRY(h->cols_b.upload(cols_b, (size_t)h->total_b * 8, stream));
   DTRY(h->d_off_a.upload(off_a, (size_t)(n_pairs + 1) * 8, stream));
   DTRY(h->d_off_b.upload(off_b, (size_t)(n_pairs + 1) * 8, stream));
+  {
+    // the ranges of the uploaded columns, found on the device (two 4-byte words back)
+    DevBuf stats;
+    DTRY(stats.alloc(16));
+    int st[4] = {0, 0, 0, 0};
+    if(hipMemset(stats.p, 0, 16) != hipSuccess) {
+      pm_dp_batch_destroy(h);
+      return fail(PM_E_HIP, "hipMemset failed");
+    }
+    if(h->total_a > 0) {
+      dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_a.p, h->total_a, (int *)stats.p);
+    }
+    if(h->total_b > 0) {
+      dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_b.p, h->total_b, (int *)stats.p + 2);
+    }
+    if(hipGetLastError() != hipSuccess || hipMemcpy(st, stats.p, 16, hipMemcpyDeviceToHost) != hipSuccess) {
+      pm_dp_batch_destroy(h);
+      return fail(PM_E_HIP, "column statistics failed");
+    }
+    const int max_a = st[0], max_colsum_b = st[3];
+    if((int64_t)max_colsum_b * max_sub_all > 32767) { // the column weights are int16 lanes of v_dot2_i32_i16
+      pm_dp_batch_destroy(h);
+      return fail(PM_E_INVALID, "pm_dp_batch_create: (rows of a column of B) x max|sub| exceeds 32767");
+    }
+    h->dot4 = max_a <= 127 && max_colsum_b * max_sub_acgt <= 127;
+    if(const char *e = getenv("PM_DP_DOT4")) {
+      h->dot4 = h->dot4 && atoi(e) != 0;
+    }
+  }
   DTRY(h->bnd.alloc((size_t)h->total_a * 8));
   DTRY(h->scores.alloc((size_t)n_pairs * 4));
   DTRY(h->pipe_error.alloc(4));
