@@ -105,3 +105,33 @@ def gather_pair_results(scores, paths, rank: int, world: int, dist=None):
         return None, None
     import numpy as np
     return np.concatenate([g[0] for g in gathered]), [p for g in gathered for p in g[1]]
+
+
+def slice_pairs(inputs, lo: int, hi: int):
+    """Pairs [lo, hi) of a DpInputs as a DpInputs of their own (offsets rebased to 0)."""
+    import numpy as np
+    from .dp import DpInputs
+    a0, a1 = int(inputs.off_a[lo]), int(inputs.off_a[hi])
+    b0, b1 = int(inputs.off_b[lo]), int(inputs.off_b[hi])
+    return DpInputs(inputs.cols_a[a0:a1], (np.asarray(inputs.off_a[lo:hi + 1]) - a0).astype(np.int64), inputs.cols_b[b0:b1],
+                    (np.asarray(inputs.off_b[lo:hi + 1]) - b0).astype(np.int64))
+
+
+def align_sharded(inputs, params, rank: int, world: int, dist=None, device: int = 0, align_fn=None):
+    """DP over a static pair partition: rank r aligns the contiguous slice partition(n_pairs, world, r) on its GPU,
+    rank 0 receives every shard's scores and paths in rank order (host-side gather, no data-path collective).
+    align_fn(sub_inputs, params) -> (scores, paths) replaces the HIP path in the CPU tests (the oracle)."""
+    lo, hi = partition(inputs.n_pairs, world, rank)
+    sub = slice_pairs(inputs, lo, hi)
+    if align_fn is not None:
+        scores, paths = align_fn(sub, params)
+    else:
+        from .dp import DpBatch
+        batch = DpBatch(sub, params, device=device)
+        try:
+            batch.run(traceback=True)
+            scores, ops, n_ops = batch.fetch()
+            paths = batch.paths(ops, n_ops)
+        finally:
+            batch.close()
+    return gather_pair_results(scores, paths, rank, world, dist)

@@ -117,3 +117,60 @@ def test_two_ranks_on_the_gpu_reproduce_the_single_process_bytes(oracle_build, t
         assert p.wait(timeout=180) == 0
     assert open(merged, "rb").read() == open(single, "rb").read()
     assert os.path.getsize(merged) > 5000
+
+
+DP_WORKER = r"""
+import os, pickle, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import numpy as np
+import torch.distributed as dist
+from paramugsy_amd import dp, shard
+rank, world, use_gpu = int(sys.argv[1]), int(sys.argv[2]), sys.argv[5] == "gpu"
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[3], rank=rank, world_size=world)
+inputs = dp.synth_pairs(31, 23, 3, 180, indel_rate=0.03, vary_length=True)   # every rank builds the same batch
+params = dp.make_params(3, 3)
+fn = None
+if not use_gpu:
+    import pyoracle
+    fn = lambda sub, p: pyoracle.dp_align(sub, p)
+scores, paths = shard.align_sharded(inputs, params, rank, world, dist=dist, device=0, align_fn=fn)
+if rank == 0:
+    pickle.dump((np.asarray(scores), [np.asarray(p) for p in paths]), open(sys.argv[4], "wb"))
+else:
+    assert scores is None and paths is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def run_dp_ranks(tmp_path, mode, world=2):
+    import pickle
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER.format(root=ROOT))
+    out = str(tmp_path / "gathered.pkl")
+    port = str(free_port())
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), port, out, mode]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    return pickle.load(open(out, "rb"))
+
+
+def check_dp_gather(scores, paths):
+    import pyoracle
+    from paramugsy_amd import dp
+    inputs = dp.synth_pairs(31, 23, 3, 180, indel_rate=0.03, vary_length=True)
+    o_scores, o_paths = pyoracle.dp_align(inputs, dp.make_params(3, 3))
+    assert np.array_equal(scores, o_scores) and len(paths) == len(o_paths) == 23
+    assert all(np.array_equal(a, b) for a, b in zip(paths, o_paths))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dp_pair_partition_gathers_in_pair_order(world, oracle_build, tmp_path):
+    """The DP's N>1 path on CPU: `world` gloo ranks align contiguous slices of the pair list (the oracle stands in for
+    the HIP path), rank 0 gathers; scores and paths come back in pair order and equal one run over all pairs."""
+    check_dp_gather(*run_dp_ranks(tmp_path, "cpu", world))
+
+
+@pytest.mark.gpu
+def test_dp_two_ranks_on_the_gpu(oracle_build, tmp_path):
+    check_dp_gather(*run_dp_ranks(tmp_path, "gpu"))
