@@ -8,12 +8,13 @@
 //   * one 64-lane wavefront per profile pair, one pair per workgroup, thousands of pairs per launch;
 //   * the columns of B are cut into stripes of 64 lanes x C columns; a lane keeps its C columns' state
 //     (H-gap_open of the previous row, F, and the columns' substitution weights) in registers for the whole
-//     stripe: 5 VGPRs per column;
+//     stripe: 4-5 VGPRs per column;
 //   * the wave sweeps the rows of A as an anti-diagonal wavefront: at step t lane l is on row t-l.  The two
 //     values a row hands to the next lane (H-gap_open and E of the lane's last column) move with one
 //     v_mov_b32_dpp wave_shr:1 each;
 //   * A's packed columns are loaded 64 at a time (one coalesced 512-byte load per 64 steps), expanded to
-//     int16 pairs and staged in a 128-row LDS ring; each lane reads its row with one ds_read_b128;
+//     int8/int16 lanes and staged in a 128-row LDS ring; each lane reads its row with one ds_read_b64 (b96 with
+//     int16 weights);
 //   * the column score is sum-of-pairs = v_dot4_i32_i8 + v_dot2_i32_i16 (or 3 x v_dot2_i32_i16) accumulating onto
 //     the diagonal (the last half lane of the gap-row dot carries gap_open so that the stored H-gap_open needs no
 //     correction);
