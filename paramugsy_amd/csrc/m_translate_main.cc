@@ -2,6 +2,7 @@
 // the reference's lib/m_translate/m_translate_main.cc:19-46; the work runs on the GPU through the C ABI.
 // Optional: PARAMUGSY_DEVICE=<n> selects the HIP device (default 0).
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <fstream>
 #include <string>
@@ -34,5 +35,9 @@ int main(int argc, char **argv) {
     // the reference ends in SIGABRT (uncaught exception / assert) on every failure past argument checking
     return 134;
   }
-  return 0;
+  // done: everything this process wrote is flushed below; leave without tearing the HIP runtime down (tens of
+  // milliseconds that a short-lived tool has no use for)
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }

@@ -7,6 +7,7 @@
 //   mugsy_profiles untranslate -profile_paths_list <file> -in_maf <maf> -out_maf <maf>   (lib/profiles/m_untranslate.ml:168-221)
 // The other commands (maf_to_xmfa, fasta_to_maf) are format converters outside the path; they exit 2 here.
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -96,5 +97,9 @@ int main(int argc, char **argv) {
     fprintf(stderr, "mugsy_profiles %s: error %d: %s\n", cmd.c_str(), rc, pm_last_error());
     return 2; // an uncaught OCaml exception exits 2
   }
-  return 0;
+  // done: everything this process wrote is flushed below; leave without tearing the HIP runtime down (tens of
+  // milliseconds that a short-lived tool has no use for)
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }

@@ -3,6 +3,7 @@
 //   maf_analyzer  <maf>       > report        (lib/profiles_cpp/maf_analyzer.cc:12-38)
 // Same command lines and output bytes; the work runs on the GPU through the C ABI.  PARAMUGSY_DEVICE selects the device.
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 
 #include "../../include/paramugsy_amd.h"
@@ -27,5 +28,9 @@ int main(int argc, char **argv) {
     fprintf(stderr, "error %d: %s\n", rc, pm_last_error());
     return 134;
   }
-  return 0;
+  // done: everything this process wrote is flushed below; leave without tearing the HIP runtime down (tens of
+  // milliseconds that a short-lived tool has no use for)
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }

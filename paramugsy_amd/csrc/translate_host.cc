@@ -381,13 +381,61 @@ struct TextSink {
   bool maybe_flush() { return buf.size() < (1 << 20) - 4096 ? true : flush(); }
 };
 
-int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const std::vector<int32_t> &status,
-                  const std::vector<int64_t> &unit_entry_off, const std::vector<pm_entry_t> &entries, const std::vector<int64_t> &offsets,
-                  std::string &last_left, std::string &last_right) {
-  TextSink out(f);
-  out.last_left = last_left;
-  out.last_right = last_right;
-  for(size_t u = 0; u < units.delta.size(); ++u) {
+// A host array whose elements are left uninitialised (plain malloc), for buffers a copy is about to fill.
+template <typename T>
+struct HostArray {
+  T *p = nullptr;
+  size_t n = 0;
+  explicit HostArray(size_t count) : n(count) { p = (T *)malloc((count ? count : 1) * sizeof(T)); }
+  ~HostArray() { free(p); }
+  HostArray(const HostArray &) = delete;
+  HostArray &operator=(const HostArray &) = delete;
+  bool ok() const { return p != nullptr; }
+  T *data() { return p; }
+  char *bytes() { return (char *)p; }
+  size_t size_bytes() const { return n * sizeof(T); }
+};
+
+// First touch of freshly allocated buffers, spread over a few threads (a page fault per 4 KiB is what a 100 MB
+// device-to-host copy into new memory otherwise pays for, one at a time).
+static void touch_pages(const std::vector<std::pair<char *, size_t> > &bufs) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t n_threads = hw == 0 ? 1 : (hw > 8 ? 8 : hw);
+  size_t total = 0;
+  for(size_t k = 0; k < bufs.size(); ++k) {
+    total += bufs[k].second;
+  }
+  if(total < ((size_t)8 << 20)) {
+    n_threads = 1;
+  }
+  auto work = [&](size_t t) {
+    for(size_t k = 0; k < bufs.size(); ++k) {
+      size_t pages = (bufs[k].second + 4095) / 4096;
+      for(size_t pg = t; pg < pages; pg += n_threads) {
+        ((volatile char *)bufs[k].first)[pg * 4096] = 0;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for(size_t t = 1; t < n_threads; ++t) {
+    th.emplace_back(work, t);
+  }
+  work(0);
+  for(size_t k = 0; k < th.size(); ++k) {
+    th[k].join();
+  }
+}
+
+// Text of the units [u0, u1): what M_delta_stream_writer::write prints for their entries, starting from the header
+// names (last_left, last_right) that the writer holds when it reaches u0.
+static void format_units(size_t u0, size_t u1, const Side &left, const Side &right, const UnitList &units,
+                         const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string last_left,
+                         std::string last_right, std::string &text) {
+  TextSink out(nullptr);
+  out.buf.swap(text);
+  out.last_left.swap(last_left);
+  out.last_right.swap(last_right);
+  for(size_t u = u0; u < u1; ++u) {
     int l = units.left[u], r = units.right[u];
     for(int64_t k = unit_entry_off[u]; k < unit_entry_off[u + 1]; ++k) {
       const pm_entry_t &en = entries[(size_t)k];
@@ -415,25 +463,90 @@ int write_results(FILE *f, const Side &left, const Side &right, const UnitList &
       for(int64_t o = 0; o < en.n_offsets; ++o) {
         out.put_i64(offsets[(size_t)(en.offset_begin + o)]);
         out.buf.push_back('\n');
-        if(!out.maybe_flush()) {
-          return fail(PM_E_IO, "write failed");
-        }
       }
     }
+  }
+  text.swap(out.buf);
+}
+
+// Formatting is the longest host phase of a job (tens of MB of decimal text), and units are independent but for the
+// header rule, which only needs the names of the last entry printed before a unit: the units are cut into slices of
+// about equal output, every slice is formatted by its own thread from the header names in force at its start, and
+// the slices are written in order.
+int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
+                  const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string &last_left,
+                  std::string &last_right) {
+  const size_t U = units.delta.size();
+  // the reference dies inside the first failing unit: what it had emitted so far is on the stream, nothing after it
+  size_t end = U, failed = U;
+  for(size_t u = 0; u < U; ++u) {
     if(status[u] != PM_ST_OK) {
-      // the reference dies inside this unit: what it had emitted so far is on the stream, nothing after it
-      out.flush();
-      char msg[160];
-      snprintf(msg, sizeof msg, "work unit %zu (delta entry %d, left row %d, right row %d) failed with status %d", u, units.delta[u], l, r,
-               (int)status[u]);
-      return fail(status[u] == PM_ST_MALFORMED_INPUT ? PM_E_MALFORMED : PM_E_UNIT, msg);
+      failed = u;
+      end = u + 1;
+      break;
     }
   }
-  if(!out.flush()) {
-    return fail(PM_E_IO, "write failed");
+  const int64_t total_entries = end > 0 ? unit_entry_off[end] : 0;
+  size_t n_slices = 1;
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t want = hw == 0 ? 1 : (hw > 16 ? 16 : hw);
+    // a slice is worth a thread from a few thousand entries up
+    n_slices = (size_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)want, total_entries / 4096));
   }
-  last_left = out.last_left;
-  last_right = out.last_right;
+  std::vector<size_t> cut(n_slices + 1, end);
+  cut[0] = 0;
+  for(size_t s = 1; s < n_slices; ++s) { // first unit whose entries start at or after the s-th share of the entries
+    int64_t target = total_entries * (int64_t)s / (int64_t)n_slices;
+    cut[s] = (size_t)(std::lower_bound(unit_entry_off, unit_entry_off + end, target) - unit_entry_off);
+    if(cut[s] < cut[s - 1]) {
+      cut[s] = cut[s - 1];
+    }
+  }
+  // header names in force at the start of each slice: those of the last unit before it that printed an entry
+  std::vector<std::string> ll(n_slices), rr(n_slices);
+  ll[0] = last_left;
+  rr[0] = last_right;
+  for(size_t s = 1; s < n_slices; ++s) {
+    ll[s] = ll[s - 1];
+    rr[s] = rr[s - 1];
+    for(size_t u = cut[s]; u-- > cut[s - 1];) {
+      if(unit_entry_off[u + 1] > unit_entry_off[u]) {
+        ll[s] = left.major[units.left[u]];
+        rr[s] = right.major[units.right[u]];
+        break;
+      }
+    }
+  }
+  std::vector<std::string> text(n_slices);
+  {
+    std::vector<std::thread> workers;
+    for(size_t s = 1; s < n_slices; ++s) {
+      workers.emplace_back([&, s]() { format_units(cut[s], cut[s + 1], left, right, units, unit_entry_off, entries, offsets, ll[s], rr[s], text[s]); });
+    }
+    format_units(cut[0], cut[1], left, right, units, unit_entry_off, entries, offsets, ll[0], rr[0], text[0]);
+    for(size_t k = 0; k < workers.size(); ++k) {
+      workers[k].join();
+    }
+  }
+  for(size_t s = 0; s < n_slices; ++s) {
+    if(!text[s].empty() && fwrite(text[s].data(), 1, text[s].size(), f) != text[s].size()) {
+      return fail(PM_E_IO, "write failed");
+    }
+  }
+  for(size_t u = end; u-- > 0;) { // the names the writer holds afterwards
+    if(unit_entry_off[u + 1] > unit_entry_off[u]) {
+      last_left = left.major[units.left[u]];
+      last_right = right.major[units.right[u]];
+      break;
+    }
+  }
+  if(failed < U) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "work unit %zu (delta entry %d, left row %d, right row %d) failed with status %d", failed, units.delta[failed],
+             units.left[failed], units.right[failed], (int)status[failed]);
+    return fail(status[failed] == PM_ST_MALFORMED_INPUT ? PM_E_MALFORMED : PM_E_UNIT, msg);
+  }
   return PM_OK;
 }
 
@@ -558,10 +671,18 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
       rc = pm_job_sizes(job, &ne, &no);
     }
     double t3 = now();
-    std::vector<int32_t> status((size_t)uv.n);
-    std::vector<int64_t> ent_off((size_t)uv.n + 1);
-    std::vector<pm_entry_t> entries((size_t)ne);
-    std::vector<int64_t> offsets((size_t)no);
+    // result buffers: not value-initialised (144 MB for a million units); their pages are touched by a few threads at
+    // once before the device-to-host copies land in them
+    HostArray<int32_t> status((size_t)uv.n);
+    HostArray<int64_t> ent_off((size_t)uv.n + 1);
+    HostArray<pm_entry_t> entries((size_t)ne);
+    HostArray<int64_t> offsets((size_t)no);
+    if(!status.ok() || !ent_off.ok() || !entries.ok() || !offsets.ok()) {
+      pm_job_destroy(job);
+      return fail(PM_E_INVALID, "out of host memory");
+    }
+    touch_pages({{status.bytes(), status.size_bytes()}, {ent_off.bytes(), ent_off.size_bytes()}, {entries.bytes(), entries.size_bytes()},
+                 {offsets.bytes(), offsets.size_bytes()}});
     if(!rc) {
       rc = pm_job_fetch(job, status.data(), ent_off.data(), entries.data(), offsets.data());
       if(rc == PM_E_UNIT) {
@@ -573,7 +694,8 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
       return rc;
     }
     double t4 = now();
-    PM_TRY(write_results(out, w.left, w.right, w.units, status, ent_off, entries, offsets, last_left, last_right));
+    PM_TRY(write_results(out, w.left, w.right, w.units, status.data(), ent_off.data(), entries.data(), offsets.data(), last_left,
+                         last_right));
     if(timing) {
       fprintf(stderr, "[pm] device init + upload + prepare + sizing: %.3f s; run: %.4f s; fetch: %.3f s; format + write: %.3f s\n", t2 - t1,
               t3 - t2, t4 - t3, now() - t4);

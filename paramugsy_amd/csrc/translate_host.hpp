@@ -48,9 +48,9 @@ int parse_delta_file(const std::string &path, DeltaTable &table);
 int parse_delta_text(const std::string &text, const std::string &label, DeltaTable &table);
 bool read_stream(FILE *f, std::string &out);
 void enumerate_units(const Side &left, const Side &right, const DeltaTable &table, size_t first_entry, UnitList &units);
-int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const std::vector<int32_t> &status,
-                  const std::vector<int64_t> &unit_entry_off, const std::vector<pm_entry_t> &entries, const std::vector<int64_t> &offsets,
-                  std::string &last_left, std::string &last_right);
+int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
+                  const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string &last_left,
+                  std::string &last_right);
 int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w);
 void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units);
 int translate_to_file(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
