@@ -98,8 +98,12 @@ int main(int argc, char **argv) {
     return 2; // an uncaught OCaml exception exits 2
   }
   // done: everything this process wrote is flushed below; leave without tearing the HIP runtime down (tens of
-  // milliseconds that a short-lived tool has no use for)
+  // milliseconds that a short-lived tool has no use for) -- unless a tool library rides along in this process
+  // (rocprofv3 and friends write their results from exit handlers)
   fflush(stdout);
   fflush(stderr);
-  _exit(0);
+  if(!getenv("LD_PRELOAD") && !getenv("ROCP_TOOL_LIBRARIES") && !getenv("HSA_TOOLS_LIB")) {
+    _exit(0);
+  }
+  return 0;
 }
