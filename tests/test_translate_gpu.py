@@ -268,3 +268,38 @@ def test_coordinate_width_is_chosen_from_the_tables(coordinate_width, oracle_bui
         ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
         assert_same_result(res, ora)
         assert (res.status == 0).all() and len(res.entries) > 10
+
+
+def test_file_level_failure_writes_what_precedes_it(tmp_path):
+    """A job in which some unit fails (here: a row whose recorded profile length is too short for its gaps): the
+    reference dies inside that unit; the drop-in writes the output that precedes it -- byte for byte the beginning of
+    what the intact job prints, up to an entry boundary -- then reports the unit and exits 134."""
+    w = synth.make_workload(str(tmp_path / "job"), 31, **MODES["typical"])
+    good = str(tmp_path / "good.delta")
+    translate(w.left_dir, w.right_dir, w.delta_paths, good)
+    full = open(good, "rb").read()
+    assert full.count(b"\n") > 200
+    # break one row in the later part of the left side: halve its p_length field
+    path = os.path.join(w.left_dir, "profiles")
+    lines = open(path).read().split("\n")
+    heads = [i for i, ln in enumerate(lines) if ln.count(" ") == 6 and not ln[0].isdigit()]
+    broke = 0
+    for i in heads[len(heads) * 2 // 3:]:
+        f = lines[i].split(" ")
+        f[5] = str(max(1, int(f[5]) // 2))
+        lines[i] = " ".join(f)
+        broke += 1
+    open(path, "w").write("\n".join(lines))
+    assert broke > 3
+    bad = str(tmp_path / "bad.delta")
+    with pytest.raises(capi.PmError) as e:
+        translate(w.left_dir, w.right_dir, w.delta_paths, bad)
+    assert e.value.code == capi.PM_E_UNIT and "work unit" in str(e.value)
+    part = open(bad, "rb").read()
+    assert 100 < len(part) < len(full) and full.startswith(part)
+    assert part.endswith(b"\n0\n") or part.count(b"\n") == 2  # ends on an entry boundary
+    # the executable: same bytes, exit status 134 (the reference ends in SIGABRT)
+    cli = str(tmp_path / "cli.delta")
+    r = subprocess.run([os.path.join(ROOT, "bin", "m_translate"), w.left_dir, w.right_dir, w.list_path, cli], capture_output=True)
+    assert r.returncode == 134 and b"work unit" in r.stderr
+    assert open(cli, "rb").read() == part
