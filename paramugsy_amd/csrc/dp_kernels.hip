@@ -501,7 +501,7 @@ struct pm_dp_batch {
   i64 cells = 0;
   int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
   bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
-  int waves_override = 0; // PM_DP_WAVES=1|4|8 forces the waves-per-pair choice
+  int waves_override = 0; // PM_DP_WAVES=1|2|4|8 forces the waves-per-pair choice
   DevBuf pipe_error;
   hipStream_t last_stream = nullptr;
 };
@@ -697,14 +697,14 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
         max_stripes = std::max(max_stripes, (lbk + 64 * h->cols_per_lane - 1) / (64 * h->cols_per_lane));
         max_la = std::max(max_la, h->off_a[k + 1] - h->off_a[k]);
       }
-      bool fits = (max_stripes / 4 + 2) * max_la < ((i64)1 << 30); // the progress word is an int
-      if(h->cols_per_lane == 16 && fits && max_stripes >= 2 && n < 4096) {
-        nw = 4;
-        if(max_stripes >= 8 && n < 1024) { // deep pairs, very few of them: eight stripes in flight per pair
-          nw = 8;
+      bool fits = (max_stripes + 2) * max_la < ((i64)1 << 30); // the progress word is an int
+      // enough waves to give every SIMD about four (1 024 SIMDs), as far as the pairs have stripes to run side by side
+      if(fits && max_stripes >= 2 && n < 4096) {
+        while(nw < 8 && nw * 2 <= max_stripes && n * nw < 4096) {
+          nw *= 2;
         }
       }
-      if(h->waves_override == 1 || ((h->waves_override == 4 || h->waves_override == 8) && h->cols_per_lane == 16 && fits)) {
+      if(h->waves_override == 1 || ((h->waves_override == 2 || h->waves_override == 4 || h->waves_override == 8) && fits)) {
         nw = h->waves_override;
       }
     }
@@ -720,38 +720,36 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
   else {                               \
     DP_LAUNCH_FILL(CC, TR, false, NWV); \
   }
-    if(h->cols_per_lane == 16 && nw == 8) {
-      if(traceback) {
-        DP_LAUNCH_FILL_D4(16, true, 8)
-      }
-      else {
-        DP_LAUNCH_FILL_D4(16, false, 8)
-      }
-    }
-    else if(h->cols_per_lane == 16 && nw == 4) {
-      if(traceback) {
-        DP_LAUNCH_FILL_D4(16, true, 4)
-      }
-      else {
-        DP_LAUNCH_FILL_D4(16, false, 4)
-      }
-    }
-    else if(h->cols_per_lane == 16) {
-      if(traceback) {
-        DP_LAUNCH_FILL_D4(16, true, 1)
-      }
-      else {
-        DP_LAUNCH_FILL_D4(16, false, 1)
-      }
+#define DP_LAUNCH_FILL_TR(CC, NWV)       \
+  if(traceback) {                        \
+    DP_LAUNCH_FILL_D4(CC, true, NWV)     \
+  }                                      \
+  else {                                 \
+    DP_LAUNCH_FILL_D4(CC, false, NWV)    \
+  }
+#define DP_LAUNCH_FILL_NW(CC)    \
+  switch(nw) {                   \
+  case 8:                        \
+    DP_LAUNCH_FILL_TR(CC, 8)     \
+    break;                       \
+  case 4:                        \
+    DP_LAUNCH_FILL_TR(CC, 4)     \
+    break;                       \
+  case 2:                        \
+    DP_LAUNCH_FILL_TR(CC, 2)     \
+    break;                       \
+  default:                       \
+    DP_LAUNCH_FILL_TR(CC, 1)     \
+    break;                       \
+  }
+    if(h->cols_per_lane == 16) {
+      DP_LAUNCH_FILL_NW(16)
     }
     else {
-      if(traceback) {
-        DP_LAUNCH_FILL_D4(8, true, 1)
-      }
-      else {
-        DP_LAUNCH_FILL_D4(8, false, 1)
-      }
+      DP_LAUNCH_FILL_NW(8)
     }
+#undef DP_LAUNCH_FILL_NW
+#undef DP_LAUNCH_FILL_TR
 #undef DP_LAUNCH_FILL_D4
 #undef DP_LAUNCH_FILL
     PM_HIP(hipGetLastError());

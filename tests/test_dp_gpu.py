@@ -73,7 +73,7 @@ def test_chunked_workspace_gives_same_results(oracle_build):
     assert np.array_equal(s1, s2) and all(np.array_equal(a, b) for a, b in zip(p1, p2))
 
 
-@pytest.mark.parametrize("waves", ["1", "4", "8"])
+@pytest.mark.parametrize("waves", ["1", "2", "4", "8"])
 @pytest.mark.parametrize("cols", ["8", "16"])
 @pytest.mark.parametrize("dot4", ["0", "1"])
 def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, oracle_build, monkeypatch):
