@@ -12,7 +12,8 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libparamugsy_amd.so")
+# PM_LIB_PATH: a differently configured build of the same library (tools/dp_mode_timing.py compares block geometries)
+LIB_PATH = os.environ.get("PM_LIB_PATH") or os.path.join(_HERE, "libparamugsy_amd.so")
 
 PM_OK = 0
 PM_E_INVALID, PM_E_NO_DEVICE, PM_E_HIP, PM_E_IO, PM_E_PARSE, PM_E_UNIT, PM_E_MALFORMED = -1, -2, -3, -4, -5, -6, -7

@@ -39,22 +39,18 @@
 #include <string>
 #include <vector>
 
+#include "dp_internal.hpp"
 #include "pm_internal.hpp"
 
 namespace pm {
 
-typedef long long i64;
-typedef unsigned long long u64;
 typedef short short2_t __attribute__((ext_vector_type(2)));
 
-#define DP_NEG_INF (-(1 << 29))
 #define DPP_WAVE_SHR1 0x138
 
-struct DpParamsD {
-  int sub[25];
-  int go;
-  int ge;
-};
+// What the fill kernel leaves behind for the path (dp_internal.hpp): nothing (scores only), 4 decision bits per cell,
+// or the row/column checkpoints the walk of dp_walk.hip recomputes blocks from.
+enum { DP_MODE_SCORE = 0, DP_MODE_BITS = 1, DP_MODE_CKPT = 2 };
 
 __device__ __forceinline__ int dot2(int a, int b, int acc) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
@@ -150,26 +146,29 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 // stripe may start a 64-row block as soon as the stripe to its left has published those rows of its boundary:
 // a pipeline of stripes, synchronised through one progress word per wave in LDS.  Waits are bounded (a timeout sets
 // *pipe_error and lets the wave run on, so the grid always drains).
-template <int C, bool TRACE, bool DOT4, int NW>
+template <int C, int MODE, bool DOT4, int NW>
 __global__ void __launch_bounds__(64 * NW)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, i64 first_pair, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
                int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P) {
   static_assert(C % 8 == 0, "whole traceback words per lane per step");
+  constexpr bool TRACE = MODE == DP_MODE_BITS;
+  constexpr bool CKPT = MODE == DP_MODE_CKPT;
   constexpr int TBW = C / 8;
   __shared__ int4 ring_all[NW][128];
   __shared__ int progress[NW]; // per wave: rows of boundary published so far, cumulated over the wave's stripes
-  __shared__ unsigned tbstage_all[NW][4][64 * TBW]; // the decisions of the current tile (4 steps), per wave
+  constexpr int TBS = TRACE ? 64 * TBW : 1;
+  __shared__ unsigned tbstage_all[NW][TRACE ? 4 : 1][TBS]; // the decisions of the current tile (4 steps), per wave
   const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   int4 *ring = ring_all[wv];
-  unsigned(*tbstage)[64 * TBW] = tbstage_all[wv];
+  unsigned(*tbstage)[TBS] = tbstage_all[wv];
   const i64 pair = first_pair + blockIdx.x;
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
   const u64 *A = cols_a + a0;
   const u64 *B = cols_b + b0;
-  unsigned *tbp = TRACE ? tb + tb_off[blockIdx.x] : nullptr;
+  unsigned *tbp = (TRACE || CKPT) ? tb + tb_off[blockIdx.x] : nullptr;
   int2 *bp = bnd + a0;
   const int go = P.go, ge = P.ge;
   const int gop = go - ge; // cost of opening over extending, the only gap constant left in skewed coordinates
@@ -326,7 +325,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
             }
           }
         }
-        if(TRACE) { // into this lane's slot of the tile being assembled in LDS
+        if constexpr(TRACE) { // into this lane's slot of the tile being assembled in LDS
 #pragma unroll
           for(int k = 0; k < TBW; ++k) {
             tbstage[tq][lane * TBW + k] = accw[k];
@@ -336,8 +335,26 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         if(lane == 63 && s + 1 < n_stripes) {
           bp[ii16 >> 4] = make_int2(hop[C - 1], e);
         }
+        if constexpr(CKPT) { // what this row hands to the next column group: one coalesced store per step
+          if(DP_CK_W == 1 || (lane & (DP_CK_W - 1)) == DP_CK_W - 1) {
+            *reinterpret_cast<int2 *>(tbp + dp_ck_col_word(la, s, t, lane)) = make_int2(hop[C - 1], e);
+          }
+        }
       }
-      if(TRACE && (tq == 3 || t == steps - 1)) {
+      if constexpr(CKPT) {
+        // the lane's column state every DP_CK_R steps, the lanes of a group one step apart (after the same row of A)
+        if(((t + 1) & (DP_CK_R - 1)) < DP_CK_W) {
+          const int tt = t + 1 - (lane & (DP_CK_W - 1));
+          if(tt > 0 && (tt & (DP_CK_R - 1)) == 0) {
+            int4 *dst = reinterpret_cast<int4 *>(tbp + dp_ck_row_word(la, lb, C, s, tt / DP_CK_R - 1, lane));
+#pragma unroll
+            for(int c = 0; c < C; c += 2) {
+              dst[c / 2] = make_int4(hop[c], f[c], hop[c + 1], f[c + 1]);
+            }
+          }
+        }
+      }
+      if constexpr(TRACE) if(tq == 3 || t == steps - 1) {
         // tile complete (or the stripe's last, partial tile): every lane writes its own 4 x TBW words, contiguously;
         // the wave's store covers one contiguous 1-2 KiB tile
         unsigned *dst = tbp + (((i64)s * tiles + (t >> 2)) * 64 + lane) * (4 * TBW);
@@ -502,6 +519,8 @@ struct pm_dp_batch {
   int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
   bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
   int waves_override = 0; // PM_DP_WAVES=1|2|4|8 forces the waves-per-pair choice
+  bool ckpt = true;       // paths from checkpoints + block recomputation (dp_walk.hip); PM_DP_MODE=bits stores 4 bits per cell
+  int walk_lanes = 0;     // lanes per pair of the checkpoint walk (2, 4, 8, 16); 0 = chosen per launch; PM_DP_WALK_LANES overrides
   DevBuf pipe_error;
   hipStream_t last_stream = nullptr;
 };
@@ -556,6 +575,15 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   }
   if(const char *e = getenv("PM_DP_COLS")) {
     h->cols_per_lane = atoi(e) == 8 ? 8 : 16;
+  }
+  if(const char *e = getenv("PM_DP_MODE")) {
+    h->ckpt = strcmp(e, "bits") != 0;
+  }
+  if(const char *e = getenv("PM_DP_WALK_LANES")) {
+    int v = atoi(e);
+    if(dp_walk_lanes_ok(h->cols_per_lane, v)) {
+      h->walk_lanes = v;
+    }
   }
   h->n_pairs = n_pairs;
   h->off_a.assign(off_a, off_a + n_pairs + 1);
@@ -640,7 +668,7 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   i64 used = 0;
   for(i64 k = 0; k < n_pairs; ++k) {
     i64 la = off_a[k + 1] - off_a[k], lb = off_b[k + 1] - off_b[k];
-    i64 need = dp_tb_words(la, lb, h->cols_per_lane);
+    i64 need = h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane) : dp_tb_words(la, lb, h->cols_per_lane);
     h->cells += la * lb;
     if(!cur.empty() && used + need > budget_words) {
       h->chunk_tb.push_back(cur);
@@ -669,8 +697,22 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   return PM_OK;
 }
 
-static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_trace) {
+namespace {
+struct Events3 { // destroyed on every way out of dp_run
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  ~Events3() {
+    for(int k = 0; k < 3; ++k) {
+      if(ev[k]) {
+        (void)hipEventDestroy(ev[k]);
+      }
+    }
+  }
+};
+} // namespace
+
+static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_trace) {
+  Events3 events;
+  hipEvent_t *ev = events.ev;
   float acc_fill = 0, acc_trace = 0;
   bool timed = ms_fill || ms_trace;
   if(timed) {
@@ -720,12 +762,15 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
   else {                               \
     DP_LAUNCH_FILL(CC, TR, false, NWV); \
   }
-#define DP_LAUNCH_FILL_TR(CC, NWV)       \
-  if(traceback) {                        \
-    DP_LAUNCH_FILL_D4(CC, true, NWV)     \
-  }                                      \
-  else {                                 \
-    DP_LAUNCH_FILL_D4(CC, false, NWV)    \
+#define DP_LAUNCH_FILL_TR(CC, NWV)                \
+  if(traceback && h->ckpt) {                      \
+    DP_LAUNCH_FILL_D4(CC, DP_MODE_CKPT, NWV)      \
+  }                                               \
+  else if(traceback) {                            \
+    DP_LAUNCH_FILL_D4(CC, DP_MODE_BITS, NWV)      \
+  }                                               \
+  else {                                          \
+    DP_LAUNCH_FILL_D4(CC, DP_MODE_SCORE, NWV)     \
   }
 #define DP_LAUNCH_FILL_NW(CC)    \
   switch(nw) {                   \
@@ -756,7 +801,23 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
     if(timed) {
       PM_HIP(hipEventRecord(ev[1], stream));
     }
-    if(traceback) {
+    if(traceback && h->ckpt) {
+      // lanes per pair: as few as still give the launch about two wavefronts per SIMD (1 024 SIMDs)
+      int lpp = h->walk_lanes;
+      if(lpp == 0) {
+        lpp = 2;
+        while(!dp_walk_lanes_ok(h->cols_per_lane, lpp)) {
+          lpp *= 2;
+        }
+        while(lpp < 16 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp < 2 * 1024 * 64) {
+          lpp *= 2;
+        }
+      }
+      PM_TRY(dp_launch_walk(h->cols_per_lane, lpp, (const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
+                            (const i64 *)h->d_off_b.p, first, n, tb_off, (const unsigned *)h->tb.p, (unsigned char *)h->ops.p,
+                            (int *)h->n_ops.p, h->params, stream));
+    }
+    else if(traceback) {
       if(h->cols_per_lane == 16) {
         dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off,
                                                                 (const unsigned *)h->tb.p, (unsigned char *)h->ops.p, (int *)h->n_ops.p);
@@ -775,11 +836,6 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
       PM_HIP(hipEventElapsedTime(&b, ev[1], ev[2]));
       acc_fill += a;
       acc_trace += b;
-    }
-  }
-  if(timed) {
-    for(int k = 0; k < 3; ++k) {
-      (void)hipEventDestroy(ev[k]);
     }
   }
   if(ms_fill) {
@@ -860,7 +916,13 @@ int pm_dp_batch_info(pm_dp_batch_t *h, int64_t *cells, int64_t *traceback_bytes_
   if(traceback_bytes_per_run) {
     i64 words = 0;
     for(i64 k = 0; k < h->n_pairs; ++k) {
-      words += dp_tb_words(h->off_a[k + 1] - h->off_a[k], h->off_b[k + 1] - h->off_b[k], h->cols_per_lane);
+      i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+      if(h->ckpt) { // what the fill kernel writes: the column checkpoints of the rows it is on + the row checkpoints
+        words += dp_ck_bytes_written(la, lb, h->cols_per_lane) / 4;
+      }
+      else {
+        words += dp_tb_words(la, lb, h->cols_per_lane);
+      }
     }
     *traceback_bytes_per_run = words * 4;
   }
@@ -891,8 +953,9 @@ int pm_dp_batch_variant(pm_dp_batch_t *h, int32_t *cols_per_lane, int32_t *dot4,
     *dot4 = h->dot4 ? 1 : 0;
   }
   if(valu_ops_per_cell) {
-    // per cell: column score (dot4 + dot2 = 2, or 3 x dot2), E 3, F 3, H + two decision bits 5, H - open 1
-    *valu_ops_per_cell = (h->dot4 ? 2 : 3) + 3 + 3 + 5 + 1;
+    // per cell: column score (dot4 + dot2 = 2, or 3 x dot2), E 3, F 3, H + two decision bits 5, H - open 1;
+    // without the decision bits (checkpoint mode): score 2 or 3, E 1, F 1, H 1, H - open 1
+    *valu_ops_per_cell = h->ckpt ? (h->dot4 ? 2 : 3) + 4 : (h->dot4 ? 2 : 3) + 3 + 3 + 5 + 1;
   }
   return PM_OK;
 }

@@ -1,0 +1,299 @@
+// dp_walk.hip -- the path of every pair from the checkpoints the score-only fill kernel left (dp_internal.hpp), gfx950.
+//
+// NO REFERENCE COUNTERPART; checked against oracle/dp_oracle.c only.
+//
+// A group of LPP lanes (2, 4, 8 or 16; 64 / LPP pairs per wavefront) walks one pair from (La, Lb) back to (0, 0).
+// The walk needs the four decisions of the cells it visits; the fill kernel stored none.  So, block by block along the path:
+//   1. the block is the C columns of one lane of the fill kernel x the rows between two of that lane's row checkpoints
+//      (at most DP_CK_R rows);
+//   2. its top edge ({H~ - gop, F~} of the C columns) comes from the row checkpoint, its left edge ({H~ - gop, E~} per row)
+//      from the column checkpoints of the lane to the left, A's rows and both edges are staged in LDS;
+//   3. the group re-runs the recurrence inside the block as a small anti-diagonal wavefront (lane q owns C / LPP columns,
+//      neighbours exchange with v_mov_b32_dpp row_shr:1), now WITH the four decision bits, 4 bits per cell into LDS;
+//   4. the walk follows the decisions until it leaves the block through its top or its left edge.
+// Same arithmetic, in the same skewed coordinates, as dp_fill_kernel (V~[i][j] = V[i][j] + (i + j) * gap_extend), so every
+// decision is the one the one-pass kernel would have stored.  A path crosses at most La / DP_CK_R + Lb / C + 1 blocks, i.e. the
+// walk recomputes about La * C + Lb * DP_CK_R cells of the La * Lb: 2-5 % at kilobase lengths.
+#include <hip/hip_runtime.h>
+
+#include "dp_internal.hpp"
+#include "pm_internal.hpp"
+
+namespace pm {
+
+#define DPP_WAVE_SHR1 0x138
+
+// lane l takes lane l-1's value (lane 0 keeps its own); the first lane of every group replaces what it gets
+__device__ __forceinline__ int from_left_lane(int v) { return __builtin_amdgcn_update_dpp(v, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
+
+template <int N> struct BitsWord { typedef unsigned type; };
+template <> struct BitsWord<1> { typedef unsigned char type; };
+template <> struct BitsWord<2> { typedef unsigned char type; };
+template <> struct BitsWord<4> { typedef unsigned short type; };
+
+template <int C, int LPP>
+__global__ void __launch_bounds__(64)
+dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b, const i64 *__restrict__ off_b,
+               i64 first_pair, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
+               int *__restrict__ n_ops, DpParamsD P) {
+  constexpr int R = DP_CK_R;
+  constexpr int BW = C * DP_CK_W; // columns of a block
+  constexpr int C2 = BW / LPP;    // columns per lane inside a block
+  constexpr int G = 64 / LPP;     // pairs per wavefront
+  static_assert(C2 >= 1 && C2 <= 8 && C % C2 == 0 && C2 * LPP == BW, "a lane's columns lie in one lane of the fill kernel");
+  typedef typename BitsWord<C2>::type bits_t;
+  __shared__ uint2 sh_a[G][R];
+  __shared__ int2 sh_left[G][R + 1];
+  __shared__ bits_t sh_bits[G][R][LPP];
+  const int grp = threadIdx.x / LPP, q = threadIdx.x % LPP;
+  const i64 idx = (i64)blockIdx.x * G + grp;
+  const bool valid = idx < n;
+  const i64 pair = first_pair + (valid ? idx : 0);
+  const i64 a0 = off_a[pair], b0 = off_b[pair];
+  const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
+  const uint2 *A = reinterpret_cast<const uint2 *>(cols_a + a0);
+  const u64 *B = cols_b + b0;
+  const unsigned *ckp = ck + tb_off[valid ? idx : 0];
+  unsigned char *out = ops + a0 + b0;
+  const int go = P.go, ge = P.ge, gop = go - ge;
+  int i = la, j = lb, state = 0; // DP coordinates of the walk (cell (i, j) = row i-1 of A against column j-1 of B)
+  int at = la + lb;
+
+  for(;;) {
+    const bool live = valid && i > 0 && j > 0;
+    if(!__any(live)) {
+      break;
+    }
+    // ---- the block the walk is in: column group gg (lanes l0 .. l0 + DP_CK_W - 1 of stripe s of the fill kernel), row block k
+    const int gg = live ? (j - 1) / BW : 0;
+    const int s = (gg * DP_CK_W) >> 6, l0 = (gg * DP_CK_W) & 63;
+    const int k = live ? (i - 1 + l0) / R : 0;
+    const int i0 = max(0, k * R - l0);
+    const int i1 = live ? min(la, (k + 1) * R - l0) : i0;
+    const int nrows = i1 - i0;
+    const int j0 = gg * BW;
+    // ---- this lane's columns: weights w[a] = sum_b B[j][b] * sub[a][b], constant go + ge (dp_fill_kernel's w2 high half)
+    int w[C2][5], kc[C2], hop[C2], f[C2];
+#pragma unroll
+    for(int c = 0; c < C2; ++c) {
+      const int jc = j0 + q * C2 + c;
+      const bool in = live && jc < lb;
+      const u64 col = in ? B[jc] : 0ull;
+      int cb[5];
+#pragma unroll
+      for(int b = 0; b < 5; ++b) {
+        cb[b] = (int)((col >> (8 * b)) & 0xff);
+      }
+#pragma unroll
+      for(int a = 0; a < 5; ++a) {
+        int acc = 0;
+#pragma unroll
+        for(int b = 0; b < 5; ++b) {
+          acc += cb[b] * P.sub[a * 5 + b];
+        }
+        w[c][a] = acc;
+      }
+      kc[c] = in ? go + ge : 0;
+    }
+    // ---- top edge: the state of the lane's columns after row i0 - 1 (the group's row checkpoint k - 1)
+    const bool has_top = live && k * R - l0 >= 1;
+    if(has_top) {
+      const int lf = (q * C2) / C, cf = (q * C2) % C;
+      const int2 *src = reinterpret_cast<const int2 *>(ckp + dp_ck_row_word(la, lb, C, s, k - 1, l0 + lf)) + cf;
+#pragma unroll
+      for(int c = 0; c < C2; ++c) {
+        const int2 v = src[c];
+        hop[c] = v.x;
+        f[c] = v.y;
+      }
+    }
+    else {
+#pragma unroll
+      for(int c = 0; c < C2; ++c) {
+        hop[c] = -2 * gop; // H~[0][j] - gop, H~[0][j] = -gop for j >= 1
+        f[c] = DP_NEG_INF;
+      }
+    }
+    // ---- A's rows and the left edge (rows i0 - 1 .. i1 - 1) into LDS
+    if(live) {
+      for(int r = q; r < nrows; r += LPP) {
+        sh_a[grp][r] = A[i0 + r];
+      }
+      const int gl = gg * DP_CK_W - 1, sl = gl >> 6, ll = gl & 63; // the lane left of the group (of the previous stripe for l0 = 0)
+      for(int rr = q; rr <= nrows; rr += LPP) {
+        const int row = i0 - 1 + rr; // row of A; -1 is the DP's row 0
+        int2 v;
+        if(gg == 0) {
+          v = make_int2(row < 0 ? -gop : -2 * gop, DP_NEG_INF); // H~[row + 1][0] - gop
+        }
+        else if(row < 0) {
+          v = make_int2(-2 * gop, DP_NEG_INF); // H~[0][j0] - gop, j0 >= 1
+        }
+        else {
+          v = *reinterpret_cast<const int2 *>(ckp + dp_ck_col_word(la, sl, (i64)row + ll, ll));
+        }
+        sh_left[grp][rr] = v;
+      }
+    }
+    __syncthreads();
+    // ---- the block's cells, anti-diagonal over the group's lanes: at step u lane q is on row u - q of the block
+    int e = DP_NEG_INF;
+    int diag_in = from_left_lane(hop[C2 - 1]); // H~ - gop above-left of the lane's first column
+    if(q == 0) {
+      diag_in = sh_left[grp][0].x;
+    }
+    for(int u = 0; __any(live && u - q < nrows); ++u) {
+      const int ho_n = from_left_lane(hop[C2 - 1]);
+      const int e_n = from_left_lane(e);
+      const int r = u - q;
+      if(live && r >= 0 && r < nrows) {
+        int ho_in = ho_n, e_in = e_n;
+        if(q == 0) {
+          const int2 b = sh_left[grp][r + 1];
+          ho_in = b.x;
+          e_in = b.y;
+        }
+        const uint2 ar = sh_a[grp][r];
+        const int a_0 = (int)(ar.x & 0xff), a_1 = (int)((ar.x >> 8) & 0xff), a_2 = (int)((ar.x >> 16) & 0xff), a_3 = (int)(ar.x >> 24),
+                  a_4 = (int)(ar.y & 0xff);
+        int ev = e_in, hl = ho_in, dprev = diag_in;
+        unsigned word = 0;
+#pragma unroll
+        for(int c = 0; c < C2; ++c) {
+          const int d = dprev + a_0 * w[c][0] + a_1 * w[c][1] + a_2 * w[c][2] + a_3 * w[c][3] + a_4 * w[c][4] + kc[c];
+          const unsigned b_e = (unsigned)(hl - ev) >> 31; // E extends (ties open)
+          ev = max(ev, hl);
+          const unsigned b_f = (unsigned)(hop[c] - f[c]) >> 31; // F extends
+          f[c] = max(f[c], hop[c]);
+          const int h = max(d, max(ev, f[c]));
+          const unsigned b_n = (unsigned)(d - h) >> 31;      // H is not the diagonal
+          const unsigned b_x = (unsigned)(ev - f[c]) >> 31; // F beats E
+          dprev = hop[c];
+          hop[c] = h - gop;
+          hl = hop[c];
+          word = (word << 4) | (b_e << 3) | (b_f << 2) | (b_n << 1) | b_x;
+        }
+        e = ev;
+        diag_in = ho_in;
+        sh_bits[grp][r][q] = (bits_t)word;
+      }
+    }
+    __syncthreads();
+    // ---- follow the decisions until the walk leaves the block.  The group's lanes look at the next LPP cells along the
+    // current direction (diagonal in state H, along the row in E, along the column in F); a ballot finds how far the run
+    // goes and the whole run is emitted at once, lane q writing op q of it.
+    bool inb = live;
+    while(__any(inb)) {
+      const int di = state != 1, dj = state != 2;
+      const int ci = i - q * di, cj = j - q * dj;
+      const bool cv = inb && ci - 1 >= i0 && cj - 1 >= j0; // i0, j0 >= 0: also inside the DP
+      unsigned nib = 0;
+      if(cv) {
+        const int cc = cj - 1 - j0;
+        const unsigned word = sh_bits[grp][ci - 1 - i0][cc / C2];
+        nib = (word >> (4 * (C2 - 1 - cc % C2))) & 15u;
+      }
+      const unsigned keep = state == 0 ? (~nib & 2u) : (state == 1 ? (nib & 8u) : (nib & 4u));
+      const int sh = grp * LPP;
+      const u64 gmask = LPP == 64 ? ~0ull : ((1ull << (LPP & 63)) - 1);
+      const u64 gc = (__ballot(cv && keep != 0) >> sh) & gmask;
+      const u64 gv = (__ballot(cv) >> sh) & gmask;
+      const unsigned gf = (unsigned)(__ballot((nib & 1u) != 0) >> sh) & 1u;
+      const int run = gc == gmask ? LPP : __builtin_ctzll(~gc);
+      if(inb) {
+        if(state == 0) {
+          if(run == 0) { // the cell itself is not diagonal: switch to the gap state it names, no move
+            state = gf ? 2 : 1;
+          }
+          else {
+            if(q < run) {
+              out[at - 1 - q] = 0;
+            }
+            at -= run;
+            i -= run;
+            j -= run;
+          }
+        }
+        else {
+          // the cells that extend are consumed in this state; the first one that does not is consumed too and returns
+          // the walk to H (if it lies in this block; otherwise the next block goes on in this state)
+          int take = run, next = state;
+          if(run < LPP && ((gv >> run) & 1ull)) {
+            take = run + 1;
+            next = 0;
+          }
+          if(q < take) {
+            out[at - 1 - q] = (unsigned char)state; // 1 = I (state E), 2 = D (state F)
+          }
+          at -= take;
+          if(state == 1) {
+            j -= take;
+          }
+          else {
+            i -= take;
+          }
+          state = next;
+        }
+        inb = i > 0 && j > 0 && i - 1 >= i0 && j - 1 >= j0;
+      }
+    }
+    __syncthreads();
+  }
+  // one profile exhausted: the rest is a single gap run
+  if(valid) {
+    const int rest = i + j;
+    const unsigned char op = i == 0 ? 1 : 2;
+    for(int k2 = q; k2 < rest; k2 += LPP) {
+      out[at - 1 - k2] = op;
+    }
+    at -= rest;
+    if(q == 0) {
+      n_ops[pair] = la + lb - at;
+    }
+  }
+}
+
+template <int C, int LPP>
+static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b, i64 first_pair, i64 n, const i64 *tb_off,
+                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, hipStream_t stream) {
+  constexpr int G = 64 / LPP;
+  const unsigned blocks = (unsigned)((n + G - 1) / G);
+  dp_walk_kernel<C, LPP><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+int dp_launch_walk(int cols_per_lane, int lanes_per_pair, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
+                   i64 first_pair, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
+                   hipStream_t stream) {
+  if(n <= 0) {
+    return PM_OK;
+  }
+  // lanes per pair: a lane owns BW / LPP of the block's BW = C * DP_CK_W columns, 1 to 8 of them, inside one lane of the fill kernel
+#define WALK(CC, LL)                                                                                                        \
+  if constexpr((CC * DP_CK_W) % LL == 0 && (CC * DP_CK_W) / LL >= 1 && (CC * DP_CK_W) / LL <= 8 && CC % ((CC * DP_CK_W) / LL) == 0) { \
+    if(lanes_per_pair == LL) {                                                                                              \
+      return launch_walk<CC, LL>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P, stream);           \
+    }                                                                                                                       \
+  }
+  if(cols_per_lane == 16) {
+    WALK(16, 2) WALK(16, 4) WALK(16, 8) WALK(16, 16) WALK(16, 32) WALK(16, 64)
+  }
+  else {
+    WALK(8, 2) WALK(8, 4) WALK(8, 8) WALK(8, 16) WALK(8, 32)
+  }
+#undef WALK
+  return fail(PM_E_INVALID, "dp_launch_walk: lanes per pair not available for this block width");
+}
+
+// the group sizes dp_launch_walk accepts for a fill kernel with `cols_per_lane` columns per lane
+bool dp_walk_lanes_ok(int cols_per_lane, int lanes_per_pair) {
+  const int bw = cols_per_lane * DP_CK_W;
+  if(lanes_per_pair < 2 || lanes_per_pair > 64 || (lanes_per_pair & (lanes_per_pair - 1)) || bw % lanes_per_pair) {
+    return false;
+  }
+  const int c2 = bw / lanes_per_pair;
+  return c2 >= 1 && c2 <= 8 && cols_per_lane % c2 == 0 && !(cols_per_lane == 8 && lanes_per_pair == 64);
+}
+
+} // namespace pm

@@ -64,7 +64,9 @@ def test_varying_lengths_with_indels(oracle_build):
     assert any((p != 0).any() for p in paths)  # some optimal paths carry gaps
 
 
-def test_chunked_workspace_gives_same_results(oracle_build):
+@pytest.mark.parametrize("mode", ["bits", "ckpt"])
+def test_chunked_workspace_gives_same_results(mode, oracle_build, monkeypatch):
+    monkeypatch.setenv("PM_DP_MODE", mode)
     inputs = dp.synth_pairs(78, 30, 2, 600)
     params = dp.make_params(2, 2)
     s1, p1, i1 = run_and_compare(inputs, params)
@@ -76,12 +78,15 @@ def test_chunked_workspace_gives_same_results(oracle_build):
 @pytest.mark.parametrize("waves", ["1", "2", "4", "8"])
 @pytest.mark.parametrize("cols", ["8", "16"])
 @pytest.mark.parametrize("dot4", ["0", "1"])
-def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, oracle_build, monkeypatch):
-    """One wave per pair and the 4- and 8-wave stripe pipelines, 8 and 16 columns per lane, int8 and int16 column scores: all
-    must give the oracle's scores and paths on pairs that span several stripes (B up to 2 600 columns)."""
+@pytest.mark.parametrize("mode", ["bits", "ckpt"])
+def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, mode, oracle_build, monkeypatch):
+    """One wave per pair and the 2-, 4- and 8-wave stripe pipelines, 8 and 16 columns per lane, int8 and int16 column scores,
+    paths from stored decision bits and from checkpoints: all must give the oracle's scores and paths on pairs that span
+    several stripes (B up to 2 600 columns)."""
     monkeypatch.setenv("PM_DP_WAVES", waves)
     monkeypatch.setenv("PM_DP_COLS", cols)
     monkeypatch.setenv("PM_DP_DOT4", dot4)
+    monkeypatch.setenv("PM_DP_MODE", mode)
     rng = np.random.default_rng(int(waves) * 100 + int(cols) + int(dot4))
     la = [700, 64, 1300, 129, 2000, 5]
     lb = [2600, 1025, 1024, 2049, 513, 1100]
@@ -89,6 +94,25 @@ def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, oracle_bu
     inputs = dp.DpInputs(np.concatenate([cols_of(n) for n in la]), np.concatenate([[0], np.cumsum(la)]).astype(np.int64),
                          np.concatenate([cols_of(n) for n in lb]), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
     run_and_compare(inputs, dp.make_params(4, 4))
+
+
+@pytest.mark.parametrize("lanes,cols", [("4", "16"), ("8", "16"), ("16", "16"), ("32", "16"), ("2", "8"), ("4", "8"), ("8", "8"), ("16", "8")])
+def test_checkpoint_walk_with_every_group_size(lanes, cols, oracle_build, monkeypatch):
+    """The checkpoint walk with every group size (lanes per pair) the block width allows, for both column counts of the fill
+    kernel: ragged pairs whose optimal paths carry long gaps, so the walk leaves blocks through their left edge as well as
+    through their top."""
+    monkeypatch.setenv("PM_DP_MODE", "ckpt")
+    monkeypatch.setenv("PM_DP_WALK_LANES", lanes)
+    monkeypatch.setenv("PM_DP_COLS", cols)
+    inputs = dp.synth_pairs(300 + int(lanes), 37, 3, 500, indel_rate=0.03, vary_length=True)
+    run_and_compare(inputs, dp.make_params(3, 3))
+    rng = np.random.default_rng(int(lanes))
+    la = [900, 40, 1, 33, 1200]
+    lb = [60, 1300, 700, 32, 1100]
+    cols_of = lambda n: np.concatenate([rng.integers(0, 3, size=(n, 5)).astype(np.uint8), np.zeros((n, 3), np.uint8)], axis=1)
+    inputs = dp.DpInputs(np.concatenate([cols_of(n) for n in la]), np.concatenate([[0], np.cumsum(la)]).astype(np.int64),
+                         np.concatenate([cols_of(n) for n in lb]), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+    run_and_compare(inputs, dp.make_params(3, 3))
 
 
 @pytest.mark.parametrize("rows,expect_dot4", [(25, True), (26, False), (200, False)])
@@ -176,6 +200,7 @@ def test_random_shapes_random_scoring(seed, oracle_build, monkeypatch):
     oracle's full-matrix aligner."""
     rng = np.random.default_rng(seed)
     monkeypatch.setenv("PM_DP_WAVES", ["1", "4", "8"][seed % 3])
+    monkeypatch.setenv("PM_DP_MODE", ["ckpt", "bits", "ckpt"][seed % 3])
     n = 150
     la = rng.integers(1, 2300, size=n)
     lb = rng.integers(1, 2300, size=n)
