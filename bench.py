@@ -2,17 +2,28 @@
 """bench.py -- throughput of the hot path on N GPUs of one node (one process per GPU, no collective on the
 data path: the work units are independent).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--path dp|translate|both]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config ns|c1|c2|deep] [--scaling weak|strong]
+                    [--path dp|translate|both]
 
-Prints ONE JSON line on rank 0.  `metric`/`value` are BASELINE.json's metric (profile-DP GCUPS, see
-paramugsy_amd/dp.py); the measured numbers of the translate path -- the path the reference actually ships
- -- ride along in the same line under "translate".  Each carries
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts N ranks of itself
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), never touches the GPU, relays rank 0's JSON
+line and exits non-zero if any rank did.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+it is one of the ranks.  A line is printed only when the number of ranks that ran equals --gpus.
+
+Prints ONE JSON line on rank 0.  `metric`/`value` are BASELINE.json's metric (profile-DP GCUPS, see paramugsy_amd/dp.py)
+on --config (default `ns`, the north-star shape at one GPU's share: 12 500 pairs of 8 rows x 4 096 columns, so that
+--gpus 8 under weak scaling is exactly the north-star's 100 k pairs); BASELINE.json configs[1] (`c1`) and the measured
+numbers of the translate path -- the path the reference actually ships -- ride along in the same line under
+"c1" and "translate".  Each carries
   roofline      achieved = algorithmic bytes per launch / average device time of the dominant kernel (HIP events
                 on the launch stream), against the 8 TB/s HBM peak
   cpu_baseline  rank 0, N=1 only: the CPU side timed on this box's host cores on a bounded sample of the same
-                workload (translate: the upstream reference binary oracle/_ref/m_translate when it travelled
-                with the snapshot, kind "reference"; otherwise the oracle, kind "port")
-Inputs are synthetic (seeded, paramugsy_amd/synth.py) and resident in HBM when the timed region starts.
+                workload, single-threaded and as one process per core (translate: the upstream reference binary
+                oracle/_ref/m_translate when it travelled with the snapshot, kind "reference"; DP: the oracle, kind "port")
+Inputs are synthetic (seeded) and resident in HBM when the timed region starts.
+--scaling weak: every rank gets the configuration's per-GPU batch; strong: ONE batch of the configuration's size (times
+--strong-factor) is partitioned over the ranks with paramugsy_amd.shard.partition (BASELINE.json configs[3]/[4] semantics,
+cf. lib/base/pm_job.ml:43-57).
 """
 import argparse
 import json
@@ -27,33 +38,96 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
+# per-GPU DP workloads (BASELINE.json configs); lengths in columns
+DP_CONFIGS = {
+    "c1": {"pairs": 10000, "rows": 2, "len": 1000, "what": "BASELINE.json configs[1]: 10 k synthetic 2-row x 1 kbp profile pairs"},
+    "ns": {"pairs": 12500, "rows": 8, "len": 4096,
+           "what": "north-star shape, one GPU's eighth of 100 k synthetic 8-row x 4 kbp profile pairs"},
+    "c2": {"pairs": 100000, "rows": 4, "len": 0,
+           "what": "stand-in for BASELINE.json configs[2] (nucmer is not in the image): 100 k ragged segment pairs, 4-row profiles, "
+                   "lengths log-normal (median 1 500, sigma 0.6, clipped to [200, 8 000]), seed 20261003"},
+    "deep": {"pairs": 512, "rows": 32, "len": 10000,
+             "what": "BASELINE.json configs[4] per GPU: 512 deep 32-row x 10 kbp profile pairs (int16 column weights)"},
+}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--path", choices=["dp", "translate", "both"], default="both")
+    ap.add_argument("--config", choices=sorted(DP_CONFIGS), default="ns")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--strong-factor", type=int, default=1, help="strong scaling: the fixed batch is this many per-GPU batches")
+    ap.add_argument("--no-c1", action="store_true", help="skip the configs[1] ride-along")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true", help="ranks report their environment and exit (no GPU work)")
     # translate workload (per rank): a Mugsy_profile node with 4+4 genomes of 1 Mbp
     ap.add_argument("--tr-genomes", type=int, default=4)
     ap.add_argument("--tr-genome-len", type=int, default=1000000)
     ap.add_argument("--tr-blocks", type=int, default=2500)
     ap.add_argument("--tr-deltas", type=int, default=16)
     ap.add_argument("--tr-entries", type=int, default=6000)
-    # dp workload (per rank): BASELINE.json configs[1]
-    ap.add_argument("--dp-pairs", type=int, default=10000)
-    ap.add_argument("--dp-rows", type=int, default=2)
-    ap.add_argument("--dp-len", type=int, default=1000)
+    # overrides of the DP configuration
+    ap.add_argument("--dp-pairs", type=int, default=0)
+    ap.add_argument("--dp-rows", type=int, default=0)
+    ap.add_argument("--dp-len", type=int, default=0)
     return ap.parse_args()
 
 
-def dist_setup(n_gpus):
-    """One process per GPU.  Returns (rank, world, torch, dist-or-None)."""
-    import torch
+# ------------------------------------------------------------------ launching N ranks
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_gpus):
+    """Parent of an N-rank run: starts N children of this script before anything touches the GPU, relays rank 0's line."""
+    port = free_port()
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_gpus), "LOCAL_WORLD_SIZE": str(n_gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]  # rank 0's JSON line, nothing a library printed
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        sys.exit(1)
+    for ln in lines:
+        print(ln)
+    sys.exit(0)
+
+
+def dist_setup(args):
+    """One process per GPU.  Returns (rank, world, local, torch, dist-or-None)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: %d ranks are running but --gpus is %d" % (world, args.gpus))
+    if args.dry_launch:
+        if world > 1:
+            import torch.distributed as dist_mod
+            dist_mod.init_process_group("gloo")
+            seen = [None] * world
+            dist_mod.all_gather_object(seen, {"rank": rank, "local_rank": local})
+            dist_mod.destroy_process_group()
+        else:
+            seen = [{"rank": rank, "local_rank": local}]
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": len(seen), "ranks": seen}))
+        sys.exit(0)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libparamugsy_amd has no CPU path")
     torch.cuda.set_device(local)
@@ -61,9 +135,8 @@ def dist_setup(n_gpus):
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl")  # RCCL; used only for the timing barrier and the max-over-ranks
+        dist_mod.init_process_group("nccl")  # RCCL; used only for the timing barrier, the max-over-ranks and the rank census
         dist = dist_mod
-    assert world == n_gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     return rank, world, local, torch, dist
 
 
@@ -90,6 +163,14 @@ def timed_region(torch, dist, fn, steps, warmup):
     return dt
 
 
+def sum_over_ranks(torch, dist, value):
+    if dist is None:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def measured_traffic(kernel_substr, config_key):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/pmc_traffic.json), if the bench
     configuration is the profiled one.  rocprofv3 cannot run inside bench.py; the file is written by
@@ -111,6 +192,15 @@ def measured_traffic(kernel_substr, config_key):
             return int((2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
     return None
 
+
+def host_cores():
+    try:
+        return max(1, min(len(os.sched_getaffinity(0)), 16))  # a one-GPU box's CPU share is 16
+    except Exception:
+        return max(1, min(os.cpu_count() or 1, 16))
+
+
+# ------------------------------------------------------------------ translate path
 
 def bench_translate(args, rank, world, local, torch, dist):
     from paramugsy_amd import synth
@@ -134,6 +224,7 @@ def bench_translate(args, rank, world, local, torch, dist):
     ms_emit = sum(p[3] for p in prof) / len(prof)
     count_bytes, emit_bytes, n_live = job.kernel_bytes()
     units = t.n_units
+    units_all = sum_over_ranks(torch, dist, units)
     # the dominant kernel is whichever of the two unit passes is longer; both read the same tables, the emit
     # pass also writes the entries and offsets
     dom_ms = max(ms_count, ms_emit)
@@ -143,7 +234,7 @@ def bench_translate(args, rank, world, local, torch, dist):
     tr_key = "translate:%d:%d:%d:%d:%d" % (args.tr_genomes, args.tr_genome_len, args.tr_blocks, args.tr_deltas, args.tr_entries)
     out = {
         "metric": "translate work units/s (delta entry x left row x right row; m_translate.cc:625-647)",
-        "value": units * world * args.steps / dt,
+        "value": units_all * args.steps / dt,
         "unit": "units/s",
         "ms_per_step": dt / args.steps * 1e3,
         "dtype": "int32" if bits == 32 else "int64",
@@ -170,6 +261,26 @@ def bench_translate(args, rank, world, local, torch, dist):
             out["cpu_baseline"] = {"value": units / cpu_dt, "unit": "units/s", "cores": 1, "kind": kind,
                                    "sample": "the whole per-rank job through the CLI (parse + translate + write), %d units, %.2f s, rc %d"
                                    % (units, cpu_dt, r.returncode)}
+            # the same binary as one process per host core, each on its own slice of the delta-file list (the reference's
+            # own way to use several cores: one OS process per job, lib/base/queued_task_server.ml:57-66)
+            nproc = min(host_cores(), len(w.delta_paths))
+            if nproc > 1:
+                from paramugsy_amd.shard import partition
+                lists = []
+                for k in range(nproc):
+                    lo, hi = partition(len(w.delta_paths), nproc, k)
+                    lp = os.path.join(tmp, "list_%d.txt" % k)
+                    with open(lp, "w") as f:
+                        f.write("".join(p + "\n" for p in w.delta_paths[lo:hi]))
+                    lists.append(lp)
+                t0 = time.perf_counter()
+                ps = [subprocess.Popen([exe, w.left_dir, w.right_dir, lp, os.path.join(tmp, "cpu_%d.delta" % k)])
+                      for k, lp in enumerate(lists)]
+                rcs = [p.wait() for p in ps]
+                par_dt = time.perf_counter() - t0
+                out["cpu_baseline"]["all_cores"] = {"value": units / par_dt, "unit": "units/s", "cores": nproc, "nproc": nproc,
+                                                    "sample": "the same job as %d processes over slices of the delta-file list, %.2f s, rc %s"
+                                                    % (nproc, par_dt, sorted(set(rcs)))}
             # whole-job time of the drop-in CLI on the same files, PCIe and text I/O included
             cli = os.path.join(ROOT, "bin", "m_translate")
             if os.path.exists(cli):
@@ -186,81 +297,172 @@ def bench_translate(args, rank, world, local, torch, dist):
     return out
 
 
-def bench_dp(args, rank, world, local, torch, dist):
-    """One step = one pass (fill + traceback) over this rank's profile pairs, inputs resident in HBM."""
+# ------------------------------------------------------------------ profile DP
+
+def dp_inputs_for(cfg_name, cfg, rank, world, scaling, strong_factor):
+    """This rank's pairs of the configuration.  weak: the per-GPU batch, seeded by rank.  strong: the contiguous slice
+    shard.partition gives this rank of ONE batch of strong_factor per-GPU batches (every rank generates the same seeded
+    batch description and keeps its slice)."""
     import numpy as np
     from paramugsy_amd import dp as dpm
-    rows, L, n = args.dp_rows, args.dp_len, args.dp_pairs
-    inputs = dpm.synth_pairs_fast(20261003 + rank, n, rows, L)
+    from paramugsy_amd.shard import partition
+    n, rows, L = cfg["pairs"], cfg["rows"], cfg["len"]
+    seed = 20261003
+    if scaling == "strong":
+        n_total = n * strong_factor
+        lo, hi = partition(n_total, world, rank)
+    else:
+        n_total = n
+        lo, hi = 0, n
+        seed += rank
+    if cfg_name == "c1" and scaling == "weak":
+        return dpm.synth_pairs_fast(seed, n, rows, L), n_total  # the generator round 1's numbers were measured with
+    if L > 0:
+        la = np.full(n_total, L, dtype=np.int64)
+        lb = la
+    else:
+        la, lb = dpm.ragged_lengths(seed, n_total)
+    # a slice of a seeded batch: seed the slice by its position so that no rank has to generate the whole batch
+    return dpm.synth_batch(seed * 1000003 + lo, la[lo:hi], lb[lo:hi], rows, rows), n_total
+
+
+def _oracle_leg(payload):
+    """One worker of the all-cores CPU baseline: the oracle on a slice of the sample (runs in a child process)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from paramugsy_amd import dp as dpm
+    ca, oa, cb, ob, sub, go, ge = payload
+    p = dpm.PmDpParams()
+    for k in range(25):
+        p.sub[k] = sub[k]
+    p.gap_open, p.gap_extend = go, ge
+    t0 = time.perf_counter()
+    pyoracle.dp_align(dpm.DpInputs(ca, oa, cb, ob), p)
+    return time.perf_counter() - t0
+
+
+def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, with_cpu):
+    """One step = one pass (fill + path) over this rank's profile pairs, inputs resident in HBM."""
+    import numpy as np
+    from paramugsy_amd import dp as dpm
+    from paramugsy_amd.shard import slice_pairs
+    cfg = dict(DP_CONFIGS[cfg_name])
+    if cfg_name == args.config:
+        cfg["pairs"] = args.dp_pairs or cfg["pairs"]
+        cfg["rows"] = args.dp_rows or cfg["rows"]
+        cfg["len"] = args.dp_len or cfg["len"]
+    rows = cfg["rows"]
+    inputs, n_total = dp_inputs_for(cfg_name, cfg, rank, world, args.scaling, args.strong_factor)
+    n = inputs.n_pairs
     params = dpm.make_params(rows, rows)
     batch = dpm.DpBatch(inputs, params, device=local)
     stream = torch.cuda.current_stream().cuda_stream
-    dt = timed_region(torch, dist, lambda: batch.run(True, stream), args.steps, args.warmup)
+    dt = timed_region(torch, dist, lambda: batch.run(True, stream), steps, warmup)
     info = batch.info()
-    prof = [batch.run_profiled(True, stream) for _ in range(max(3, min(args.steps, 10)))]
+    prof = [batch.run_profiled(True, stream) for _ in range(max(3, min(steps, 10)))]
     ms_fill = sum(p[0] for p in prof) / len(prof)
     ms_tb = sum(p[1] for p in prof) / len(prof)
     cells = info["cells"]
-    # algorithmic bytes per launch (DESIGN.md 6): 0.5 byte of decisions per cell + the packed columns read
-    # (B once, A once per stripe) + the scores; the skew padding of the decision buffer is not counted
-    alg_bytes = cells // 2 + info["input_bytes"] + n * 4
-    # int32 VALU peak: every non-packed int32 VALU instruction measured at 4 cycles per wave64 instruction per
-    # SIMD (tools/ubench/valu_rates.hip, profiles/r01_valu_rates.txt) -> 16 lanes/clk x 4 SIMDs x 256 CUs x 2.4 GHz
-    valu_peak = 256 * 4 * 16 * 2.4e9
+    cells_all = sum_over_ranks(torch, dist, cells)
     variant = batch.variant()
-    ops_per_cell = variant["valu_ops_per_cell"]  # csrc/dp_kernels.hip: column score 2 or 3, E 3, F 3, H + flags 5, H - open 1
+    # algorithmic bytes per pass of the fill kernel (DESIGN.md 6): what it must write for the path (checkpoint mode: the
+    # column and row checkpoints; bits mode: 0.5 byte of decisions per cell) + the packed columns it reads (B once, A once
+    # per stripe) + the scores
+    alg_bytes = info["traceback_bytes"] + info["input_bytes"] + n * 4
+    # int32 VALU peak: the half-rate class (v_max_i32, v_dot*, v_max3, v_alignbit...) issues at 4 cycles per wave64
+    # instruction per SIMD (tools/ubench/valu_rates2.hip, profiles/r02_valu_rates2.txt) -> 16 lanes/clk x 4 SIMDs x 256 CUs x 2.4 GHz
+    valu_peak = 256 * 4 * 16 * 2.4e9
+    ops_per_cell = variant["valu_ops_per_cell"]
+    shape = "%d-row x %d-column" % (rows, cfg["len"]) if cfg["len"] else "%d-row, ragged (%d..%d columns)" % (
+        rows, int(np.diff(inputs.off_a).min()) if n else 0, int(np.diff(inputs.off_a).max()) if n else 0)
     out = {
         "metric": "profile-DP GCUPS (global affine-gap profile x profile alignment, scores + traceback)",
-        "value": cells * world * args.steps / dt / 1e9,
+        "value": cells_all * steps / dt / 1e9,
         "unit": "GCUPS",
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": dt / steps * 1e3,
         "dtype": "int32",
-        "config": {"workload": "%d synthetic %d-row x %d-column profile pairs per rank, int32 affine-gap scores, scores + full traceback"
-                   % (n, rows, L), "pairs_per_rank": n, "rows": rows, "columns": L, "cells_per_step_per_rank": cells,
+        "config": {"workload": "%s: %d synthetic %s profile pairs on this rank (%s scaling, %d in the whole job), int32 affine-gap scores, "
+                               "scores + full traceback" % (cfg["what"], n, shape, args.scaling, n_total if args.scaling == "strong" else n * world),
+                   "name": cfg_name, "pairs_per_rank": n, "rows": rows, "columns": cfg["len"], "cells_per_step_per_rank": cells,
                    "chunks": info["chunks"], "kernel_variant": variant,
                    "reference_counterpart": "none: the reference has no DP (SURVEY.md 0); specification and oracle are this repo's own"},
-        "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_traceback_kernel": ms_tb},
+        "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_walk_kernel" if variant.get("checkpoints") else "dp_traceback_kernel": ms_tb},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": measured_traffic("dp_fill_kernel", "dp:%d:%d:%d" % (n, rows, L)), "kernel": "dp_fill_kernel",
+                     "traffic": measured_traffic("dp_fill_kernel", "dp:%s:%d:%d:%d" % (cfg_name, n, rows, cfg["len"])),
+                     "kernel": "dp_fill_kernel",
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "valu": {"ops_per_cell": ops_per_cell, "achieved_Tops": cells * ops_per_cell / (ms_fill * 1e-3) / 1e12,
-                              "peak_Tops": valu_peak / 1e12, "frac": cells * ops_per_cell / (ms_fill * 1e-3) / valu_peak},
+                              "peak_Tops": valu_peak / 1e12, "frac": cells * ops_per_cell / (ms_fill * 1e-3) / valu_peak,
+                              "note": "useful cell instructions only (per-step overhead, wavefront fill/drain and column padding "
+                                      "excluded) against the half-rate VALU issue limit; the issue-slot utilisation is higher"},
                      "note": "max-plus recurrence: the fill kernel is bound by int32 VALU issue, not by HBM; the HBM fraction is reported as measured"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if with_cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
         # cpu_baseline leg: the oracle's scalar full-matrix aligner on a bounded sample of the same batch
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle
-        k = max(1, min(n, int(2.0e9 // max(1, L * L))))  # about 2e9 cells
-        sample = dpm.DpInputs(inputs.cols_a[:k * L], inputs.off_a[:k + 1], inputs.cols_b[:k * L], inputs.off_b[:k + 1])
+        la = np.diff(inputs.off_a)
+        lb = np.diff(inputs.off_b)
+        cum = np.cumsum(la * lb)
+        k = int(max(1, min(n, np.searchsorted(cum, 2.0e9) + 1)))  # about 2e9 cells: 10-15 s on one core
+        sample = slice_pairs(inputs, 0, k)
         t0 = time.perf_counter()
         o_scores, o_paths = pyoracle.dp_align(sample, params)
         cpu_dt = time.perf_counter() - t0
         scores, ops, n_ops = batch.fetch()
         same = bool(np.array_equal(scores[:k], o_scores)) and all(
             np.array_equal(p, q) for p, q in zip(batch.paths(ops, n_ops)[:k], o_paths))
-        out["cpu_baseline"] = {"value": k * L * L / cpu_dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
+        sample_cells = int(cum[k - 1])
+        out["cpu_baseline"] = {"value": sample_cells / cpu_dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
                                "sample": "first %d pairs of the same batch through oracle/dp_oracle.c (scalar C, scores + paths), %.1f s; "
                                          "GPU results identical on the sample: %s" % (k, cpu_dt, same)}
+        nproc = host_cores()
+        if nproc > 1:
+            import multiprocessing as mp
+            from paramugsy_amd.shard import partition
+            kk = int(max(nproc, min(n, np.searchsorted(cum, 1.0e9 * nproc) + 1)))  # about 1e9 cells per core
+            payloads = []
+            for w_ in range(nproc):
+                lo, hi = partition(kk, nproc, w_)
+                sl = slice_pairs(inputs, lo, hi)
+                payloads.append((np.ascontiguousarray(sl.cols_a), sl.off_a, np.ascontiguousarray(sl.cols_b), sl.off_b,
+                                 list(params.sub), params.gap_open, params.gap_extend))
+            with mp.get_context("spawn").Pool(nproc) as pool:
+                t0 = time.perf_counter()
+                pool.map(_oracle_leg, payloads)
+                par_dt = time.perf_counter() - t0
+            out["cpu_baseline"]["all_cores"] = {"value": int(cum[kk - 1]) / par_dt / 1e9, "unit": "GCUPS", "cores": nproc, "nproc": nproc,
+                                                "sample": "first %d pairs as %d processes (one per host core), %.1f s wall incl. process start"
+                                                % (kk, nproc, par_dt)}
     batch.close()
     return out
 
 
 def main():
     args = parse_args()
-    rank, world, local, torch, dist = dist_setup(args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)  # does not return
+    rank, world, local, torch, dist = dist_setup(args)
+    ran = int(round(sum_over_ranks(torch, dist, 1)))
+    if ran != args.gpus:
+        raise SystemExit("bench.py: %d ranks ran, --gpus is %d: refusing to print a line" % (ran, args.gpus))
     result = {}
     tr = None
     if args.path in ("translate", "both"):
         tr = bench_translate(args, rank, world, local, torch, dist)
     dp = None
+    c1 = None
     if args.path in ("dp", "both"):
-        dp = bench_dp(args, rank, world, local, torch, dist)
+        dp = bench_dp(args, args.config, rank, world, local, torch, dist, args.steps, args.warmup, True)
+        if args.config != "c1" and not args.no_c1 and args.scaling == "weak":
+            c1 = bench_dp(args, "c1", rank, world, local, torch, dist, max(args.steps, 20), args.warmup, False)
     main_part = dp if dp is not None else tr
     result.update(main_part)
-    result.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+    result.update({"n_gpus": ran, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": args.scaling,
                    "vs_baseline": None, "data": "synthetic"})
+    if c1 is not None:
+        result["c1"] = c1
     if dp is not None and tr is not None:
         result["translate"] = tr
     if rank == 0:

@@ -189,8 +189,10 @@ int pm_untranslate(const char *const *profile_dirs, int n_dirs, const char *in_m
  * A profile is a run of 8-byte columns {nA, nC, nG, nT, nGap, 0, 0, 0} (how many rows hold each symbol).
  * Pair k aligns columns [off_a[k], off_a[k+1]) of cols_a with columns [off_b[k], off_b[k+1]) of cols_b,
  * globally, with affine gaps, int32 scores; recurrence and tie-breaking: oracle/dp_oracle.h.
- * Limits: |sub| <= 127, gap penalties >= 0 with gap_open + gap_extend <= 32767, profile length <= 2^24 columns,
- * (La + Lb) * gap_extend < 2^28, scores within +-2^28. */
+ * Bytes 5-7 of a column are not scored (byte 5 is where pm_dp_pack_maf counts symbols that are neither ACGT nor a gap).
+ * Limits, all enforced by pm_dp_batch_create (PM_E_INVALID): |sub| <= 127, gap penalties >= 0 with gap_open + gap_extend <= 32767,
+ * profile length <= 2^24 columns, (largest row total of a column of B) x max|sub| <= 32767, and scores within +-2^28:
+ * rows(A) x rows(B) x max|sub| x min(La, Lb) + (La + Lb) x gap_extend + 2 x gap_open < 2^28 for every pair. */
 typedef struct pm_dp_params {
   int32_t sub[25]; /* sub[a*5+b], symbols A, C, G, T, gap */
   int32_t gap_open;
@@ -203,7 +205,7 @@ typedef struct pm_dp_batch pm_dp_batch_t; /* opaque; owns device memory */
  * processed in consecutive chunks that fit it. */
 int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
                        const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out);
-/* One pass over every pair: fill (scores + 4 decision bits per cell) and, when traceback != 0, the path walk.
+/* One pass over every pair: fill (scores, and what the path walk needs) and, when traceback != 0, the path walk.
  * Asynchronous on hip_stream. */
 int pm_dp_batch_run(pm_dp_batch_t *batch, int traceback, void *hip_stream);
 /* Same, timed with HIP events on the stream (waits): device milliseconds of the fill and traceback kernels. */
@@ -212,9 +214,15 @@ int pm_dp_batch_run_profiled(pm_dp_batch_t *batch, int traceback, void *hip_stre
  * the LAST n_ops[k] bytes of that slot, first op first (0 = M, 1 = I: column of B against a gap, 2 = D). */
 int pm_dp_batch_fetch(pm_dp_batch_t *batch, int32_t *scores, uint8_t *ops, int32_t *n_ops);
 int pm_dp_batch_info(pm_dp_batch_t *batch, int64_t *cells, int64_t *traceback_bytes_per_run, int64_t *input_bytes, int32_t *n_chunks);
+/* first_pair[c] = first pair of chunk c, first_pair[n_chunks] = n_pairs (at most `capacity` values are written). */
+int pm_dp_batch_chunks(pm_dp_batch_t *batch, int64_t *first_pair, int32_t capacity);
 /* Which kernel variant the batch runs: columns of B per lane (8/16), whether the int8 dot4 path applies, and the VALU
  * instructions per DP cell of that variant (for roofline accounting). */
 int pm_dp_batch_variant(pm_dp_batch_t *batch, int32_t *cols_per_lane, int32_t *dot4, int32_t *valu_ops_per_cell);
+/* How the batch gets its paths: checkpoints != 0 -> the fill kernel computes scores only and leaves row/column checkpoints,
+ * and the walk re-runs the recurrence inside the block_rows x block_columns blocks the path crosses (the default);
+ * checkpoints == 0 -> the fill kernel stores 4 decision bits per cell (environment PM_DP_MODE=bits).  Same results. */
+int pm_dp_batch_path_mode(pm_dp_batch_t *batch, int32_t *checkpoints, int32_t *block_rows, int32_t *block_columns);
 void pm_dp_batch_destroy(pm_dp_batch_t *batch);
 
 #ifdef __cplusplus

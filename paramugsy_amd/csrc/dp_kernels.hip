@@ -644,6 +644,24 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
       pm_dp_batch_destroy(h);
       return fail(PM_E_INVALID, "pm_dp_batch_create: (rows of a column of B) x max|sub| exceeds 32767");
     }
+    // every score the kernel carries must stay within +-2^28 (the skewed H~ = H + (i + j) * gap_extend as well, and the
+    // decision bits are signs of 32-bit differences against the -2^29 sentinel): bound the largest magnitude any cell can
+    // reach from the column statistics and refuse the batch otherwise
+    {
+      const int64_t max_colsum_a = st[1];
+      int64_t worst = 0;
+      for(int64_t k = 0; k < n_pairs; ++k) {
+        const int64_t la = off_a[k + 1] - off_a[k], lb = off_b[k + 1] - off_b[k];
+        const int64_t m = max_colsum_a * max_colsum_b * max_sub_all * std::min(la, lb) + (la + lb) * (int64_t)params->gap_extend +
+                          2 * (int64_t)params->gap_open;
+        worst = std::max(worst, m);
+      }
+      if(worst >= ((int64_t)1 << 28)) {
+        pm_dp_batch_destroy(h);
+        return fail(PM_E_INVALID, "pm_dp_batch_create: scores could leave +-2^28 (rows(A) x rows(B) x max|sub| x min(La, Lb) + (La + Lb) x gap_extend "
+                                  "+ 2 x gap_open too large)");
+      }
+    }
     h->dot4 = max_a <= 127 && max_colsum_b * max_sub_acgt <= 127;
     if(const char *e = getenv("PM_DP_DOT4")) {
       h->dot4 = h->dot4 && atoi(e) != 0;
@@ -956,6 +974,33 @@ int pm_dp_batch_variant(pm_dp_batch_t *h, int32_t *cols_per_lane, int32_t *dot4,
     // per cell: column score (dot4 + dot2 = 2, or 3 x dot2), E 3, F 3, H + two decision bits 5, H - open 1;
     // without the decision bits (checkpoint mode): score 2 or 3, E 1, F 1, H 1, H - open 1
     *valu_ops_per_cell = h->ckpt ? (h->dot4 ? 2 : 3) + 4 : (h->dot4 ? 2 : 3) + 3 + 3 + 5 + 1;
+  }
+  return PM_OK;
+}
+
+int pm_dp_batch_chunks(pm_dp_batch_t *h, int64_t *first_pair, int32_t capacity) {
+  if(!h || (!first_pair && capacity > 0)) {
+    return fail(PM_E_INVALID, "pm_dp_batch_chunks: null argument");
+  }
+  const int32_t nc = (int32_t)h->chunk_tb.size();
+  for(int32_t c = 0; c <= nc && c < capacity; ++c) {
+    first_pair[c] = h->chunk_first[c];
+  }
+  return PM_OK;
+}
+
+int pm_dp_batch_path_mode(pm_dp_batch_t *h, int32_t *checkpoints, int32_t *block_rows, int32_t *block_columns) {
+  if(!h) {
+    return fail(PM_E_INVALID, "pm_dp_batch_path_mode: null batch");
+  }
+  if(checkpoints) {
+    *checkpoints = h->ckpt ? 1 : 0;
+  }
+  if(block_rows) {
+    *block_rows = h->ckpt ? DP_CK_R : 0;
+  }
+  if(block_columns) {
+    *block_columns = h->ckpt ? DP_CK_W * h->cols_per_lane : 0;
   }
   return PM_OK;
 }

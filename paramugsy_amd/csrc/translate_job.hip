@@ -783,7 +783,17 @@ int pm_job_run_profiled(pm_job_t *j, void *hip_stream, float *ms_filter, float *
     return rc;
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  hipEvent_t ev[5];
+  struct Events { // destroyed on every way out, failed launches included
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~Events() {
+      for(int k = 0; k < 5; ++k) {
+        if(ev[k]) {
+          (void)hipEventDestroy(ev[k]);
+        }
+      }
+    }
+  } events;
+  hipEvent_t *ev = events.ev;
   for(int k = 0; k < 5; ++k) {
     PM_HIP(hipEventCreate(&ev[k]));
   }
@@ -792,9 +802,6 @@ int pm_job_run_profiled(pm_job_t *j, void *hip_stream, float *ms_filter, float *
   float ms[4] = {0, 0, 0, 0};
   for(int k = 0; k < 4; ++k) {
     PM_HIP(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]));
-  }
-  for(int k = 0; k < 5; ++k) {
-    (void)hipEventDestroy(ev[k]);
   }
   float *outp[4] = {ms_filter, ms_count, ms_scan, ms_emit};
   for(int k = 0; k < 4; ++k) {

@@ -43,14 +43,25 @@ def make_params(rows_a: int, rows_b: int, match: int = 5, mismatch: int = -4, ba
 
 
 def pack_profile(rows: Sequence[bytes]) -> np.ndarray:
-    """Gapped row texts of one alignment block -> uint8 [columns, 8] packed columns {nA,nC,nG,nT,nGap,0,0,0}."""
+    """Gapped row texts of one alignment block -> uint8 [columns, 8] packed columns {nA,nC,nG,nT,nGap,nOther,0,0}.
+
+    Case-insensitive.  A symbol that is neither ACGT nor '-' (N, IUPAC codes) is counted in byte 5, which the DP does not
+    score: such a row is neutral in that column, and every column's six counts sum to the number of rows.  Host-side
+    helper for tests; the product's entry point for MAF blocks is pm_dp_pack_maf."""
+    if len(rows) > 255:
+        raise ValueError("a packed column counts rows in a byte: at most 255 rows, got %d" % len(rows))
     n = len(rows[0])
     out = np.zeros((n, 8), dtype=np.uint8)
     for r in rows:
         a = np.frombuffer(r.upper(), dtype=np.uint8)
-        assert len(a) == n
+        if len(a) != n:
+            raise ValueError("rows of one block must have the same number of columns")
+        known = np.zeros(n, dtype=bool)
         for k, ch in enumerate(SYMBOLS):
-            out[:, k] += (a == ch).astype(np.uint8)
+            hit = a == ch
+            out[:, k] += hit.astype(np.uint8)
+            known |= hit
+        out[:, 5] += (~known).astype(np.uint8)
     return out
 
 
@@ -64,6 +75,8 @@ def _lib():
         l.pm_dp_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_dp_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         l.pm_dp_batch_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        l.pm_dp_batch_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        l.pm_dp_batch_path_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.pm_dp_batch_destroy.argtypes = [C.c_void_p]
         l.pm_dp_batch_destroy.restype = None
         l._dp_bound = True
@@ -115,10 +128,20 @@ class DpBatch:
         capi.check(_lib().pm_dp_batch_info(self._h, C.byref(cells), C.byref(tb), C.byref(inp), C.byref(chunks)))
         return {"cells": cells.value, "traceback_bytes": tb.value, "input_bytes": inp.value, "chunks": chunks.value}
 
+    def chunks(self) -> np.ndarray:
+        """First pair of every chunk, plus n_pairs."""
+        n = self.info()["chunks"]
+        first = np.zeros(n + 1, dtype=np.int64)
+        capi.check(_lib().pm_dp_batch_chunks(self._h, first.ctypes.data, n + 1))
+        return first
+
     def variant(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         capi.check(_lib().pm_dp_batch_variant(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"cols_per_lane": a.value, "dot4": bool(b.value), "valu_ops_per_cell": c.value}
+        ck, br, bc = C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(_lib().pm_dp_batch_path_mode(self._h, C.byref(ck), C.byref(br), C.byref(bc)))
+        return {"cols_per_lane": a.value, "dot4": bool(b.value), "valu_ops_per_cell": c.value, "checkpoints": bool(ck.value),
+                "block_rows": br.value, "block_columns": bc.value}
 
     def fetch(self, with_paths: bool = True):
         n = len(self._oa) - 1
@@ -229,3 +252,66 @@ def synth_pairs_fast(seed: int, n_pairs: int, rows: int, length: int, sub_rate: 
 
     off = (np.arange(n_pairs + 1, dtype=np.int64) * L)
     return DpInputs(counts(ca), off, counts(cb), off.copy())
+
+
+def synth_batch(seed: int, la, lb, rows_a: int, rows_b: int, sub_rate: float = 0.08, row_noise: float = 0.1,
+                gap_col_rate: float = 0.05, shift_rate: float = 0.3) -> DpInputs:
+    """Vectorised generator for big and for ragged batches (PCG64, seeded): pair k has la[k] x lb[k] columns.
+
+    A's consensus is uniform ACGT.  B's consensus is A's resampled to lb[k] columns (column j of B copies column
+    floor(j * la / lb) of A, so unequal lengths put evenly spread indels on the optimal path), cyclically shifted by 1-5
+    columns for a fraction `shift_rate` of the pairs, with substitutions at `sub_rate`.  Every row copies its consensus with
+    probability 1 - row_noise (else a random base) and is a gap with probability gap_col_rate."""
+    rng = np.random.default_rng(seed)
+    la = np.asarray(la, dtype=np.int64)
+    lb = np.asarray(lb, dtype=np.int64)
+    n = len(la)
+    off_a = np.concatenate([[0], np.cumsum(la)]).astype(np.int64)
+    off_b = np.concatenate([[0], np.cumsum(lb)]).astype(np.int64)
+    ta, tb = int(off_a[-1]), int(off_b[-1])
+    cons_a = rng.integers(0, 4, size=ta, dtype=np.uint8)
+    it = np.int32 if max(ta, tb) < (1 << 30) else np.int64  # index arithmetic in 32 bits when it fits
+    pid = np.repeat(np.arange(n, dtype=np.int32), lb)
+    pos = np.arange(tb, dtype=it) - off_b[:-1].astype(it)[pid]
+    shift = np.where(rng.random(n) < shift_rate, rng.integers(1, 6, size=n), 0).astype(it)
+    lbp = np.maximum(lb, 1).astype(it)[pid]
+    pos += shift[pid]
+    pos -= np.where(pos >= lbp, lbp, it(0))  # cyclic shift by < 6 columns (profiles shorter than that wrap twice at most)
+    pos -= np.where(pos >= lbp, lbp, it(0))
+    pos = np.minimum(pos, lbp - 1)
+    if np.array_equal(la, lb):
+        src = off_a[:-1].astype(it)[pid] + pos
+    else:
+        lap = la.astype(np.int64)[pid]
+        src = off_a[:-1][pid] + np.minimum((pos.astype(np.int64) * lap) // lbp, np.maximum(lap - 1, 0))
+    if ta > 0:
+        cons_b = cons_a[np.minimum(src, ta - 1)]
+    else:
+        cons_b = rng.integers(0, 4, size=tb, dtype=np.uint8)
+    del pid, pos, src, lbp
+    subs = rng.integers(0, 65536, size=tb, dtype=np.uint16) < int(sub_rate * 65536)
+    cons_b[subs] = rng.integers(0, 4, size=int(subs.sum()), dtype=np.uint8)
+    del subs
+
+    t_noise, t_gap = np.uint32(int(row_noise * 65536)), np.uint32(int(gap_col_rate * 16384))
+
+    def counts(cons: np.ndarray, rows: int) -> np.ndarray:
+        acc = np.zeros(len(cons), dtype=np.uint64)
+        for _r in range(rows):
+            x = rng.integers(0, 1 << 32, size=len(cons), dtype=np.uint32)  # bits 0-15 noise, 16-17 a base, 18-31 gap
+            r = np.where((x & np.uint32(0xffff)) < t_noise, ((x >> np.uint32(16)) & np.uint32(3)).astype(np.uint8), cons)
+            r = np.where((x >> np.uint32(18)) < t_gap, np.uint8(4), r)
+            acc += np.left_shift(np.uint64(1), r.astype(np.uint64) << np.uint64(3))
+        return acc.view(np.uint8).reshape(len(cons), 8)
+
+    return DpInputs(counts(cons_a, rows_a), off_a, counts(cons_b, rows_b), off_b)
+
+
+def ragged_lengths(seed: int, n_pairs: int, median: float = 1500.0, sigma: float = 0.6, lo: int = 200, hi: int = 8000,
+                   jitter: float = 0.05):
+    """Segment lengths for the stand-in of BASELINE.json configs[2] (nucmer is not in the image, so there are no real
+    anchors): la log-normal (median, sigma) clipped to [lo, hi]; lb = la * (1 + N(0, jitter)), clipped likewise."""
+    rng = np.random.default_rng(seed)
+    la = np.clip(np.exp(rng.normal(np.log(median), sigma, size=n_pairs)), lo, hi).astype(np.int64)
+    lb = np.clip(la * (1.0 + rng.normal(0.0, jitter, size=n_pairs)), lo, hi).astype(np.int64)
+    return la, lb

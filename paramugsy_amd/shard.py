@@ -61,13 +61,59 @@ def merge_delta_outputs(parts: Sequence[bytes]) -> bytes:
     return b"".join(out)
 
 
+def _comm_device(dist):
+    """Tensors of the host-side gather live where the process group can move them: the GPU for RCCL, host memory for gloo."""
+    import torch
+    try:
+        if dist.get_backend() == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+    except Exception:
+        pass
+    return torch.device("cpu")
+
+
+def _all_ok(ok: bool, rank: int, world: int, dist, what: str, err: Optional[BaseException]) -> None:
+    """Every rank learns whether every rank's compute succeeded; if one failed, all raise (none is left waiting in a gather)."""
+    import torch
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_comm_device(dist))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if err is not None:
+            raise RuntimeError("%s failed on rank %d: %s" % (what, rank, err)) from err
+        raise RuntimeError("%s failed on another rank" % what)
+
+
+def gather_bytes(mine: bytes, rank: int, world: int, dist) -> Optional[List[bytes]]:
+    """Rank-ordered list of every rank's byte string on rank 0 (None elsewhere), as flat uint8 tensors: sizes first, then one
+    point-to-point transfer per rank; nothing is pickled."""
+    import numpy as np
+    import torch
+    dev = _comm_device(dist)
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    sizes[rank] = len(mine)
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
+    sizes = [int(x) for x in sizes.tolist()]
+    if rank != 0:
+        if len(mine) > 0:
+            dist.send(torch.from_numpy(np.frombuffer(mine, dtype=np.uint8).copy()).to(dev), dst=0)
+        return None
+    parts = [mine]
+    for r in range(1, world):
+        buf = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
+        if sizes[r] > 0:
+            dist.recv(buf, src=r)
+        parts.append(buf.cpu().numpy().tobytes())
+    return parts
+
+
 def translate_sharded(left_dir: str, right_dir: str, delta_paths: Sequence[str], out_path: str, rank: int, world: int,
                       dist=None, device: int = 0,
                       translate_fn: Optional[Callable[[str, str, Sequence[str], str], None]] = None) -> None:
     """Every rank translates its slice of the delta-file list; rank 0 writes the merged output.
 
     `dist` is torch.distributed (already initialised; RCCL on GPUs, gloo in the CPU tests) and is used only for
-    the host-side gather.  `translate_fn(left_dir, right_dir, paths, out_path)` defaults to the GPU path."""
+    the host-side gather.  `translate_fn(left_dir, right_dir, paths, out_path)` defaults to the GPU path.  If the
+    translation fails on any rank, every rank raises."""
     if translate_fn is None:
         from .translate import translate
 
@@ -76,18 +122,22 @@ def translate_sharded(left_dir: str, right_dir: str, delta_paths: Sequence[str],
     lo, hi = partition(len(delta_paths), world, rank)
     fd, tmp = tempfile.mkstemp(prefix="pm_shard_%d_" % rank, suffix=".delta")
     os.close(fd)
+    mine, err = b"", None
     try:
         translate_fn(left_dir, right_dir, list(delta_paths[lo:hi]), tmp)
         with open(tmp, "rb") as f:
             mine = f.read()
+    except Exception as e:  # noqa: BLE001 -- reported to every rank below
+        err = e
     finally:
         os.unlink(tmp)
     if world == 1 or dist is None:
+        if err is not None:
+            raise err
         parts = [mine]
     else:
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(mine, gathered, dst=0)
-        parts = gathered
+        _all_ok(err is None, rank, world, dist, "translate", err)
+        parts = gather_bytes(mine, rank, world, dist)
     if rank == 0:
         # the file header names the directories, which are the same for every shard; the merged file is
         # what one process over the whole list prints
@@ -96,15 +146,27 @@ def translate_sharded(left_dir: str, right_dir: str, delta_paths: Sequence[str],
 
 
 def gather_pair_results(scores, paths, rank: int, world: int, dist=None):
-    """DP: rank-ordered concatenation of per-shard scores and paths on rank 0 (None elsewhere)."""
+    """DP: rank-ordered concatenation of per-shard scores and paths on rank 0 (None elsewhere).  Three flat arrays travel per
+    rank (scores int32, path lengths int32, all ops uint8 back to back); the per-pair views are rebuilt on rank 0."""
     if world == 1 or dist is None:
         return scores, paths
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object((scores, paths), gathered, dst=0)
+    import numpy as np
+    scores = np.ascontiguousarray(scores, dtype=np.int32)
+    n_ops = np.array([len(p) for p in paths], dtype=np.int32)
+    flat = np.concatenate([np.asarray(p, dtype=np.uint8) for p in paths]) if len(paths) else np.zeros(0, dtype=np.uint8)
+    g_scores = gather_bytes(scores.tobytes(), rank, world, dist)
+    g_nops = gather_bytes(n_ops.tobytes(), rank, world, dist)
+    g_ops = gather_bytes(flat.tobytes(), rank, world, dist)
     if rank != 0:
         return None, None
-    import numpy as np
-    return np.concatenate([g[0] for g in gathered]), [p for g in gathered for p in g[1]]
+    all_scores = np.concatenate([np.frombuffer(b, dtype=np.int32) for b in g_scores])
+    all_paths = []
+    for nb, ob in zip(g_nops, g_ops):
+        lens = np.frombuffer(nb, dtype=np.int32)
+        ops = np.frombuffer(ob, dtype=np.uint8)
+        ends = np.cumsum(lens)
+        all_paths += [ops[e - l:e] for l, e in zip(lens, ends)]
+    return all_scores, all_paths
 
 
 def slice_pairs(inputs, lo: int, hi: int):
@@ -120,18 +182,28 @@ def slice_pairs(inputs, lo: int, hi: int):
 def align_sharded(inputs, params, rank: int, world: int, dist=None, device: int = 0, align_fn=None):
     """DP over a static pair partition: rank r aligns the contiguous slice partition(n_pairs, world, r) on its GPU,
     rank 0 receives every shard's scores and paths in rank order (host-side gather, no data-path collective).
-    align_fn(sub_inputs, params) -> (scores, paths) replaces the HIP path in the CPU tests (the oracle)."""
+    align_fn(sub_inputs, params) -> (scores, paths) replaces the HIP path in the CPU tests (the oracle).  If the alignment
+    fails on any rank, every rank raises."""
     lo, hi = partition(inputs.n_pairs, world, rank)
     sub = slice_pairs(inputs, lo, hi)
-    if align_fn is not None:
-        scores, paths = align_fn(sub, params)
-    else:
-        from .dp import DpBatch
-        batch = DpBatch(sub, params, device=device)
-        try:
-            batch.run(traceback=True)
-            scores, ops, n_ops = batch.fetch()
-            paths = batch.paths(ops, n_ops)
-        finally:
-            batch.close()
+    scores, paths, err = None, None, None
+    try:
+        if align_fn is not None:
+            scores, paths = align_fn(sub, params)
+        else:
+            from .dp import DpBatch
+            batch = DpBatch(sub, params, device=device)
+            try:
+                batch.run(traceback=True)
+                scores, ops, n_ops = batch.fetch()
+                paths = batch.paths(ops, n_ops)
+            finally:
+                batch.close()
+    except Exception as e:  # noqa: BLE001 -- reported to every rank below
+        err = e
+    if world == 1 or dist is None:
+        if err is not None:
+            raise err
+        return scores, paths
+    _all_ok(err is None, rank, world, dist, "align", err)
     return gather_pair_results(scores, paths, rank, world, dist)

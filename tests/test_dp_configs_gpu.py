@@ -1,0 +1,101 @@
+"""BASELINE.json's DP configurations at full shape on the GPU, under the oracle (oracle/dp_oracle.c -- this repo's own
+specification: the reference has no DP).  The batches are too big for the scalar oracle as a whole, so every
+test checks the scores of a SAMPLE of pairs against the oracle's scorer and re-scores the sampled paths under the
+specification (a path that spans the pair and re-scores to the optimum is an optimal alignment); the sample always holds the
+first and the last pair of several chunks of the traceback workspace."""
+import numpy as np
+import pytest
+
+from paramugsy_amd import dp
+from paramugsy_amd.shard import slice_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def check_sample(inputs, params, scores, paths, sample, full_paths_for=()):
+    import pyoracle
+    sample = sorted(set(int(k) for k in sample))
+    for k in sample:
+        one = slice_pairs(inputs, k, k + 1)
+        assert scores[k] == pyoracle.dp_scores(one, params)[0], "score of pair %d" % k
+        rc, s = pyoracle.dp_score_of_path(inputs, params, k, paths[k])
+        assert rc == 0 and s == scores[k], "path of pair %d" % k
+    for k in full_paths_for:  # the oracle's own path, op for op
+        one = slice_pairs(inputs, int(k), int(k) + 1)
+        o_scores, o_paths = pyoracle.dp_align(one, params)
+        assert o_scores[0] == scores[k] and np.array_equal(o_paths[0], paths[k]), "oracle path of pair %d" % k
+
+
+def test_north_star_shape_one_gpu_share_default_budget(oracle_build):
+    """12 500 pairs of 8 rows x 4 096 columns (one GPU's eighth of the north-star's 100 k) at the DEFAULT traceback budget, so
+    that several chunks of the workspace really run."""
+    n, rows, L = 12500, 8, 4096
+    inputs = dp.synth_batch(20261003, np.full(n, L), np.full(n, L), rows, rows)
+    params = dp.make_params(rows, rows)
+    batch = dp.DpBatch(inputs, params)
+    chunks = batch.chunks()
+    assert len(chunks) - 1 >= 3, "the default budget must split this batch into several chunks"
+    batch.run(traceback=True)
+    scores, ops, n_ops = batch.fetch()
+    paths = batch.paths(ops, n_ops)
+    sample = []
+    for c in range(len(chunks) - 1):
+        sample += [chunks[c], chunks[c + 1] - 1]
+    sample += list(np.random.default_rng(1).integers(0, n, size=6))
+    check_sample(inputs, params, scores, paths, sample, full_paths_for=[chunks[1] - 1, chunks[1]])
+    assert all(len(p) >= L for p in paths[::97])
+    # score-only pass: same scores
+    batch.run(traceback=False)
+    s2, _, _ = batch.fetch(with_paths=False)
+    assert np.array_equal(s2, scores)
+    batch.close()
+
+
+@pytest.mark.parametrize("n_pairs", [64, 128, 512])
+def test_deep_profiles_32_rows_10k_columns(n_pairs, oracle_build):
+    """BASELINE.json configs[4]'s shape (32 rows x 10 kbp, int16 column weights) at 64 / 128 / 512 pairs: the launches that take
+    the 8-, 4- and 2-wave stripe pipelines.  fetch() fails loudly if a stripe ever timed out waiting for its neighbour."""
+    rows, L = 32, 10000
+    inputs = dp.synth_batch(77 + n_pairs, np.full(n_pairs, L), np.full(n_pairs, L), rows, rows)
+    params = dp.make_params(rows, rows)
+    batch = dp.DpBatch(inputs, params)
+    assert not batch.variant()["dot4"]
+    batch.run(traceback=True)
+    scores, ops, n_ops = batch.fetch()  # raises on pipe_error != 0
+    paths = batch.paths(ops, n_ops)
+    check_sample(inputs, params, scores, paths, [0, 1, n_pairs // 2, n_pairs - 1])
+    batch.close()
+
+
+def test_ragged_segment_batch_stand_in_for_config_2(oracle_build):
+    """Stand-in for BASELINE.json configs[2] ("~100 k segment profile alignments"; nucmer is not in the image): 20 000 ragged
+    4-row pairs, lengths log-normal (median 1 500, sigma 0.6, clipped to [200, 8 000]), lb = la * (1 + N(0, 0.05)).  The bench
+    runs the same generator at 100 000 pairs (bench.py --config c2)."""
+    n, rows = 20000, 4
+    la, lb = dp.ragged_lengths(20261003, n)
+    inputs = dp.synth_batch(20261003, la, lb, rows, rows)
+    params = dp.make_params(rows, rows)
+    batch = dp.DpBatch(inputs, params, tb_budget_bytes=8 << 30)
+    chunks = batch.chunks()
+    assert len(chunks) - 1 >= 3
+    batch.run(traceback=True)
+    scores, ops, n_ops = batch.fetch()
+    paths = batch.paths(ops, n_ops)
+    order = np.argsort(la * lb)
+    sample = [chunks[1] - 1, chunks[1], chunks[2] - 1, chunks[2], 0, n - 1, order[0], order[-1], order[n // 2]]
+    small = [int(k) for k in order[:3]] + [int(order[n // 2])]
+    check_sample(inputs, params, scores, paths, sample, full_paths_for=small)
+    assert any((p != 0).any() for p in paths[:50])  # unequal lengths: the optimal paths carry gaps
+    batch.close()
+
+
+def test_scores_beyond_the_int32_headroom_are_refused():
+    """100-row x 10 kbp profiles with match 5 could push the skewed scores past 2^28: refused at creation (PM_E_INVALID)."""
+    from paramugsy_amd import capi
+    n, L = 2, 10000
+    cols = np.zeros((n * L, 8), dtype=np.uint8)
+    cols[:, 0] = 100
+    off = np.arange(n + 1, dtype=np.int64) * L
+    with pytest.raises(capi.PmError) as e:
+        dp.DpBatch(dp.DpInputs(cols, off, cols.copy(), off.copy()), dp.make_params(1, 1, open_per_pair=40, extend_per_pair=3))
+    assert e.value.code == capi.PM_E_INVALID

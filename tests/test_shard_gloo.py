@@ -174,3 +174,34 @@ def test_dp_pair_partition_gathers_in_pair_order(world, oracle_build, tmp_path):
 @pytest.mark.gpu
 def test_dp_two_ranks_on_the_gpu(oracle_build, tmp_path):
     check_dp_gather(*run_dp_ranks(tmp_path, "gpu"))
+
+
+FAIL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import torch.distributed as dist
+from paramugsy_amd import dp, shard
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[3], rank=rank, world_size=world)
+inputs = dp.synth_pairs(31, 9, 2, 60)
+def fn(sub, p):
+    if rank == 1:
+        raise ValueError("boom on rank 1")
+    import pyoracle
+    return pyoracle.dp_align(sub, p)
+try:
+    shard.align_sharded(inputs, dp.make_params(2, 2), rank, world, dist=dist, align_fn=fn)
+    rc = 0
+except RuntimeError as e:
+    rc = 7
+dist.destroy_process_group()
+sys.exit(rc)
+"""
+
+
+def test_a_failing_rank_makes_every_rank_raise_instead_of_hanging(oracle_build, tmp_path):
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER.format(root=ROOT))
+    port = str(free_port())
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port]) for r in range(2)]
+    assert [p.wait(timeout=120) for p in procs] == [7, 7]
