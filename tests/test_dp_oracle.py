@@ -49,4 +49,9 @@ def test_oracle_scores_match_numpy_transcription(seed, oracle_build):
 def test_pack_profile_counts():
     cols = dp.pack_profile([b"ACGT-N", b"AC-TTa", b"-CGTAa"])
     assert cols[:, :5].tolist() == [[2, 0, 0, 0, 1], [0, 3, 0, 0, 0], [0, 0, 2, 0, 1], [0, 0, 0, 3, 0], [1, 0, 0, 1, 1], [2, 0, 0, 0, 0]]
-    assert (cols[:, 5:] == 0).all()
+    # the N of the last column is neither a base nor a gap: counted in byte 5, which the DP does not score
+    assert cols[:, 5].tolist() == [0, 0, 0, 0, 0, 1] and (cols[:, 6:] == 0).all()
+    assert (cols[:, :6].sum(axis=1) == 3).all()
+    import pytest
+    with pytest.raises(ValueError):
+        dp.pack_profile([b"A"] * 256)
