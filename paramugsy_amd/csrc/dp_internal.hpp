@@ -35,10 +35,10 @@ struct DpParamsD {
 //            SAME row of A, so the blocks are rectangles: lane l stores after the step t with (t + 1 - l % DP_CK_W) a multiple
 //            of DP_CK_R.
 #ifndef DP_CK_R
-#define DP_CK_R 32
+#define DP_CK_R 64
 #endif
 #ifndef DP_CK_W
-#define DP_CK_W 2
+#define DP_CK_W 4
 #endif
 static_assert((DP_CK_R & (DP_CK_R - 1)) == 0 && DP_CK_R >= 16, "DP_CK_R is a power of two");
 static_assert(DP_CK_W == 1 || DP_CK_W == 2 || DP_CK_W == 4, "DP_CK_W in {1, 2, 4}");
@@ -65,9 +65,133 @@ __host__ __device__ inline i64 dp_ck_bytes_written(i64 la, i64 lb, int C) {
   return dp_ck_stripes(lb, C) * (la * dp_ck_col_words_per_step() + dp_ck_nck(la) * 64 * 2 * C) * 4;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Device code shared by the fill kernel and the walk: the hand-scheduled cell of the recurrence.
+#if defined(__HIPCC__)
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int dot2(int a, int b, int acc) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
+}
+
+__device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)lo & 0xffffu) | ((unsigned)hi << 16)); }
+
+// One cell of the recurrence, hand-scheduled.  The compiler's version of the same cell spends one more VALU op on
+// a register copy (the old H of the row above must survive as the next cell's diagonal while the new H is written);
+// here the next cell's diagonal term is folded into its score (dn = hop + gap-row dot) BEFORE hop is overwritten, so
+// every per-column register is updated in place: 14 ops with int8 weights (DOT4), 15 with int16.
+//   dp   in : diag + dot2(gap row)  for this cell          dn  out: the same for the next cell (unless LAST)
+//   hl       : H~ - gop of the cell to the left            hop in/out: H~ - gop of the row above / of this cell
+//   ax, az   : A's base counts (four int8, or two int16 pairs), ay : A's (nGap, 1)
+// gfx950 needs 3 independent instructions between a dot op and a different op that reads its result: the orders
+// below keep >= 3 everywhere (score -> max3, dot2 -> the next cell's score).
+#define PM_CELL_E_T "v_sub_u32 %[t], %[hl], %[e]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\tv_max_i32 %[e], %[e], %[hl]\n\t"
+#define PM_CELL_F_T "v_sub_u32 %[t], %[hop], %[f]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\tv_max_i32 %[f], %[f], %[hop]\n\t"
+#define PM_CELL_E "v_max_i32 %[e], %[e], %[hl]\n\t"
+#define PM_CELL_F "v_max_i32 %[f], %[f], %[hop]\n\t"
+#define PM_CELL_SCORE4 "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
+#define PM_CELL_SCORE2 "v_dot2_i32_i16 %[dp], %[ax], %[w0], %[dp]\n\tv_dot2_i32_i16 %[dp], %[az], %[w1], %[dp]\n\t"
+#define PM_CELL_NEXT "v_dot2_i32_i16 %[dn], %[ay], %[w2n], %[hop]\n\t"
+#define PM_CELL_H "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
+#define PM_CELL_H_T                                                                                                    \
+  "v_max3_i32 %[h], %[dp], %[e], %[f]\n\tv_sub_u32 %[t], %[dp], %[h]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"   \
+  "v_sub_u32 %[t], %[e], %[f]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
+#define PM_CELL_OUT "v_subrev_u32 %[hop], %[gop], %[h]"
+#define PM_CELL_OPERANDS                                                                                               \
+  [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t), [h] "=&v"(h)  \
+      : [hl] "v"(hl), [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az), [w0] "v"(w0), [w1] "v"(w1), [w2n] "v"(w2n), [gop] "s"(gop)
+template <bool TRACE, bool LAST, bool DOT4>
+__device__ __forceinline__ void dp_cell(int &dp, int &dn, int &e, int &f, int &hop, unsigned &acc, int hl, int ax, int ay,
+                                        int az, int w0, int w1, int w2n, int gop) {
+  int t, h;
+  if(TRACE) {
+    if(LAST) { // the trailing s_nop keeps hop two wait states away from the DPP read that follows the step
+      if(DOT4) {
+        asm volatile(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+      }
+      else {
+        asm volatile(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+      }
+    }
+    else {
+      if(DOT4) {
+        asm volatile(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT : PM_CELL_OPERANDS);
+      }
+      else {
+        asm volatile(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT : PM_CELL_OPERANDS);
+      }
+    }
+  }
+  else { // score only: 6 (7) ops; s_nops stand in for the decision ops that separate the dot ops from their readers
+    if(LAST) {
+      if(DOT4) {
+        asm volatile(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+      }
+      else {
+        asm volatile(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+      }
+    }
+    else {
+      if(DOT4) {
+        asm volatile(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT : PM_CELL_OPERANDS);
+      }
+      else {
+        asm volatile(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT : PM_CELL_OPERANDS);
+      }
+    }
+  }
+}
+
+
+// B's packed column -> the cell's weight registers: w[a] = sum_b count[b] * sub[a][b]; w0/w1 hold the four base weights
+// (four int8 with DOT4, else two int16 pairs), w2 = (w[gap], go + ge): A's third pair is (nGap, 1), the 1 picks up gop + 2 * ge.
+template <bool DOT4>
+__device__ __forceinline__ void dp_column_weights(u64 col, bool in, const DpParamsD &P, int &w0, int &w1, int &w2) {
+  int cb[5], w[5];
+#pragma unroll
+  for(int b = 0; b < 5; ++b) {
+    cb[b] = (int)((col >> (8 * b)) & 0xff);
+  }
+#pragma unroll
+  for(int a = 0; a < 5; ++a) {
+    int acc = 0;
+#pragma unroll
+    for(int b = 0; b < 5; ++b) {
+      acc += cb[b] * P.sub[a * 5 + b];
+    }
+    w[a] = acc;
+  }
+  if(DOT4) {
+    w0 = (int)(((unsigned)w[0] & 0xffu) | (((unsigned)w[1] & 0xffu) << 8) | (((unsigned)w[2] & 0xffu) << 16) | ((unsigned)w[3] << 24));
+    w1 = 0;
+  }
+  else {
+    w0 = pack16(w[0], w[1]);
+    w1 = pack16(w[2], w[3]);
+  }
+  w2 = pack16(w[4], in ? P.go + P.ge : 0);
+}
+
+// A's packed column -> what the cell reads per row: x = nA, nC, nG, nT as four int8 (DOT4) or (nA, nC) as an int16 pair,
+// y = (nGap, 1), z = (nG, nT) as an int16 pair (unused with DOT4), w = 0.
+template <bool DOT4>
+__device__ __forceinline__ int4 dp_expand_row(u64 col) {
+  int4 v = make_int4(0, 0, 0, 0);
+  if(DOT4) {
+    v.x = (int)(col & 0xffffffffull);
+  }
+  else {
+    v.x = (int)(col & 0xff) | ((int)((col >> 8) & 0xff) << 16);
+    v.z = (int)((col >> 16) & 0xff) | ((int)((col >> 24) & 0xff) << 16);
+  }
+  v.y = (int)((col >> 32) & 0xff) | (1 << 16);
+  return v;
+}
+#endif
+
 // dp_walk.hip: one launch walks the paths of pairs [first_pair, first_pair + n) from their checkpoints.
 // cols_per_lane (of the fill kernel) in {8, 16}; lanes_per_pair a power of two for which dp_walk_lanes_ok() holds.
-int dp_launch_walk(int cols_per_lane, int lanes_per_pair, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
+int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    i64 first_pair, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
                    hipStream_t stream);
 

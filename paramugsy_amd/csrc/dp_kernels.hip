@@ -44,85 +44,11 @@
 
 namespace pm {
 
-typedef short short2_t __attribute__((ext_vector_type(2)));
-
 #define DPP_WAVE_SHR1 0x138
 
 // What the fill kernel leaves behind for the path (dp_internal.hpp): nothing (scores only), 4 decision bits per cell,
 // or the row/column checkpoints the walk of dp_walk.hip recomputes blocks from.
 enum { DP_MODE_SCORE = 0, DP_MODE_BITS = 1, DP_MODE_CKPT = 2 };
-
-__device__ __forceinline__ int dot2(int a, int b, int acc) {
-  return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
-}
-
-__device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)lo & 0xffffu) | ((unsigned)hi << 16)); }
-
-// One cell of the recurrence, hand-scheduled.  The compiler's version of the same cell spends one more VALU op on
-// a register copy (the old H of the row above must survive as the next cell's diagonal while the new H is written);
-// here the next cell's diagonal term is folded into its score (dn = hop + gap-row dot) BEFORE hop is overwritten, so
-// every per-column register is updated in place: 14 ops with int8 weights (DOT4), 15 with int16.
-//   dp   in : diag + dot2(gap row)  for this cell          dn  out: the same for the next cell (unless LAST)
-//   hl       : H~ - gop of the cell to the left            hop in/out: H~ - gop of the row above / of this cell
-//   ax, az   : A's base counts (four int8, or two int16 pairs), ay : A's (nGap, 1)
-// gfx950 needs 3 independent instructions between a dot op and a different op that reads its result: the orders
-// below keep >= 3 everywhere (score -> max3, dot2 -> the next cell's score).
-#define PM_CELL_E_T "v_sub_u32 %[t], %[hl], %[e]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\tv_max_i32 %[e], %[e], %[hl]\n\t"
-#define PM_CELL_F_T "v_sub_u32 %[t], %[hop], %[f]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\tv_max_i32 %[f], %[f], %[hop]\n\t"
-#define PM_CELL_E "v_max_i32 %[e], %[e], %[hl]\n\t"
-#define PM_CELL_F "v_max_i32 %[f], %[f], %[hop]\n\t"
-#define PM_CELL_SCORE4 "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
-#define PM_CELL_SCORE2 "v_dot2_i32_i16 %[dp], %[ax], %[w0], %[dp]\n\tv_dot2_i32_i16 %[dp], %[az], %[w1], %[dp]\n\t"
-#define PM_CELL_NEXT "v_dot2_i32_i16 %[dn], %[ay], %[w2n], %[hop]\n\t"
-#define PM_CELL_H "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
-#define PM_CELL_H_T                                                                                                    \
-  "v_max3_i32 %[h], %[dp], %[e], %[f]\n\tv_sub_u32 %[t], %[dp], %[h]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"   \
-  "v_sub_u32 %[t], %[e], %[f]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"
-#define PM_CELL_OUT "v_subrev_u32 %[hop], %[gop], %[h]"
-#define PM_CELL_OPERANDS                                                                                               \
-  [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t), [h] "=&v"(h)  \
-      : [hl] "v"(hl), [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az), [w0] "v"(w0), [w1] "v"(w1), [w2n] "v"(w2n), [gop] "s"(gop)
-template <bool TRACE, bool LAST, bool DOT4>
-__device__ __forceinline__ void dp_cell(int &dp, int &dn, int &e, int &f, int &hop, unsigned &acc, int hl, int ax, int ay,
-                                        int az, int w0, int w1, int w2n, int gop) {
-  int t, h;
-  if(TRACE) {
-    if(LAST) { // the trailing s_nop keeps hop two wait states away from the DPP read that follows the step
-      if(DOT4) {
-        asm volatile(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
-      }
-      else {
-        asm volatile(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
-      }
-    }
-    else {
-      if(DOT4) {
-        asm volatile(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT : PM_CELL_OPERANDS);
-      }
-      else {
-        asm volatile(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT : PM_CELL_OPERANDS);
-      }
-    }
-  }
-  else { // score only: 6 (7) ops; s_nops stand in for the decision ops that separate the dot ops from their readers
-    if(LAST) {
-      if(DOT4) {
-        asm volatile(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
-      }
-      else {
-        asm volatile(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
-      }
-    }
-    else {
-      if(DOT4) {
-        asm volatile(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT : PM_CELL_OPERANDS);
-      }
-      else {
-        asm volatile(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT : PM_CELL_OPERANDS);
-      }
-    }
-  }
-}
 
 // lane l takes lane l-1's value; lane 0 takes `lane0`.  Needs all 64 lanes enabled.
 __device__ __forceinline__ int from_left(int lane0, int v) {
@@ -199,33 +125,12 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     for(int c = 0; c < C; ++c) {
       const int j = j0 + c;
       const bool in = j < lb;
-      const u64 col = in ? B[j] : 0ull;
-      int cb[5], w[5];
-#pragma unroll
-      for(int b = 0; b < 5; ++b) {
-        cb[b] = (int)((col >> (8 * b)) & 0xff);
-      }
-#pragma unroll
-      for(int a = 0; a < 5; ++a) {
-        int acc = 0;
-#pragma unroll
-        for(int b = 0; b < 5; ++b) {
-          acc += cb[b] * P.sub[a * 5 + b];
-        }
-        w[a] = acc;
-      }
-      if(DOT4) {
-        w0[c] = (int)(((unsigned)w[0] & 0xffu) | (((unsigned)w[1] & 0xffu) << 8) | (((unsigned)w[2] & 0xffu) << 16) | ((unsigned)w[3] << 24));
-        w1[c] = 0;
-      }
-      else {
-        w0[c] = pack16(w[0], w[1]);
-        w1[c] = pack16(w[2], w[3]);
-      }
-      w2[c] = pack16(w[4], in ? go + ge : 0); // A's third pair is (nGap, 1): the 1 picks up gop + 2*ge
+      dp_column_weights<DOT4>(in ? B[j] : 0ull, in, P, w0[c], w1[c], w2[c]);
       hop[c] = -2 * gop;                      // H~[0][j+1] - gop, H~[0][j] = -gop for j >= 1
       f[c] = DP_NEG_INF;
     }
+    // row checkpoints: lane l stores after the steps t with t + 1 - l % DP_CK_W a positive multiple of DP_CK_R
+    int ck_left = DP_CK_R - 1 + (lane & (DP_CK_W - 1)), ck_m = 0;
     int diag_in = (j0 == 0 ? 0 : -gop) - gop; // H~[0][j0] - gop
     int e = DP_NEG_INF; // the running E of this lane's row; between steps: what the lane hands to its right neighbour
     int bin_ho = 0, bin_e = DP_NEG_INF;
@@ -239,18 +144,8 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       {
         // stage rows [t0, t0+63] of A: one coalesced 8-byte load per lane, expanded to int16 pairs
         const int r = t0 + lane;
-        int4 v = make_int4(0, 0, 0, 0);
-        if(r < la) {
-          const u64 col = A[r];
-          if(DOT4) {
-            v.x = (int)(col & 0xffffffffull); // nA, nC, nG, nT as four int8
-          }
-          else {
-            v.x = (int)(col & 0xff) | ((int)((col >> 8) & 0xff) << 16);
-            v.z = (int)((col >> 16) & 0xff) | ((int)((col >> 24) & 0xff) << 16);
-          }
-          v.y = (int)((col >> 32) & 0xff) | (1 << 16); // (nGap, 1): next to x, so that the int8 path reads 8 bytes
-        }
+        // (nGap, 1) sits next to x, so that the int8 path reads 8 bytes per row
+        const int4 v = r < la ? dp_expand_row<DOT4>(A[r]) : make_int4(0, 0, 0, 0);
         ring[r & 127] = v;
         if(NW > 1 && s > 0) {
           // rows [t0, t0+63] of the left stripe's boundary must have been published by its wave
@@ -271,7 +166,12 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         if(s > 0) {
           int2 b = make_int2(0, DP_NEG_INF);
           if(r < la) {
-            b = bp[r];
+            if constexpr(CKPT) { // lane 63 closes a column group: its column checkpoints of stripe s - 1 are the seam
+              b = *reinterpret_cast<const int2 *>(tbp + dp_ck_col_word(la, s - 1, (i64)r + 63, 63));
+            }
+            else {
+              b = bp[r];
+            }
           }
           // consume the loaded values here, so the wait for them sits in this block (once per 64 steps) and
           // not in front of the v_readlane of every step
@@ -332,8 +232,10 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           }
         }
         diag_in = ho_in;
-        if(lane == 63 && s + 1 < n_stripes) {
-          bp[ii16 >> 4] = make_int2(hop[C - 1], e);
+        if constexpr(!CKPT) {
+          if(lane == 63 && s + 1 < n_stripes) {
+            bp[ii16 >> 4] = make_int2(hop[C - 1], e);
+          }
         }
         if constexpr(CKPT) { // what this row hands to the next column group: one coalesced store per step
           if(DP_CK_W == 1 || (lane & (DP_CK_W - 1)) == DP_CK_W - 1) {
@@ -342,15 +244,15 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         }
       }
       if constexpr(CKPT) {
-        // the lane's column state every DP_CK_R steps, the lanes of a group one step apart (after the same row of A)
-        if(((t + 1) & (DP_CK_R - 1)) < DP_CK_W) {
-          const int tt = t + 1 - (lane & (DP_CK_W - 1));
-          if(tt > 0 && (tt & (DP_CK_R - 1)) == 0) {
-            int4 *dst = reinterpret_cast<int4 *>(tbp + dp_ck_row_word(la, lb, C, s, tt / DP_CK_R - 1, lane));
+        // the lane's column state every DP_CK_R steps, the lanes of a group one step apart (after the same row of A):
+        // a per-lane countdown, one VALU op per step
+        if(--ck_left < 0) {
+          ck_left += DP_CK_R;
+          int4 *dst = reinterpret_cast<int4 *>(tbp + dp_ck_row_word(la, lb, C, s, ck_m, lane));
+          ++ck_m;
 #pragma unroll
-            for(int c = 0; c < C; c += 2) {
-              dst[c / 2] = make_int4(hop[c], f[c], hop[c + 1], f[c + 1]);
-            }
+          for(int c = 0; c < C; c += 2) {
+            dst[c / 2] = make_int4(hop[c], f[c], hop[c + 1], f[c + 1]);
           }
         }
       }
@@ -523,6 +425,24 @@ struct pm_dp_batch {
   int walk_lanes = 0;     // lanes per pair of the checkpoint walk (2, 4, 8, 16); 0 = chosen per launch; PM_DP_WALK_LANES overrides
   DevBuf pipe_error;
   hipStream_t last_stream = nullptr;
+  // chunk pipeline (more than one chunk): the workspace is two halves, chunk c uses half c % 2; the path kernel of chunk c runs
+  // on `path_stream` beside the fill kernel of chunk c + 1
+  i64 tb_half_words = 0;
+  hipStream_t path_stream = nullptr;
+  std::vector<hipEvent_t> ev_fill, ev_path;                  // per chunk: fill done / path done
+  std::vector<hipEvent_t> tv_fill0, tv_fill1, tv_path0, tv_path1; // timing events of the profiled run
+  ~pm_dp_batch() {
+    for(std::vector<hipEvent_t> *v : {&ev_fill, &ev_path, &tv_fill0, &tv_fill1, &tv_path0, &tv_path1}) {
+      for(hipEvent_t e : *v) {
+        if(e) {
+          (void)hipEventDestroy(e);
+        }
+      }
+    }
+    if(path_stream) {
+      (void)hipStreamDestroy(path_stream);
+    }
+  }
 };
 
 extern "C" {
@@ -676,18 +596,28 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   }
   DTRY(h->n_ops.alloc((size_t)n_pairs * 4));
   DTRY(h->ops.alloc((size_t)(h->total_a + h->total_b)));
-  // chunks: consecutive pairs whose traceback fits the budget; the buffer is reused chunk after chunk
+  // chunks: consecutive pairs whose workspace fits the budget.  A batch that fits is one chunk; otherwise the budget is cut
+  // in two halves that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernel
+  // of the next (dp_run)
   if(tb_budget_bytes <= 0) {
     tb_budget_bytes = (int64_t)32 << 30;
   }
-  i64 budget_words = tb_budget_bytes / 4;
+  auto need_words = [&](i64 k) {
+    i64 la = off_a[k + 1] - off_a[k], lb = off_b[k + 1] - off_b[k];
+    return h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane) : dp_tb_words(la, lb, h->cols_per_lane);
+  };
+  i64 total_words = 0;
+  for(i64 k = 0; k < n_pairs; ++k) {
+    total_words += need_words(k);
+    h->cells += (off_a[k + 1] - off_a[k]) * (off_b[k + 1] - off_b[k]);
+  }
+  const bool one_chunk = total_words <= tb_budget_bytes / 4;
+  i64 budget_words = one_chunk ? tb_budget_bytes / 4 : tb_budget_bytes / 8;
   h->chunk_first.push_back(0);
   std::vector<i64> cur;
   i64 used = 0;
   for(i64 k = 0; k < n_pairs; ++k) {
-    i64 la = off_a[k + 1] - off_a[k], lb = off_b[k + 1] - off_b[k];
-    i64 need = h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane) : dp_tb_words(la, lb, h->cols_per_lane);
-    h->cells += la * lb;
+    i64 need = need_words(k);
     if(!cur.empty() && used + need > budget_words) {
       h->chunk_tb.push_back(cur);
       h->chunk_first.push_back(k);
@@ -701,7 +631,24 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   h->chunk_tb.push_back(cur);
   h->chunk_first.push_back(n_pairs);
   h->tb_words_cap = std::max(h->tb_words_cap, used);
-  DTRY(h->tb.alloc((size_t)h->tb_words_cap * 4));
+  const bool pipelined = h->chunk_tb.size() > 1;
+  h->tb_half_words = pipelined ? ((h->tb_words_cap + 63) / 64) * 64 : 0;
+  DTRY(h->tb.alloc((size_t)(pipelined ? 2 * h->tb_half_words : h->tb_words_cap) * 4));
+  if(pipelined) {
+    if(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking) != hipSuccess) {
+      pm_dp_batch_destroy(h);
+      return fail(PM_E_HIP, "hipStreamCreate failed");
+    }
+    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if(hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+        pm_dp_batch_destroy(h);
+        return fail(PM_E_HIP, "hipEventCreate failed");
+      }
+      h->ev_fill.push_back(a);
+      h->ev_path.push_back(b);
+    }
+  }
   // per-chunk offset tables live back to back in one device array
   {
     std::vector<i64> flat;
@@ -715,63 +662,35 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   return PM_OK;
 }
 
-namespace {
-struct Events3 { // destroyed on every way out of dp_run
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  ~Events3() {
-    for(int k = 0; k < 3; ++k) {
-      if(ev[k]) {
-        (void)hipEventDestroy(ev[k]);
+// The fill kernel of chunk c into workspace `tbw`.
+static int dp_launch_fill(pm_dp_batch *h, size_t c, unsigned *tbw, int traceback, hipStream_t stream) {
+  const i64 first = h->chunk_first[c], n = h->chunk_first[c + 1] - first;
+  const i64 *tb_off = (const i64 *)h->d_tb_off.p + first;
+  // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
+  // have several stripes to pipeline
+  int nw = 1;
+  {
+    i64 max_stripes = 0, max_la = 0;
+    for(i64 k = first; k < first + n; ++k) {
+      i64 lbk = h->off_b[k + 1] - h->off_b[k];
+      max_stripes = std::max(max_stripes, (lbk + 64 * h->cols_per_lane - 1) / (64 * h->cols_per_lane));
+      max_la = std::max(max_la, h->off_a[k + 1] - h->off_a[k]);
+    }
+    bool fits = (max_stripes + 2) * max_la < ((i64)1 << 30); // the progress word is an int
+    // enough waves to give every SIMD about four (1 024 SIMDs), as far as the pairs have stripes to run side by side
+    if(fits && max_stripes >= 2 && n < 4096) {
+      while(nw < 8 && nw * 2 <= max_stripes && n * nw < 4096) {
+        nw *= 2;
       }
+    }
+    if(h->waves_override == 1 || ((h->waves_override == 2 || h->waves_override == 4 || h->waves_override == 8) && fits)) {
+      nw = h->waves_override;
     }
   }
-};
-} // namespace
-
-static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_trace) {
-  Events3 events;
-  hipEvent_t *ev = events.ev;
-  float acc_fill = 0, acc_trace = 0;
-  bool timed = ms_fill || ms_trace;
-  if(timed) {
-    for(int k = 0; k < 3; ++k) {
-      PM_HIP(hipEventCreate(&ev[k]));
-    }
-  }
-  for(size_t c = 0; c + 1 < h->chunk_first.size(); ++c) {
-    i64 first = h->chunk_first[c], n = h->chunk_first[c + 1] - first;
-    if(n <= 0) {
-      continue;
-    }
-    const i64 *tb_off = (const i64 *)h->d_tb_off.p + first;
-    if(timed) {
-      PM_HIP(hipEventRecord(ev[0], stream));
-    }
-    // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
-    // have several stripes to pipeline
-    int nw = 1;
-    {
-      i64 max_stripes = 0, max_la = 0;
-      for(i64 k = first; k < first + n; ++k) {
-        i64 lbk = h->off_b[k + 1] - h->off_b[k];
-        max_stripes = std::max(max_stripes, (lbk + 64 * h->cols_per_lane - 1) / (64 * h->cols_per_lane));
-        max_la = std::max(max_la, h->off_a[k + 1] - h->off_a[k]);
-      }
-      bool fits = (max_stripes + 2) * max_la < ((i64)1 << 30); // the progress word is an int
-      // enough waves to give every SIMD about four (1 024 SIMDs), as far as the pairs have stripes to run side by side
-      if(fits && max_stripes >= 2 && n < 4096) {
-        while(nw < 8 && nw * 2 <= max_stripes && n * nw < 4096) {
-          nw *= 2;
-        }
-      }
-      if(h->waves_override == 1 || ((h->waves_override == 2 || h->waves_override == 4 || h->waves_override == 8) && fits)) {
-        nw = h->waves_override;
-      }
-    }
 #define DP_LAUNCH_FILL(CC, TR, D4, NWV)                                                                                                   \
   dp_fill_kernel<CC, TR, D4, NWV><<<(unsigned)n, 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,             \
                                                                         (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p, first, tb_off, \
-                                                                        (unsigned *)h->tb.p, (int2 *)h->bnd.p, (int *)h->scores.p,         \
+                                                                        tbw, (int2 *)h->bnd.p, (int *)h->scores.p,                         \
                                                                         (int *)h->pipe_error.p, h->params)
 #define DP_LAUNCH_FILL_D4(CC, TR, NWV) \
   if(h->dot4) {                        \
@@ -805,64 +724,130 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
     DP_LAUNCH_FILL_TR(CC, 1)     \
     break;                       \
   }
-    if(h->cols_per_lane == 16) {
-      DP_LAUNCH_FILL_NW(16)
-    }
-    else {
-      DP_LAUNCH_FILL_NW(8)
-    }
+  if(h->cols_per_lane == 16) {
+    DP_LAUNCH_FILL_NW(16)
+  }
+  else {
+    DP_LAUNCH_FILL_NW(8)
+  }
 #undef DP_LAUNCH_FILL_NW
 #undef DP_LAUNCH_FILL_TR
 #undef DP_LAUNCH_FILL_D4
 #undef DP_LAUNCH_FILL
-    PM_HIP(hipGetLastError());
-    if(timed) {
-      PM_HIP(hipEventRecord(ev[1], stream));
-    }
-    if(traceback && h->ckpt) {
-      // lanes per pair: as few as still give the launch about two wavefronts per SIMD (1 024 SIMDs)
-      int lpp = h->walk_lanes;
-      if(lpp == 0) {
-        lpp = 2;
-        while(!dp_walk_lanes_ok(h->cols_per_lane, lpp)) {
-          lpp *= 2;
-        }
-        while(lpp < 16 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp < 2 * 1024 * 64) {
-          lpp *= 2;
-        }
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+// The path kernel of chunk c from workspace `tbw`: the checkpoint walk, or the walk over stored decision bits.
+static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStream_t stream) {
+  const i64 first = h->chunk_first[c], n = h->chunk_first[c + 1] - first;
+  const i64 *tb_off = (const i64 *)h->d_tb_off.p + first;
+  if(h->ckpt) {
+    // lanes per pair: as few as still give the launch about two wavefronts per SIMD (1 024 SIMDs)
+    int lpp = h->walk_lanes;
+    if(lpp == 0) {
+      lpp = 2;
+      while(!dp_walk_lanes_ok(h->cols_per_lane, lpp)) {
+        lpp *= 2;
       }
-      PM_TRY(dp_launch_walk(h->cols_per_lane, lpp, (const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
-                            (const i64 *)h->d_off_b.p, first, n, tb_off, (const unsigned *)h->tb.p, (unsigned char *)h->ops.p,
-                            (int *)h->n_ops.p, h->params, stream));
-    }
-    else if(traceback) {
-      if(h->cols_per_lane == 16) {
-        dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off,
-                                                                (const unsigned *)h->tb.p, (unsigned char *)h->ops.p, (int *)h->n_ops.p);
+      while(lpp < 32 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp < 2 * 1024 * 64) {
+        lpp *= 2;
       }
-      else {
-        dp_traceback_kernel<8><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off,
-                                                               (const unsigned *)h->tb.p, (unsigned char *)h->ops.p, (int *)h->n_ops.p);
-      }
-      PM_HIP(hipGetLastError());
     }
-    if(timed) {
-      PM_HIP(hipEventRecord(ev[2], stream));
-      PM_HIP(hipEventSynchronize(ev[2]));
-      float a = 0, b = 0;
-      PM_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
-      PM_HIP(hipEventElapsedTime(&b, ev[1], ev[2]));
-      acc_fill += a;
-      acc_trace += b;
+    return dp_launch_walk(h->cols_per_lane, lpp, h->dot4, (const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
+                          (const i64 *)h->d_off_b.p, first, n, tb_off, tbw, (unsigned char *)h->ops.p, (int *)h->n_ops.p, h->params, stream);
+  }
+  if(h->cols_per_lane == 16) {
+    dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off, tbw,
+                                                            (unsigned char *)h->ops.p, (int *)h->n_ops.p);
+  }
+  else {
+    dp_traceback_kernel<8><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off, tbw,
+                                                           (unsigned char *)h->ops.p, (int *)h->n_ops.p);
+  }
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
+// One pass over every chunk.  One chunk: fill, then path, on `stream`.  Several chunks: fill kernels on `stream`, path kernels
+// on the batch's own stream, chunk c's path beside chunk c + 1's fill (the two halves of the workspace alternate); `stream`
+// ends up waiting for the last path kernels, so the caller sees one asynchronous operation on its stream.
+// Timed: device time of the fill and of the path kernels, summed over the chunks (events around every launch on its stream).
+static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_path) {
+  const size_t nc = h->chunk_tb.size();
+  const bool timed = ms_fill || ms_path;
+  const bool pipelined = nc > 1 && h->path_stream && traceback;
+  if(timed && h->tv_fill0.size() < nc) {
+    for(std::vector<hipEvent_t> *v : {&h->tv_fill0, &h->tv_fill1, &h->tv_path0, &h->tv_path1}) {
+      while(v->size() < nc) {
+        hipEvent_t e = nullptr;
+        PM_HIP(hipEventCreate(&e));
+        v->push_back(e);
+      }
     }
   }
-  if(ms_fill) {
-    *ms_fill = acc_fill;
+  unsigned *tb = (unsigned *)h->tb.p;
+  for(size_t c = 0; c < nc; ++c) {
+    if(h->chunk_first[c + 1] - h->chunk_first[c] <= 0) {
+      continue;
+    }
+    unsigned *tbw = tb + (h->tb_half_words ? (c & 1) * h->tb_half_words : 0);
+    hipStream_t ps = pipelined ? h->path_stream : stream;
+    if(pipelined && c >= 2) {
+      PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c - 2], 0)); // the half is free again
+    }
+    if(timed) {
+      PM_HIP(hipEventRecord(h->tv_fill0[c], stream));
+    }
+    PM_TRY(dp_launch_fill(h, c, tbw, traceback, stream));
+    if(timed) {
+      PM_HIP(hipEventRecord(h->tv_fill1[c], stream));
+    }
+    if(traceback) {
+      if(pipelined) {
+        PM_HIP(hipEventRecord(h->ev_fill[c], stream));
+        PM_HIP(hipStreamWaitEvent(ps, h->ev_fill[c], 0));
+      }
+      if(timed) {
+        PM_HIP(hipEventRecord(h->tv_path0[c], ps));
+      }
+      PM_TRY(dp_launch_path(h, c, tbw, ps));
+      if(timed) {
+        PM_HIP(hipEventRecord(h->tv_path1[c], ps));
+      }
+      if(pipelined) {
+        PM_HIP(hipEventRecord(h->ev_path[c], ps));
+      }
+    }
   }
-  if(ms_trace) {
-    *ms_trace = acc_trace;
+  if(pipelined) { // the caller's stream is done when the last two path kernels are
+    for(size_t c = nc >= 2 ? nc - 2 : 0; c < nc; ++c) {
+      PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c], 0));
+    }
   }
   h->last_stream = stream;
+  if(timed) {
+    PM_HIP(hipStreamSynchronize(stream));
+    float acc_fill = 0, acc_path = 0;
+    for(size_t c = 0; c < nc; ++c) {
+      if(h->chunk_first[c + 1] - h->chunk_first[c] <= 0) {
+        continue;
+      }
+      float a = 0, b = 0;
+      PM_HIP(hipEventElapsedTime(&a, h->tv_fill0[c], h->tv_fill1[c]));
+      if(traceback) {
+        PM_HIP(hipEventElapsedTime(&b, h->tv_path0[c], h->tv_path1[c]));
+      }
+      acc_fill += a;
+      acc_path += b;
+    }
+    if(ms_fill) {
+      *ms_fill = acc_fill;
+    }
+    if(ms_path) {
+      *ms_path = acc_path;
+    }
+  }
   return PM_OK;
 }
 

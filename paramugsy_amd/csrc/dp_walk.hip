@@ -2,19 +2,24 @@
 //
 // NO REFERENCE COUNTERPART; checked against oracle/dp_oracle.c only.
 //
-// A group of LPP lanes (2, 4, 8 or 16; 64 / LPP pairs per wavefront) walks one pair from (La, Lb) back to (0, 0).
+// A group of LPP lanes (64 / LPP pairs per wavefront) walks one pair from (La, Lb) back to (0, 0).
 // The walk needs the four decisions of the cells it visits; the fill kernel stored none.  So, block by block along the path:
-//   1. the block is the C columns of one lane of the fill kernel x the rows between two of that lane's row checkpoints
-//      (at most DP_CK_R rows);
-//   2. its top edge ({H~ - gop, F~} of the C columns) comes from the row checkpoint, its left edge ({H~ - gop, E~} per row)
-//      from the column checkpoints of the lane to the left, A's rows and both edges are staged in LDS;
-//   3. the group re-runs the recurrence inside the block as a small anti-diagonal wavefront (lane q owns C / LPP columns,
-//      neighbours exchange with v_mov_b32_dpp row_shr:1), now WITH the four decision bits, 4 bits per cell into LDS;
-//   4. the walk follows the decisions until it leaves the block through its top or its left edge.
+//   1. the block is the C * DP_CK_W columns of one column group of the fill kernel x the DP_CK_R rows between two of that
+//      group's row checkpoints;
+//   2. its top edge ({H~ - gop, F~} of the columns) comes from the row checkpoint, its left edge ({H~ - gop, E~} per row)
+//      from the column checkpoints of the group to the left; A's rows (expanded as the fill kernel's LDS ring holds them) and
+//      the left edge are staged in LDS;
+//   3. the group re-runs the recurrence inside the block as a small anti-diagonal wavefront (lane q owns BW / LPP columns,
+//      neighbours exchange with v_mov_b32_dpp wave_shr:1) with the fill kernel's own hand-scheduled cell (dp_cell, 14 VALU
+//      instructions with the four decision bits), 4 bits per cell into LDS;
+//   4. the walk follows the decisions until it leaves the block through its top or its left edge, a whole run at a time.
 // Same arithmetic, in the same skewed coordinates, as dp_fill_kernel (V~[i][j] = V[i][j] + (i + j) * gap_extend), so every
-// decision is the one the one-pass kernel would have stored.  A path crosses at most La / DP_CK_R + Lb / C + 1 blocks, i.e. the
-// walk recomputes about La * C + Lb * DP_CK_R cells of the La * Lb: 2-5 % at kilobase lengths.
+// decision is the one the one-pass kernel would have stored.  A path crosses at most La / R + Lb / BW + 1 blocks, i.e. the
+// walk recomputes about La * BW + Lb * R cells of the La * Lb: 2-6 % at kilobase lengths.  It is bound by VALU issue like the
+// fill kernel (the groups of a launch keep every SIMD busy), so what counts is instructions per recomputed cell.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "dp_internal.hpp"
 #include "pm_internal.hpp"
@@ -31,18 +36,18 @@ template <> struct BitsWord<1> { typedef unsigned char type; };
 template <> struct BitsWord<2> { typedef unsigned char type; };
 template <> struct BitsWord<4> { typedef unsigned short type; };
 
-template <int C, int LPP>
+template <int C, int LPP, bool DOT4>
 __global__ void __launch_bounds__(64)
 dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b, const i64 *__restrict__ off_b,
                i64 first_pair, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
-               int *__restrict__ n_ops, DpParamsD P) {
+               int *__restrict__ n_ops, DpParamsD P, int ablate) {
   constexpr int R = DP_CK_R;
   constexpr int BW = C * DP_CK_W; // columns of a block
   constexpr int C2 = BW / LPP;    // columns per lane inside a block
   constexpr int G = 64 / LPP;     // pairs per wavefront
   static_assert(C2 >= 1 && C2 <= 8 && C % C2 == 0 && C2 * LPP == BW, "a lane's columns lie in one lane of the fill kernel");
   typedef typename BitsWord<C2>::type bits_t;
-  __shared__ uint2 sh_a[G][R];
+  __shared__ int4 sh_a[G][R]; // A's rows of the block, expanded as the cell reads them
   __shared__ int2 sh_left[G][R + 1];
   __shared__ bits_t sh_bits[G][R][LPP];
   const int grp = threadIdx.x / LPP, q = threadIdx.x % LPP;
@@ -51,7 +56,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const i64 pair = first_pair + (valid ? idx : 0);
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
-  const uint2 *A = reinterpret_cast<const uint2 *>(cols_a + a0);
+  const u64 *A = cols_a + a0;
   const u64 *B = cols_b + b0;
   const unsigned *ckp = ck + tb_off[valid ? idx : 0];
   unsigned char *out = ops + a0 + b0;
@@ -69,34 +74,23 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     const int s = (gg * DP_CK_W) >> 6, l0 = (gg * DP_CK_W) & 63;
     const int k = live ? (i - 1 + l0) / R : 0;
     const int i0 = max(0, k * R - l0);
-    const int i1 = live ? min(la, (k + 1) * R - l0) : i0;
+    // the walk only moves up and left: rows below row i - 1 and columns right of column j - 1 are never visited and no
+    // cell that is depends on them, so the block is cut to rows [i0, i) and to the lanes up to the one that owns column j - 1
+    const int i1 = live ? i : i0;
     const int nrows = i1 - i0;
     const int j0 = gg * BW;
-    // ---- this lane's columns: weights w[a] = sum_b B[j][b] * sub[a][b], constant go + ge (dp_fill_kernel's w2 high half)
-    int w[C2][5], kc[C2], hop[C2], f[C2];
+    const int qmax = live ? (j - 1 - j0) / C2 : -1;
+    const bool mine = live && q <= qmax; // this lane has cells to recompute
+    // ---- this lane's columns: the cell's weight registers, as in dp_fill_kernel
+    int w0[C2], w1[C2], w2[C2], hop[C2], f[C2];
 #pragma unroll
     for(int c = 0; c < C2; ++c) {
       const int jc = j0 + q * C2 + c;
       const bool in = live && jc < lb;
-      const u64 col = in ? B[jc] : 0ull;
-      int cb[5];
-#pragma unroll
-      for(int b = 0; b < 5; ++b) {
-        cb[b] = (int)((col >> (8 * b)) & 0xff);
-      }
-#pragma unroll
-      for(int a = 0; a < 5; ++a) {
-        int acc = 0;
-#pragma unroll
-        for(int b = 0; b < 5; ++b) {
-          acc += cb[b] * P.sub[a * 5 + b];
-        }
-        w[c][a] = acc;
-      }
-      kc[c] = in ? go + ge : 0;
+      dp_column_weights<DOT4>(in ? B[jc] : 0ull, in, P, w0[c], w1[c], w2[c]);
     }
     // ---- top edge: the state of the lane's columns after row i0 - 1 (the group's row checkpoint k - 1)
-    const bool has_top = live && k * R - l0 >= 1;
+    const bool has_top = live && k * R - l0 >= 1 && !(ablate & 2);
     if(has_top) {
       const int lf = (q * C2) / C, cf = (q * C2) % C;
       const int2 *src = reinterpret_cast<const int2 *>(ckp + dp_ck_row_word(la, lb, C, s, k - 1, l0 + lf)) + cf;
@@ -117,13 +111,13 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     // ---- A's rows and the left edge (rows i0 - 1 .. i1 - 1) into LDS
     if(live) {
       for(int r = q; r < nrows; r += LPP) {
-        sh_a[grp][r] = A[i0 + r];
+        sh_a[grp][r] = dp_expand_row<DOT4>(A[i0 + r]);
       }
       const int gl = gg * DP_CK_W - 1, sl = gl >> 6, ll = gl & 63; // the lane left of the group (of the previous stripe for l0 = 0)
       for(int rr = q; rr <= nrows; rr += LPP) {
         const int row = i0 - 1 + rr; // row of A; -1 is the DP's row 0
         int2 v;
-        if(gg == 0) {
+        if(gg == 0 || (ablate & 2)) {
           v = make_int2(row < 0 ? -gop : -2 * gop, DP_NEG_INF); // H~[row + 1][0] - gop
         }
         else if(row < 0) {
@@ -142,40 +136,63 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     if(q == 0) {
       diag_in = sh_left[grp][0].x;
     }
-    for(int u = 0; __any(live && u - q < nrows); ++u) {
-      const int ho_n = from_left_lane(hop[C2 - 1]);
-      const int e_n = from_left_lane(e);
+    const int4 *arow = &sh_a[grp][0];
+    const int2 *lrow = &sh_left[grp][1];
+    bits_t *brow = &sh_bits[grp][0][q];
+    // A's row and (first lane of the group) the left edge are read one step ahead, so that the reads' latency is not on the
+    // step's path; the index is clamped instead of predicated (a row that is read and not used costs nothing)
+    int4 a_nx = arow[min(max(-q, 0), R - 1)];
+    int2 l_nx = lrow[min(max(-q, 0), R - 1)];
+    if(ablate & 1) { // timing experiments only (PM_DP_WALK_ABLATE): no recomputation, every decision reads "diagonal"
+      for(int r = q; r < R * LPP; r += LPP) {
+        (&sh_bits[grp][0][0])[r] = 0;
+      }
+    }
+    for(int u = 0; !(ablate & 1) && __any(mine && u - q < nrows); ++u) {
+      int ho_in = from_left_lane(hop[C2 - 1]);
+      int e_in = from_left_lane(e);
       const int r = u - q;
-      if(live && r >= 0 && r < nrows) {
-        int ho_in = ho_n, e_in = e_n;
-        if(q == 0) {
-          const int2 b = sh_left[grp][r + 1];
-          ho_in = b.x;
-          e_in = b.y;
+      const int4 a = a_nx;
+      const int2 lb_ = l_nx;
+      {
+        const int rn = min(max(r + 1, 0), R - 1);
+        if(DOT4) {
+          const int2 t2 = *reinterpret_cast<const int2 *>(arow + rn);
+          a_nx.x = t2.x;
+          a_nx.y = t2.y;
         }
-        const uint2 ar = sh_a[grp][r];
-        const int a_0 = (int)(ar.x & 0xff), a_1 = (int)((ar.x >> 8) & 0xff), a_2 = (int)((ar.x >> 16) & 0xff), a_3 = (int)(ar.x >> 24),
-                  a_4 = (int)(ar.y & 0xff);
-        int ev = e_in, hl = ho_in, dprev = diag_in;
-        unsigned word = 0;
+        else {
+          a_nx = arow[rn];
+        }
+        if(q == 0) {
+          l_nx = lrow[rn];
+        }
+      }
+      if(mine && r >= 0 && r < nrows) {
+        if(q == 0) {
+          ho_in = lb_.x;
+          e_in = lb_.y;
+        }
+        const int ax = a.x, ay = a.y, az = DOT4 ? 0 : a.z;
+        unsigned acc;
+        asm volatile("" : "=v"(acc)); // every bit that is read gets shifted in below
+        e = e_in;
+        int dd[2];
+        asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(ay), "v"(w2[0]), "v"(diag_in));
 #pragma unroll
         for(int c = 0; c < C2; ++c) {
-          const int d = dprev + a_0 * w[c][0] + a_1 * w[c][1] + a_2 * w[c][2] + a_3 * w[c][3] + a_4 * w[c][4] + kc[c];
-          const unsigned b_e = (unsigned)(hl - ev) >> 31; // E extends (ties open)
-          ev = max(ev, hl);
-          const unsigned b_f = (unsigned)(hop[c] - f[c]) >> 31; // F extends
-          f[c] = max(f[c], hop[c]);
-          const int h = max(d, max(ev, f[c]));
-          const unsigned b_n = (unsigned)(d - h) >> 31;      // H is not the diagonal
-          const unsigned b_x = (unsigned)(ev - f[c]) >> 31; // F beats E
-          dprev = hop[c];
-          hop[c] = h - gop;
-          hl = hop[c];
-          word = (word << 4) | (b_e << 3) | (b_f << 2) | (b_n << 1) | b_x;
+          const int hl = c == 0 ? ho_in : hop[c == 0 ? 0 : c - 1];
+          if(c == C2 - 1) {
+            dp_cell<true, true, DOT4>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], acc, hl, ax, ay, DOT4 ? ax : az, w0[c],
+                                      DOT4 ? w0[c] : w1[c], 0, gop);
+          }
+          else {
+            dp_cell<true, false, DOT4>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], acc, hl, ax, ay, DOT4 ? ax : az, w0[c],
+                                       DOT4 ? w0[c] : w1[c], w2[c + 1 < C2 ? c + 1 : c], gop);
+          }
         }
-        e = ev;
         diag_in = ho_in;
-        sh_bits[grp][r][q] = (bits_t)word;
+        brow[r * LPP] = (bits_t)acc;
       }
     }
     __syncthreads();
@@ -253,17 +270,18 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   }
 }
 
-template <int C, int LPP>
+template <int C, int LPP, bool DOT4>
 static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b, i64 first_pair, i64 n, const i64 *tb_off,
                        const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, hipStream_t stream) {
   constexpr int G = 64 / LPP;
   const unsigned blocks = (unsigned)((n + G - 1) / G);
-  dp_walk_kernel<C, LPP><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P);
+  static const int ablate = getenv("PM_DP_WALK_ABLATE") ? atoi(getenv("PM_DP_WALK_ABLATE")) : 0;
+  dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P, ablate);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
 
-int dp_launch_walk(int cols_per_lane, int lanes_per_pair, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
+int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    i64 first_pair, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
                    hipStream_t stream) {
   if(n <= 0) {
@@ -273,7 +291,8 @@ int dp_launch_walk(int cols_per_lane, int lanes_per_pair, const u64 *cols_a, con
 #define WALK(CC, LL)                                                                                                        \
   if constexpr((CC * DP_CK_W) % LL == 0 && (CC * DP_CK_W) / LL >= 1 && (CC * DP_CK_W) / LL <= 8 && CC % ((CC * DP_CK_W) / LL) == 0) { \
     if(lanes_per_pair == LL) {                                                                                              \
-      return launch_walk<CC, LL>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P, stream);           \
+      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P, stream) \
+                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P, stream); \
     }                                                                                                                       \
   }
   if(cols_per_lane == 16) {

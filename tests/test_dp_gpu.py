@@ -96,7 +96,7 @@ def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, mode, ora
     run_and_compare(inputs, dp.make_params(4, 4))
 
 
-@pytest.mark.parametrize("lanes,cols", [("4", "16"), ("8", "16"), ("16", "16"), ("32", "16"), ("2", "8"), ("4", "8"), ("8", "8"), ("16", "8")])
+@pytest.mark.parametrize("lanes,cols", [("8", "16"), ("16", "16"), ("32", "16"), ("64", "16"), ("4", "8"), ("8", "8"), ("16", "8"), ("32", "8")])
 def test_checkpoint_walk_with_every_group_size(lanes, cols, oracle_build, monkeypatch):
     """The checkpoint walk with every group size (lanes per pair) the block width allows, for both column counts of the fill
     kernel: ragged pairs whose optimal paths carry long gaps, so the walk leaves blocks through their left edge as well as
