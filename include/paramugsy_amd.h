@@ -225,6 +225,29 @@ int pm_dp_batch_variant(pm_dp_batch_t *batch, int32_t *cols_per_lane, int32_t *d
 int pm_dp_batch_path_mode(pm_dp_batch_t *batch, int32_t *checkpoints, int32_t *block_rows, int32_t *block_columns);
 void pm_dp_batch_destroy(pm_dp_batch_t *batch);
 
+/* MAF blocks into the DP and out of it (csrc/dp_maf.hip).  A list of blocks is described flat: `text` holds the gapped texts of
+ * every row of every block back to back (no separators), row r is bytes [row_off[r], row_off[r+1]), block b is rows
+ * [block_row[b], block_row[b+1]) (block_row[0] = 0, block_row[n_blocks] = n_rows); the rows of one block have the same length.
+ * Symbols: case-insensitive A, C, G, T -> bytes 0-3 of the packed column, '-' -> byte 4, anything else (N, IUPAC) -> byte 5
+ * (carried, not scored).  At most 255 rows per block.
+ *
+ * pm_dp_pack_maf: rows of every block -> one packed 8-byte column per block column (the per-column fold over a block's rows of
+ *   lib/profiles/m_make.ml:15-45, counting instead of voting).  col_off_out[n_blocks + 1] is always written; with cols_out == NULL
+ *   only the sizes are computed (cols_out holds col_off_out[n_blocks] * 8 bytes).
+ * pm_dp_emit_maf: pair k = block k of A and block k of B plus its path ops[ops_off[k] .. ops_off[k] + n_ops[k]) (first op first,
+ *   0 = M, 1 = I, 2 = D) -> the merged block: rows(A) + rows(B) rows of n_ops[k] bytes, A's rows first, '-' where the path skips
+ *   a row's side (the expansion of lib/profiles/m_untranslate.ml:38-52 along the DP's path).  out_off[n_pairs + 1] (byte offsets of
+ *   the pairs' texts) is always written; with out_text == NULL only the sizes are computed.  A path that does not span its pair
+ *   of blocks is refused (PM_E_INVALID).
+ * pm_dp_align_maf: two MAF files with the same number of blocks -> a MAF file of the merged blocks, `a score=<DP score>`, every
+ *   `s` line keeping its name / start / size / strand / srcSize fields.  New surface (the reference has no such stage). */
+int pm_dp_pack_maf(const uint8_t *text, const int64_t *row_off, int64_t n_rows, const int64_t *block_row, int64_t n_blocks,
+                   uint8_t *cols_out, int64_t *col_off_out, int device);
+int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a, const uint8_t *text_b,
+                   const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs, const uint8_t *ops,
+                   const int64_t *ops_off, const int32_t *n_ops, uint8_t *out_text, int64_t *out_off, int device);
+int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,430 @@
+// dp_maf.hip -- MAF blocks into the profile DP and out of it (gfx950).
+//
+// NO REFERENCE COUNTERPART for the DP itself.  The two byte transforms either side of it are the same
+// kind of work the reference does around its own path:
+//   pack   rows of a MAF block -> one packed column per block column {nA, nC, nG, nT, nGap, nOther, 0, 0}: the per-column
+//          fold over a block's rows that lib/profiles/m_make.ml:15-45 does for the consensus (here it counts instead of
+//          voting);
+//   emit   two blocks + the DP's path -> the merged block: every row's text expanded along the path with '-' where the
+//          path skips its side, as lib/profiles/m_untranslate.ml:38-52 (expand_text) re-inserts gap columns along a
+//          coordinate walk.
+// Both are byte kernels: one thread per block column (pack) or per output byte (emit), consecutive lanes on consecutive
+// bytes of a row; the path's running column positions come from one device scan over all ops.
+// Symbol policy (stated, since nothing upstream defines it): case-insensitive; A, C, G, T count in bytes 0-3, '-' in byte 4,
+// anything else (N, IUPAC codes, '.') in byte 5, which the DP does not score: such a row is neutral in that column.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "dp_internal.hpp"
+#include "pm_internal.hpp"
+
+namespace pm {
+
+// last b with off[b] <= g
+__device__ __forceinline__ i64 owner_of(const i64 *off, i64 n, i64 g) {
+  i64 lo = 0, hi = n;
+  while(hi - lo > 1) {
+    const i64 mid = (lo + hi) >> 1;
+    if(off[mid] <= g) {
+      lo = mid;
+    }
+    else {
+      hi = mid;
+    }
+  }
+  return lo;
+}
+
+__global__ void dp_pack_kernel(i64 n_cols, i64 n_blocks, const i64 *__restrict__ col_off, const i64 *__restrict__ block_row,
+                               const i64 *__restrict__ row_off, const unsigned char *__restrict__ text, u64 *__restrict__ cols) {
+  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= n_cols) {
+    return;
+  }
+  const i64 b = owner_of(col_off, n_blocks, g);
+  const i64 c = g - col_off[b];
+  u64 acc = 0;
+  for(i64 r = block_row[b]; r < block_row[b + 1]; ++r) {
+    const unsigned char ch = text[row_off[r] + c] & 0xdf; // upper case ('-' = 0x2d -> 0x0d)
+    const int k = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == ('-' & 0xdf) ? 4 : 5;
+    acc += 1ull << (8 * k);
+  }
+  cols[g] = acc;
+}
+
+// flags for the scans: a[k] = op k consumes a column of A (M or D), b[k] = of B (M or I)
+__global__ void dp_op_flags_kernel(i64 n, const unsigned char *__restrict__ ops, int *__restrict__ fa, int *__restrict__ fb, int *bad) {
+  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= n) {
+    return;
+  }
+  const unsigned char op = ops[g];
+  if(op > 2) {
+    atomicOr(bad, 1);
+  }
+  fa[g] = op != 1;
+  fb[g] = op != 2;
+}
+
+// One thread per output byte: pair p, row r of its (rows(A) + rows(B)) rows, path position k.
+__global__ void dp_emit_kernel(i64 n_out, i64 n_pairs, const i64 *__restrict__ out_off, const i64 *__restrict__ ops_off,
+                               const int *__restrict__ n_ops, const unsigned char *__restrict__ ops, const int *__restrict__ pos_a,
+                               const int *__restrict__ pos_b, const i64 *__restrict__ block_row_a, const i64 *__restrict__ row_off_a,
+                               const unsigned char *__restrict__ text_a, const i64 *__restrict__ block_row_b,
+                               const i64 *__restrict__ row_off_b, const unsigned char *__restrict__ text_b, unsigned char *__restrict__ out,
+                               int *bad) {
+  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= n_out) {
+    return;
+  }
+  const i64 p = owner_of(out_off, n_pairs, g);
+  const i64 len = n_ops[p];
+  const i64 r = (g - out_off[p]) / len, k = (g - out_off[p]) % len;
+  const i64 o = ops_off[p] + k;
+  const unsigned char op = ops[o];
+  const i64 ra = block_row_a[p + 1] - block_row_a[p];
+  unsigned char ch = '-';
+  if(r < ra) {
+    if(op != 1) {
+      const i64 row = block_row_a[p] + r;
+      const i64 c = pos_a[o] - pos_a[ops_off[p]];
+      if(c >= row_off_a[row + 1] - row_off_a[row]) {
+        atomicOr(bad, 2);
+      }
+      else {
+        ch = text_a[row_off_a[row] + c];
+      }
+    }
+  }
+  else {
+    if(op != 2) {
+      const i64 row = block_row_b[p] + (r - ra);
+      const i64 c = pos_b[o] - pos_b[ops_off[p]];
+      if(c >= row_off_b[row + 1] - row_off_b[row]) {
+        atomicOr(bad, 2);
+      }
+      else {
+        ch = text_b[row_off_b[row] + c];
+      }
+    }
+  }
+  out[g] = ch;
+}
+
+// rows of one block must have one length
+static int check_blocks(const int64_t *row_off, int64_t n_rows, const int64_t *block_row, int64_t n_blocks, const char *who) {
+  if(!row_off || !block_row || n_rows < 0 || n_blocks < 0 || block_row[0] != 0 || block_row[n_blocks] != n_rows || row_off[0] != 0) {
+    return fail(PM_E_INVALID, std::string(who) + ": bad block description");
+  }
+  for(int64_t b = 0; b < n_blocks; ++b) {
+    if(block_row[b + 1] < block_row[b]) {
+      return fail(PM_E_INVALID, std::string(who) + ": block_row must not decrease");
+    }
+    if(block_row[b + 1] - block_row[b] > 255) {
+      return fail(PM_E_INVALID, std::string(who) + ": a block has more than 255 rows (a packed column counts rows in a byte)");
+    }
+    for(int64_t r = block_row[b]; r < block_row[b + 1]; ++r) {
+      if(row_off[r + 1] < row_off[r] || row_off[r + 1] - row_off[r] != row_off[block_row[b] + 1] - row_off[block_row[b]]) {
+        return fail(PM_E_INVALID, std::string(who) + ": rows of one block must have the same number of columns");
+      }
+    }
+  }
+  return PM_OK;
+}
+
+// One `s` line of a MAF block: the six fields in front of the text verbatim, and the text.
+struct MafDpRow {
+  std::string head; // "s name start size strand srcSize"
+  std::string text;
+};
+struct MafDpBlocks {
+  std::vector<MafDpRow> rows;
+  std::vector<int64_t> block_row; // [n_blocks + 1]
+};
+
+// `a` opens a block, `s` lines are its rows, anything else (comments, `##maf`, blank lines, other line types) is skipped:
+// the block structure of lib/profiles_lib/maf_read_stream.cc:7-45 without its end-of-file quirks.
+static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if(!f) {
+    return fail(PM_E_IO, "cannot open " + path);
+  }
+  std::string text;
+  char buf[1 << 16];
+  size_t n;
+  while((n = fread(buf, 1, sizeof buf, f)) > 0) {
+    text.append(buf, n);
+  }
+  fclose(f);
+  out.block_row.clear();
+  out.rows.clear();
+  bool open = false;
+  size_t p = 0;
+  while(p < text.size()) {
+    size_t e = text.find('\n', p);
+    if(e == std::string::npos) {
+      e = text.size();
+    }
+    size_t le = e;
+    if(le > p && text[le - 1] == '\r') {
+      --le;
+    }
+    if(le > p + 1 && text[p] == 'a' && (text[p + 1] == ' ' || text[p + 1] == '\t')) {
+      out.block_row.push_back((int64_t)out.rows.size());
+      open = true;
+    }
+    else if(le > p + 1 && text[p] == 's' && (text[p + 1] == ' ' || text[p + 1] == '\t')) {
+      if(!open) {
+        return fail(PM_E_PARSE, path + ": `s` line outside a block");
+      }
+      // seven whitespace-separated fields; the text is the last
+      size_t q = p, fields = 0, text_at = 0;
+      while(q < le) {
+        while(q < le && (text[q] == ' ' || text[q] == '\t')) {
+          ++q;
+        }
+        if(q >= le) {
+          break;
+        }
+        ++fields;
+        if(fields == 7) {
+          text_at = q;
+        }
+        while(q < le && text[q] != ' ' && text[q] != '\t') {
+          ++q;
+        }
+      }
+      if(fields != 7) {
+        return fail(PM_E_PARSE, path + ": an `s` line needs 7 fields");
+      }
+      size_t head_end = text_at;
+      while(head_end > p && (text[head_end - 1] == ' ' || text[head_end - 1] == '\t')) {
+        --head_end;
+      }
+      MafDpRow r;
+      r.head.assign(text, p, head_end - p);
+      size_t te = text_at;
+      while(te < le && text[te] != ' ' && text[te] != '\t') {
+        ++te;
+      }
+      r.text.assign(text, text_at, te - text_at);
+      out.rows.push_back(r);
+    }
+    p = e + 1;
+  }
+  out.block_row.push_back((int64_t)out.rows.size()); // a file without any `a` line: block_row = {0}, no blocks
+  return PM_OK;
+}
+
+static void flatten(const MafDpBlocks &b, std::string &text, std::vector<int64_t> &row_off) {
+  row_off.assign(1, 0);
+  for(const MafDpRow &r : b.rows) {
+    text += r.text;
+    row_off.push_back((int64_t)text.size());
+  }
+}
+
+} // namespace pm
+
+using namespace pm;
+
+extern "C" {
+
+int pm_dp_pack_maf(const uint8_t *text, const int64_t *row_off, int64_t n_rows, const int64_t *block_row, int64_t n_blocks,
+                   uint8_t *cols_out, int64_t *col_off_out, int device) {
+  PM_TRY(use_device(device));
+  PM_TRY(check_blocks(row_off, n_rows, block_row, n_blocks, "pm_dp_pack_maf"));
+  if(!col_off_out) {
+    return fail(PM_E_INVALID, "pm_dp_pack_maf: null col_off_out");
+  }
+  col_off_out[0] = 0;
+  for(int64_t b = 0; b < n_blocks; ++b) {
+    const int64_t first = block_row[b];
+    col_off_out[b + 1] = col_off_out[b] + (block_row[b + 1] > first ? row_off[first + 1] - row_off[first] : 0);
+  }
+  const int64_t n_cols = col_off_out[n_blocks];
+  if(!cols_out || n_cols == 0) {
+    return PM_OK; // sizes only
+  }
+  if(!text) {
+    return fail(PM_E_INVALID, "pm_dp_pack_maf: null text");
+  }
+  DevBuf d_text, d_row_off, d_block_row, d_col_off, d_cols;
+  PM_TRY(d_text.upload(text, (size_t)row_off[n_rows], nullptr));
+  PM_TRY(d_row_off.upload(row_off, (size_t)(n_rows + 1) * 8, nullptr));
+  PM_TRY(d_block_row.upload(block_row, (size_t)(n_blocks + 1) * 8, nullptr));
+  PM_TRY(d_col_off.upload(col_off_out, (size_t)(n_blocks + 1) * 8, nullptr));
+  PM_TRY(d_cols.alloc((size_t)n_cols * 8));
+  dp_pack_kernel<<<(unsigned)((n_cols + 255) / 256), 256>>>(n_cols, n_blocks, (const i64 *)d_col_off.p, (const i64 *)d_block_row.p,
+                                                            (const i64 *)d_row_off.p, (const unsigned char *)d_text.p, (u64 *)d_cols.p);
+  PM_HIP(hipGetLastError());
+  PM_HIP(hipMemcpy(cols_out, d_cols.p, (size_t)n_cols * 8, hipMemcpyDeviceToHost));
+  return PM_OK;
+}
+
+int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a, const uint8_t *text_b,
+                   const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs, const uint8_t *ops,
+                   const int64_t *ops_off, const int32_t *n_ops, uint8_t *out_text, int64_t *out_off, int device) {
+  PM_TRY(use_device(device));
+  PM_TRY(check_blocks(row_off_a, n_rows_a, block_row_a, n_pairs, "pm_dp_emit_maf (A)"));
+  PM_TRY(check_blocks(row_off_b, n_rows_b, block_row_b, n_pairs, "pm_dp_emit_maf (B)"));
+  if(!ops_off || !n_ops || !out_off) {
+    return fail(PM_E_INVALID, "pm_dp_emit_maf: null argument");
+  }
+  out_off[0] = 0;
+  int64_t ops_end = 0;
+  for(int64_t p = 0; p < n_pairs; ++p) {
+    if(n_ops[p] < 0 || ops_off[p] < 0) {
+      return fail(PM_E_INVALID, "pm_dp_emit_maf: bad path description");
+    }
+    const int64_t rows = (block_row_a[p + 1] - block_row_a[p]) + (block_row_b[p + 1] - block_row_b[p]);
+    out_off[p + 1] = out_off[p] + rows * (int64_t)n_ops[p];
+    ops_end = std::max(ops_end, ops_off[p] + n_ops[p]);
+  }
+  const int64_t n_out = out_off[n_pairs];
+  if(!out_text || n_out == 0) {
+    return PM_OK; // sizes only
+  }
+  if(ops_end >= ((int64_t)1 << 31)) {
+    return fail(PM_E_INVALID, "pm_dp_emit_maf: more than 2^31 ops in one call");
+  }
+  if(!ops || (!text_a && row_off_a[n_rows_a] > 0) || (!text_b && row_off_b[n_rows_b] > 0)) {
+    return fail(PM_E_INVALID, "pm_dp_emit_maf: null buffer");
+  }
+  // host check: every path consumes exactly its two blocks (a path that does not cannot be expanded)
+  for(int64_t p = 0; p < n_pairs; ++p) {
+    int64_t na = 0, nb = 0;
+    for(int64_t k = 0; k < n_ops[p]; ++k) {
+      const uint8_t op = ops[ops_off[p] + k];
+      na += op != 1;
+      nb += op != 2;
+    }
+    const int64_t ra = block_row_a[p + 1] - block_row_a[p], rb = block_row_b[p + 1] - block_row_b[p];
+    const int64_t la = ra ? row_off_a[block_row_a[p] + 1] - row_off_a[block_row_a[p]] : 0;
+    const int64_t lb = rb ? row_off_b[block_row_b[p] + 1] - row_off_b[block_row_b[p]] : 0;
+    if((ra && na != la) || (rb && nb != lb)) {
+      return fail(PM_E_INVALID, "pm_dp_emit_maf: a path does not span its pair of blocks");
+    }
+  }
+  DevBuf d_ta, d_tb, d_roa, d_rob, d_bra, d_brb, d_ops, d_ops_off, d_n_ops, d_out_off, d_fa, d_fb, d_pa, d_pb, d_out, d_bad, d_tmp;
+  PM_TRY(d_ta.upload(text_a, (size_t)row_off_a[n_rows_a], nullptr));
+  PM_TRY(d_tb.upload(text_b, (size_t)row_off_b[n_rows_b], nullptr));
+  PM_TRY(d_roa.upload(row_off_a, (size_t)(n_rows_a + 1) * 8, nullptr));
+  PM_TRY(d_rob.upload(row_off_b, (size_t)(n_rows_b + 1) * 8, nullptr));
+  PM_TRY(d_bra.upload(block_row_a, (size_t)(n_pairs + 1) * 8, nullptr));
+  PM_TRY(d_brb.upload(block_row_b, (size_t)(n_pairs + 1) * 8, nullptr));
+  PM_TRY(d_ops.upload(ops, (size_t)ops_end, nullptr));
+  PM_TRY(d_ops_off.upload(ops_off, (size_t)n_pairs * 8, nullptr));
+  PM_TRY(d_n_ops.upload(n_ops, (size_t)n_pairs * 4, nullptr));
+  PM_TRY(d_out_off.upload(out_off, (size_t)(n_pairs + 1) * 8, nullptr));
+  PM_TRY(d_fa.alloc((size_t)ops_end * 4));
+  PM_TRY(d_fb.alloc((size_t)ops_end * 4));
+  PM_TRY(d_pa.alloc((size_t)ops_end * 4));
+  PM_TRY(d_pb.alloc((size_t)ops_end * 4));
+  PM_TRY(d_out.alloc((size_t)n_out));
+  PM_TRY(d_bad.alloc(4));
+  PM_HIP(hipMemset(d_bad.p, 0, 4));
+  dp_op_flags_kernel<<<(unsigned)((ops_end + 255) / 256), 256>>>(ops_end, (const unsigned char *)d_ops.p, (int *)d_fa.p, (int *)d_fb.p,
+                                                                 (int *)d_bad.p);
+  PM_HIP(hipGetLastError());
+  size_t tmp_bytes = 0;
+  PM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+  PM_TRY(d_tmp.alloc(tmp_bytes));
+  PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+  PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fb.p, (int *)d_pb.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+  dp_emit_kernel<<<(unsigned)((n_out + 255) / 256), 256>>>(n_out, n_pairs, (const i64 *)d_out_off.p, (const i64 *)d_ops_off.p,
+                                                           (const int *)d_n_ops.p, (const unsigned char *)d_ops.p, (const int *)d_pa.p,
+                                                           (const int *)d_pb.p, (const i64 *)d_bra.p, (const i64 *)d_roa.p,
+                                                           (const unsigned char *)d_ta.p, (const i64 *)d_brb.p, (const i64 *)d_rob.p,
+                                                           (const unsigned char *)d_tb.p, (unsigned char *)d_out.p, (int *)d_bad.p);
+  PM_HIP(hipGetLastError());
+  int bad = 0;
+  PM_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+  if(bad) {
+    return fail(PM_E_INVALID, "pm_dp_emit_maf: an op outside {0, 1, 2} or a path that leaves its block");
+  }
+  PM_HIP(hipMemcpy(out_text, d_out.p, (size_t)n_out, hipMemcpyDeviceToHost));
+  return PM_OK;
+}
+
+} // extern "C"
+
+extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, int device) {
+  if(!maf_a || !maf_b || !params || !out_maf) {
+    return fail(PM_E_INVALID, "pm_dp_align_maf: null argument");
+  }
+  PM_TRY(use_device(device));
+  MafDpBlocks A, B;
+  PM_TRY(parse_maf_blocks(maf_a, A));
+  PM_TRY(parse_maf_blocks(maf_b, B));
+  const int64_t n = (int64_t)A.block_row.size() - 1;
+  if(n != (int64_t)B.block_row.size() - 1) {
+    return fail(PM_E_INVALID, "pm_dp_align_maf: the two MAF files must hold the same number of blocks (pair k = block k of each)");
+  }
+  std::string ta, tb;
+  std::vector<int64_t> roa, rob;
+  flatten(A, ta, roa);
+  flatten(B, tb, rob);
+  std::vector<int64_t> coa((size_t)n + 1), cob((size_t)n + 1);
+  PM_TRY(pm_dp_pack_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), n, nullptr, coa.data(), device));
+  PM_TRY(pm_dp_pack_maf((const uint8_t *)tb.data(), rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, nullptr, cob.data(), device));
+  std::vector<uint8_t> ca((size_t)coa[n] * 8 + 8), cb((size_t)cob[n] * 8 + 8);
+  PM_TRY(pm_dp_pack_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), n, ca.data(), coa.data(), device));
+  PM_TRY(pm_dp_pack_maf((const uint8_t *)tb.data(), rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, cb.data(), cob.data(), device));
+  pm_dp_batch_t *batch = nullptr;
+  PM_TRY(pm_dp_batch_create(ca.data(), coa.data(), cb.data(), cob.data(), n, params, 0, device, &batch));
+  std::vector<int32_t> scores((size_t)n), n_ops((size_t)n);
+  std::vector<uint8_t> ops((size_t)(coa[n] + cob[n]) + 1);
+  int rc = pm_dp_batch_run(batch, 1, nullptr);
+  if(!rc) {
+    rc = pm_dp_batch_fetch(batch, scores.data(), ops.data(), n_ops.data());
+  }
+  pm_dp_batch_destroy(batch);
+  PM_TRY(rc);
+  // pair k's path is the last n_ops[k] bytes of its slot
+  std::vector<int64_t> ops_off((size_t)n), out_off((size_t)n + 1);
+  for(int64_t k = 0; k < n; ++k) {
+    ops_off[(size_t)k] = coa[k + 1] + cob[k + 1] - n_ops[(size_t)k];
+  }
+  PM_TRY(pm_dp_emit_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), (const uint8_t *)tb.data(),
+                        rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, ops.data(), ops_off.data(), n_ops.data(), nullptr,
+                        out_off.data(), device));
+  std::vector<uint8_t> merged((size_t)out_off[n] + 1);
+  PM_TRY(pm_dp_emit_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), (const uint8_t *)tb.data(),
+                        rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, ops.data(), ops_off.data(), n_ops.data(), merged.data(),
+                        out_off.data(), device));
+  FILE *f = fopen(out_maf, "wb");
+  if(!f) {
+    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
+  }
+  std::string o = "##maf version=1 scoring=paramugsy_amd\n";
+  for(int64_t k = 0; k < n; ++k) {
+    o += "a score=" + std::to_string(scores[(size_t)k]) + "\n";
+    const int64_t ra = A.block_row[k + 1] - A.block_row[k], rb = B.block_row[k + 1] - B.block_row[k];
+    const int64_t len = n_ops[(size_t)k];
+    for(int64_t r = 0; r < ra + rb; ++r) {
+      const MafDpRow &row = r < ra ? A.rows[(size_t)(A.block_row[k] + r)] : B.rows[(size_t)(B.block_row[k] + r - ra)];
+      o += row.head;
+      o += ' ';
+      o.append((const char *)merged.data() + out_off[(size_t)k] + r * len, (size_t)len);
+      o += '\n';
+    }
+    o += '\n';
+    if(o.size() > (1u << 22)) {
+      fwrite(o.data(), 1, o.size(), f);
+      o.clear();
+    }
+  }
+  fwrite(o.data(), 1, o.size(), f);
+  if(fclose(f) != 0) {
+    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
+  }
+  return PM_OK;
+}

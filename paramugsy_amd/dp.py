@@ -77,6 +77,10 @@ def _lib():
         l.pm_dp_batch_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.pm_dp_batch_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         l.pm_dp_batch_path_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        l.pm_dp_pack_maf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        l.pm_dp_emit_maf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        l.pm_dp_align_maf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PmDpParams), C.c_char_p, C.c_int]
         l.pm_dp_batch_destroy.argtypes = [C.c_void_p]
         l.pm_dp_batch_destroy.restype = None
         l._dp_bound = True
@@ -170,6 +174,60 @@ class DpBatch:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------- MAF blocks in and out (pm_dp_pack_maf / pm_dp_emit_maf)
+
+def flatten_blocks(blocks: Sequence[Sequence[bytes]]):
+    """A list of blocks (each a list of equally long gapped row texts) -> (text uint8, row_off int64, block_row int64), the flat
+    description the C ABI takes."""
+    rows = [r for b in blocks for r in b]
+    text = np.frombuffer(b"".join(rows), dtype=np.uint8).copy() if rows else np.zeros(0, dtype=np.uint8)
+    row_off = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    block_row = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.int64)
+    return text, row_off, block_row
+
+
+def pack_maf(blocks: Sequence[Sequence[bytes]], device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Rows of every block -> (packed columns uint8 [total columns, 8], col_off int64 [n_blocks + 1]) on the GPU."""
+    l = _lib()
+    text, row_off, block_row = flatten_blocks(blocks)
+    n = len(block_row) - 1
+    col_off = np.zeros(n + 1, dtype=np.int64)
+    capi.check(l.pm_dp_pack_maf(text.ctypes.data, row_off.ctypes.data, len(row_off) - 1, block_row.ctypes.data, n, None, col_off.ctypes.data, device))
+    cols = np.zeros((int(col_off[-1]), 8), dtype=np.uint8)
+    capi.check(l.pm_dp_pack_maf(text.ctypes.data, row_off.ctypes.data, len(row_off) - 1, block_row.ctypes.data, n, cols.ctypes.data,
+                                col_off.ctypes.data, device))
+    return cols, col_off
+
+
+def emit_maf(blocks_a: Sequence[Sequence[bytes]], blocks_b: Sequence[Sequence[bytes]], paths: Sequence[np.ndarray],
+             device: int = 0) -> List[List[bytes]]:
+    """Pair k = block k of each side + its path -> the merged block's rows (A's rows first), on the GPU."""
+    l = _lib()
+    ta, roa, bra = flatten_blocks(blocks_a)
+    tb, rob, brb = flatten_blocks(blocks_b)
+    n = len(paths)
+    n_ops = np.array([len(p) for p in paths], dtype=np.int32)
+    ops_off = np.concatenate([[0], np.cumsum(n_ops)]).astype(np.int64)
+    ops = np.concatenate([np.asarray(p, dtype=np.uint8) for p in paths]) if n and ops_off[-1] else np.zeros(1, dtype=np.uint8)
+    out_off = np.zeros(n + 1, dtype=np.int64)
+    args = [ta.ctypes.data, roa.ctypes.data, len(roa) - 1, bra.ctypes.data, tb.ctypes.data, rob.ctypes.data, len(rob) - 1, brb.ctypes.data, n,
+            ops.ctypes.data, ops_off.ctypes.data, n_ops.ctypes.data]
+    capi.check(l.pm_dp_emit_maf(*args, None, out_off.ctypes.data, device))
+    out = np.zeros(max(1, int(out_off[-1])), dtype=np.uint8)
+    capi.check(l.pm_dp_emit_maf(*args, out.ctypes.data, out_off.ctypes.data, device))
+    merged = []
+    for k in range(n):
+        rows = len(blocks_a[k]) + len(blocks_b[k])
+        ln = int(n_ops[k])
+        base = int(out_off[k])
+        merged.append([out[base + r * ln: base + (r + 1) * ln].tobytes() for r in range(rows)])
+    return merged
+
+
+def align_maf_files(maf_a: str, maf_b: str, params: PmDpParams, out_maf: str, device: int = 0) -> None:
+    capi.check(_lib().pm_dp_align_maf(maf_a.encode(), maf_b.encode(), C.byref(params), out_maf.encode(), device))
 
 
 # ---------------------------------------------------------------- synthetic workloads

@@ -207,3 +207,51 @@ def align_sharded(inputs, params, rank: int, world: int, dist=None, device: int 
         return scores, paths
     _all_ok(err is None, rank, world, dist, "align", err)
     return gather_pair_results(scores, paths, rank, world, dist)
+
+
+def align_blocks_sharded(blocks_a, blocks_b, params, rank: int, world: int, dist=None, device: int = 0, block_fn=None):
+    """MAF blocks in, merged MAF blocks out, over a static pair partition: pair k = block k of each side.  Rank r packs, aligns
+    and expands its contiguous slice on its GPU (pm_dp_pack_maf -> pm_dp_batch_* -> pm_dp_emit_maf); rank 0 receives every
+    shard's scores and merged blocks in pair order: the "host-side gather of MAF blocks".  Three flat arrays travel per rank
+    (scores, rows and columns per merged block, all row texts back to back).
+    block_fn(sub_a, sub_b, params) -> (scores, merged blocks) replaces the HIP path in the CPU tests (the oracle)."""
+    import numpy as np
+    lo, hi = partition(len(blocks_a), world, rank)
+    sub_a, sub_b = blocks_a[lo:hi], blocks_b[lo:hi]
+    scores, merged, err = None, None, None
+    try:
+        if block_fn is not None:
+            scores, merged = block_fn(sub_a, sub_b, params)
+        else:
+            from . import dp
+            ca, oa = dp.pack_maf(sub_a, device=device)
+            cb, ob = dp.pack_maf(sub_b, device=device)
+            batch = dp.DpBatch(dp.DpInputs(ca, oa, cb, ob), params, device=device)
+            try:
+                batch.run(traceback=True)
+                scores, ops, n_ops = batch.fetch()
+                paths = batch.paths(ops, n_ops)
+            finally:
+                batch.close()
+            merged = dp.emit_maf(sub_a, sub_b, paths, device=device)
+    except Exception as e:  # noqa: BLE001 -- reported to every rank below
+        err = e
+    if world == 1 or dist is None:
+        if err is not None:
+            raise err
+        return np.asarray(scores, dtype=np.int32), merged
+    _all_ok(err is None, rank, world, dist, "align_blocks", err)
+    shape = np.array([[len(m), len(m[0]) if m else 0] for m in merged], dtype=np.int64).reshape(-1, 2)
+    g_scores = gather_bytes(np.ascontiguousarray(scores, dtype=np.int32).tobytes(), rank, world, dist)
+    g_shape = gather_bytes(shape.tobytes(), rank, world, dist)
+    g_text = gather_bytes(b"".join(r for m in merged for r in m), rank, world, dist)
+    if rank != 0:
+        return None, None
+    all_scores = np.concatenate([np.frombuffer(b, dtype=np.int32) for b in g_scores])
+    all_blocks = []
+    for sb, tb in zip(g_shape, g_text):
+        at = 0
+        for rows, cols in np.frombuffer(sb, dtype=np.int64).reshape(-1, 2):
+            all_blocks.append([tb[at + r * cols: at + (r + 1) * cols] for r in range(int(rows))])
+            at += int(rows) * int(cols)
+    return all_scores, all_blocks

@@ -1,0 +1,138 @@
+"""MAF blocks into the profile DP and out of it: pm_dp_pack_maf, pm_dp_emit_maf, pm_dp_align_maf against oracle/dp_maf_oracle.py
+(this repo's own restatement: the reference has no DP stage) and against cases worked out by hand below."""
+import os
+
+import numpy as np
+import pytest
+
+from paramugsy_amd import dp
+
+import dp_maf_oracle as ora
+
+
+def test_oracle_hand_worked_pack():
+    # column by column: "AC-n", "aGTN", "A--T" -> col0 {A:3}, col1 {C:1, G:1, gap:1}, col2 {T:1, gap:2}, col3 {T:1, other:2}
+    cols = ora.pack_block([b"AC-n", b"aGTN", b"A--T"])
+    assert cols == [[3, 0, 0, 0, 0, 0, 0, 0], [0, 1, 1, 0, 1, 0, 0, 0], [0, 0, 0, 1, 2, 0, 0, 0], [0, 0, 0, 1, 0, 2, 0, 0]]
+    assert np.array_equal(np.array(cols, dtype=np.uint8), dp.pack_profile([b"AC-n", b"aGTN", b"A--T"]))
+
+
+def test_oracle_hand_worked_emit():
+    # A = {ACG, A-G} (3 columns), B = {CGT} (3 columns); path M D M I I: A0~B0, A1 alone, A2~B1, B2 alone... spans A (M D M = 3)
+    # and B (M M I I would be 4) -> use M D M I: B consumes M, M, I = 3
+    rows = ora.emit_block([b"ACG", b"A-G"], [b"CGT"], [0, 2, 0, 1])
+    assert rows == [b"ACG-", b"A-G-", b"C-GT"]
+    with pytest.raises(AssertionError):
+        ora.emit_block([b"ACG"], [b"CGT"], [0, 0])
+
+
+def random_blocks(rng, n, max_rows=6, max_cols=300):
+    alphabet = np.frombuffer(b"ACGTacgt-N-ACGT", dtype=np.uint8)
+    blocks = []
+    for _ in range(n):
+        rows, cols = int(rng.integers(1, max_rows + 1)), int(rng.integers(1, max_cols + 1))
+        blocks.append([alphabet[rng.integers(0, len(alphabet), size=cols)].tobytes() for _ in range(rows)])
+    return blocks
+
+
+@pytest.mark.gpu
+def test_pack_equals_oracle_on_random_blocks():
+    rng = np.random.default_rng(3)
+    blocks = random_blocks(rng, 40) + [[b"A"], [b"-", b"n"], [b"acgt" * 700] * 9]
+    cols, off = dp.pack_maf(blocks)
+    assert off.tolist() == np.concatenate([[0], np.cumsum([len(b[0]) for b in blocks])]).tolist()
+    for k, b in enumerate(blocks):
+        assert cols[off[k]:off[k + 1]].tolist() == ora.pack_block(b), "block %d" % k
+    # every column's six counts sum to the number of rows
+    for k, b in enumerate(blocks):
+        assert (cols[off[k]:off[k + 1], :6].sum(axis=1) == len(b)).all()
+
+
+@pytest.mark.gpu
+def test_blocks_through_the_dp_and_back(oracle_build):
+    """pack -> DP -> emit on random block pairs: the packed columns feed the DP (scores and paths equal the scalar oracle's on the
+    same packed columns), and the merged blocks equal the oracle's expansion, row by row; removing the '-' the path inserted
+    gives every input row back."""
+    import pyoracle
+    rng = np.random.default_rng(4)
+    A = random_blocks(rng, 25, max_rows=4, max_cols=200)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    B = []
+    for a in A:  # B's rows: a's first row with substitutions, cut to one length per block (so the optimal paths carry gaps)
+        src = np.frombuffer(a[0].upper().replace(b"N", b"A").replace(b"-", b"C"), dtype=np.uint8)
+        keep = max(1, len(src) - int(rng.integers(0, 9)))
+        B.append([np.where(rng.random(len(src)) < 0.1, rng.choice(bases, len(src)), src).astype(np.uint8)[:keep].tobytes()
+                  for _ in range(int(rng.integers(1, 4)))])
+    ca, oa = dp.pack_maf(A)
+    cb, ob = dp.pack_maf(B)
+    inputs = dp.DpInputs(ca, oa, cb, ob)
+    params = dp.make_params(2, 2)
+    batch = dp.DpBatch(inputs, params)
+    batch.run(True)
+    scores, ops, n_ops = batch.fetch()
+    paths = batch.paths(ops, n_ops)
+    batch.close()
+    o_scores, o_paths = pyoracle.dp_align(inputs, params)
+    assert np.array_equal(scores, o_scores) and all(np.array_equal(p, q) for p, q in zip(paths, o_paths))
+    merged = dp.emit_maf(A, B, paths)
+    for k in range(len(A)):
+        assert merged[k] == ora.emit_block(A[k], B[k], paths[k].tolist()), "pair %d" % k
+        for r, row in enumerate(A[k]):
+            kept = bytes(ch for ch, op in zip(merged[k][r], paths[k]) if op != 1)
+            assert kept == row
+        for r, row in enumerate(B[k]):
+            kept = bytes(ch for ch, op in zip(merged[k][len(A[k]) + r], paths[k]) if op != 2)
+            assert kept == row
+
+
+@pytest.mark.gpu
+def test_emit_refuses_a_path_that_does_not_span_the_pair():
+    from paramugsy_amd import capi
+    with pytest.raises(capi.PmError) as e:
+        dp.emit_maf([[b"ACG"]], [[b"CGT"]], [np.array([0, 0], dtype=np.uint8)])
+    assert e.value.code == capi.PM_E_INVALID
+    with pytest.raises(capi.PmError):
+        dp.pack_maf([[b"ACG", b"AC"]])  # rows of one block differ in length
+
+
+@pytest.mark.gpu
+def test_align_maf_files_end_to_end(oracle_build, tmp_path):
+    """Two MAF files -> a MAF file of merged blocks: `a score=` is the oracle's score for the packed blocks, every `s` line keeps
+    its six leading fields, and the texts are the oracle's expansion of the oracle's path."""
+    import pyoracle
+    rng = np.random.default_rng(5)
+    A = random_blocks(rng, 6, max_rows=3, max_cols=120)
+    B = random_blocks(rng, 6, max_rows=3, max_cols=120)
+
+    def write(path, blocks, tag):
+        with open(path, "wb") as f:
+            f.write(b"##maf version=1 scoring=test\n# a comment\n")
+            for k, b in enumerate(blocks):
+                f.write(b"a score=0 label=%d\n" % k)
+                for r, row in enumerate(b):
+                    size = sum(ch not in b"-" for ch in row)
+                    f.write(b"s %s.g%d %d %d + 100000 %s\n" % (tag, r, 10 * k, size, row))
+                f.write(b"\n")
+    pa, pb, po = str(tmp_path / "a.maf"), str(tmp_path / "b.maf"), str(tmp_path / "out.maf")
+    write(pa, A, b"L")
+    write(pb, B, b"R")
+    params = dp.make_params(2, 2)
+    dp.align_maf_files(pa, pb, params, po)
+    got = ora.parse_maf(po)
+    assert len(got) == 6
+    lines = open(po, "rb").read().split(b"\n")
+    score_lines = [ln for ln in lines if ln.startswith(b"a score=")]
+    for k in range(6):
+        ca = np.array(ora.pack_block(A[k]), dtype=np.uint8)
+        cb = np.array(ora.pack_block(B[k]), dtype=np.uint8)
+        one = dp.DpInputs(ca, np.array([0, len(ca)], dtype=np.int64), cb, np.array([0, len(cb)], dtype=np.int64))
+        s, p = pyoracle.dp_align(one, params)
+        assert score_lines[k] == b"a score=%d" % s[0]
+        heads, texts = got[k]
+        assert texts == ora.emit_block(A[k], B[k], p[0].tolist())
+        assert [h.split()[1] for h in heads] == [b"L.g%d" % r for r in range(len(A[k]))] + [b"R.g%d" % r for r in range(len(B[k]))]
+    # mismatching block counts are refused
+    from paramugsy_amd import capi
+    write(pb, B[:5], b"R")
+    with pytest.raises(capi.PmError):
+        dp.align_maf_files(pa, pb, params, po)

@@ -205,3 +205,80 @@ def test_a_failing_rank_makes_every_rank_raise_instead_of_hanging(oracle_build, 
     port = str(free_port())
     procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port]) for r in range(2)]
     assert [p.wait(timeout=120) for p in procs] == [7, 7]
+
+
+BLOCK_WORKER = r"""
+import os, pickle, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import numpy as np
+import torch.distributed as dist
+from paramugsy_amd import dp, shard
+rank, world, use_gpu = int(sys.argv[1]), int(sys.argv[2]), sys.argv[5] == "gpu"
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[3], rank=rank, world_size=world)
+A, B = pickle.load(open(sys.argv[6], "rb"))
+params = dp.make_params(2, 2)
+fn = None
+if not use_gpu:
+    import pyoracle, dp_maf_oracle as ora
+    def fn(sa, sb, p):
+        scores, merged = [], []
+        for a, b in zip(sa, sb):
+            ca = np.array(ora.pack_block(a), dtype=np.uint8).reshape(-1, 8); cb = np.array(ora.pack_block(b), dtype=np.uint8).reshape(-1, 8)
+            one = dp.DpInputs(ca, np.array([0, len(ca)], dtype=np.int64), cb, np.array([0, len(cb)], dtype=np.int64))
+            s, pth = pyoracle.dp_align(one, p)
+            scores.append(int(s[0])); merged.append(ora.emit_block(a, b, pth[0].tolist()))
+        return np.array(scores, dtype=np.int32), merged
+scores, blocks = shard.align_blocks_sharded(A, B, params, rank, world, dist=dist, device=0, block_fn=fn)
+if rank == 0:
+    pickle.dump((np.asarray(scores), blocks), open(sys.argv[4], "wb"))
+else:
+    assert scores is None and blocks is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def run_block_ranks(tmp_path, mode, world):
+    import pickle
+    rng = np.random.default_rng(12)
+    alphabet = np.frombuffer(b"ACGTacgt-N", dtype=np.uint8)
+    mk = lambda: [[alphabet[rng.integers(0, 10, size=c)].tobytes() for _ in range(int(rng.integers(1, 4)))]
+                  for c in rng.integers(1, 90, size=11)]
+    A, B = mk(), mk()
+    inp = str(tmp_path / "blocks.pkl")
+    pickle.dump((A, B), open(inp, "wb"))
+    script = tmp_path / "block_worker.py"
+    script.write_text(BLOCK_WORKER.format(root=ROOT))
+    out = str(tmp_path / "gathered_blocks.pkl")
+    port = str(free_port())
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), port, out, mode, inp]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    return A, B, pickle.load(open(out, "rb"))
+
+
+def check_block_gather(A, B, got):
+    import pyoracle
+    import dp_maf_oracle as ora
+    from paramugsy_amd import dp
+    scores, blocks = got
+    assert len(blocks) == len(A) == 11
+    for k in range(len(A)):
+        ca = np.array(ora.pack_block(A[k]), dtype=np.uint8).reshape(-1, 8)
+        cb = np.array(ora.pack_block(B[k]), dtype=np.uint8).reshape(-1, 8)
+        one = dp.DpInputs(ca, np.array([0, len(ca)], dtype=np.int64), cb, np.array([0, len(cb)], dtype=np.int64))
+        s, p = pyoracle.dp_align(one, dp.make_params(2, 2))
+        assert scores[k] == s[0]
+        assert [bytes(r) for r in blocks[k]] == ora.emit_block(A[k], B[k], p[0].tolist()), "pair %d" % k
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_maf_blocks_gather_in_pair_order(world, oracle_build, tmp_path):
+    """MAF blocks in, merged blocks out over `world` gloo ranks (the oracle stands in for the HIP path): rank 0 receives scores
+    and merged blocks in pair order, equal to one run over all pairs."""
+    check_block_gather(*run_block_ranks(tmp_path, "cpu", world))
+
+
+@pytest.mark.gpu
+def test_maf_blocks_two_ranks_on_the_gpu(oracle_build, tmp_path):
+    check_block_gather(*run_block_ranks(tmp_path, "gpu", 2))
