@@ -225,6 +225,21 @@ int pm_dp_batch_variant(pm_dp_batch_t *batch, int32_t *cols_per_lane, int32_t *d
 int pm_dp_batch_path_mode(pm_dp_batch_t *batch, int32_t *checkpoints, int32_t *block_rows, int32_t *block_columns);
 void pm_dp_batch_destroy(pm_dp_batch_t *batch);
 
+/* The DP fed from host memory (csrc/dp_stream.hip): pm_dp_stream_align loads a batch in `segments` pieces of consecutive pairs
+ * on an upload stream, runs the fill kernel on every piece as soon as it has arrived, one path kernel per workspace chunk, and
+ * brings the results back on a download stream.  Same inputs, same outputs and same output layout as
+ * pm_dp_batch_create + run + fetch (ops == n_ops == NULL: scores only); the device buffers are kept from call to call.
+ * Copies are asynchronous only from / to pinned host memory: pm_dp_host_alloc / pm_dp_host_free hand it out (pageable buffers
+ * work, their copies just serialise on the host).  workspace_bytes: path workspace (<= 0: 32 GiB).  Blocking: returns when
+ * every result is in the caller's arrays. */
+typedef struct pm_dp_stream pm_dp_stream_t;
+int pm_dp_host_alloc(void **ptr, int64_t bytes);
+void pm_dp_host_free(void *ptr);
+int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t workspace_bytes, int device, pm_dp_stream_t **out);
+int pm_dp_stream_align(pm_dp_stream_t *stream, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
+                       int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops);
+void pm_dp_stream_destroy(pm_dp_stream_t *stream);
+
 /* MAF blocks into the DP and out of it (csrc/dp_maf.hip).  A list of blocks is described flat: `text` holds the gapped texts of
  * every row of every block back to back (no separators), row r is bytes [row_off[r], row_off[r+1]), block b is rows
  * [block_row[b], block_row[b+1]) (block_row[0] = 0, block_row[n_blocks] = n_rows); the rows of one block have the same length.

@@ -1,0 +1,95 @@
+// dp_batch.hpp -- the host-side state of a batch of profile pairs (pm_dp_batch_t), shared by dp_kernels.hip (create / run /
+// fetch) and dp_stream.hip (the same state reused slice after slice with uploads, kernels and downloads on three streams).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "dp_internal.hpp"
+#include "pm_internal.hpp"
+
+struct pm_dp_batch {
+  int device = 0;
+  pm::i64 n_pairs = 0, total_a = 0, total_b = 0;
+  std::vector<pm::i64> off_a, off_b;
+  pm::DevBuf cols_a, cols_b, d_off_a, d_off_b, bnd, scores, ops, n_ops, tb, d_tb_off, stats;
+  std::vector<pm::i64> chunk_first;            // first pair of each chunk, plus n_pairs
+  std::vector<std::vector<pm::i64> > chunk_tb; // per chunk: word offsets of its pairs
+  pm::i64 tb_words_cap = 0;
+  pm::i64 tb_budget_bytes = 0;
+  pm::DpParamsD params;
+  int max_sub_acgt = 0, max_sub_all = 0;
+  pm::i64 cells = 0;
+  int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
+  bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
+  int waves_override = 0; // PM_DP_WAVES=1|2|4|8 forces the waves-per-pair choice
+  bool ckpt = true;       // paths from checkpoints + block recomputation (dp_walk.hip); PM_DP_MODE=bits stores 4 bits per cell
+  int walk_lanes = 0;     // lanes per pair of the checkpoint walk; 0 = chosen per launch; PM_DP_WALK_LANES overrides
+  pm::DevBuf pipe_error;
+  hipStream_t last_stream = nullptr;
+  // chunk pipeline (more than one chunk): the workspace is two halves, chunk c uses half c % 2; the path kernel of chunk c runs
+  // on `path_stream` beside the fill kernel of chunk c + 1
+  pm::i64 tb_half_words = 0;
+  hipStream_t path_stream = nullptr;
+  std::vector<hipEvent_t> ev_fill, ev_path;                       // per chunk: fill done / path done
+  std::vector<hipEvent_t> tv_fill0, tv_fill1, tv_path0, tv_path1; // timing events of the profiled run
+  // dp_stream.hip: the columns arrive in segments of consecutive pairs (seg_first: first pair of each, plus n_pairs); ev_seg[k]
+  // fires on the upload stream when segment k is in HBM, and dp_run launches the fill kernel segment by segment behind them
+  std::vector<pm::i64> seg_first;
+  std::vector<hipEvent_t> ev_seg;
+  bool seg_events_armed = false;
+  // dp_stream.hip: a one-chunk batch may run its path kernel on a stream of the caller's (`ext_path_stream`) instead of the
+  // fill kernel's stream; dp_run then records `ev_ext_fill` / `ev_ext_path` and leaves the ordering to the caller
+  hipStream_t ext_path_stream = nullptr;
+  hipEvent_t ev_ext_fill = nullptr, ev_ext_path = nullptr;
+  bool ext_path_used = false; // set by dp_run: the last run's results are complete at ev_ext_path, not at the end of its stream
+  // pinned host staging of a reusable batch (dp_stream.hip): offsets, workspace offsets and the column statistics
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  int host_stats[4] = {0, 0, 0, 0};
+  ~pm_dp_batch() {
+    for(std::vector<hipEvent_t> *v : {&ev_fill, &ev_path, &tv_fill0, &tv_fill1, &tv_path0, &tv_path1, &ev_seg}) {
+      for(hipEvent_t e : *v) {
+        if(e) {
+          (void)hipEventDestroy(e);
+        }
+      }
+    }
+    if(path_stream) {
+      (void)hipStreamDestroy(path_stream);
+    }
+    for(hipEvent_t e : {ev_ext_fill, ev_ext_path}) {
+      if(e) {
+        (void)hipEventDestroy(e);
+      }
+    }
+    if(pinned) {
+      (void)hipHostFree(pinned);
+    }
+  }
+};
+
+namespace pm {
+
+// The steps pm_dp_batch_create is made of (dp_kernels.hip).  A reusable batch goes reserve once, then load / plan / run per slice.
+int dp_batch_check_params(const pm_dp_params_t *params);
+int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device);
+// device buffers for up to cap_pairs pairs with cap_a / cap_b columns in all; only grows
+int dp_batch_reserve(pm_dp_batch *h, i64 cap_pairs, i64 cap_a, i64 cap_b);
+// offsets (rebased to 0), columns and the column statistics kernels on `stream`; the statistics land in h->host_stats once the
+// stream has run that far (the copies are asynchronous when the host buffers are pinned).  off_a / off_b point at the slice's first offset.
+int dp_batch_load(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
+                  int64_t n_pairs, hipStream_t stream);
+// the same in `segments` pieces of about equal column counts: after piece k, ev_seg[k] is recorded on `stream`; the statistics of
+// piece 0 alone land in stats_first (pinned) behind ev_seg[0], those of the whole batch in the usual place behind the last event
+int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
+                           int64_t n_pairs, int segments, int *stats_first, hipStream_t stream);
+// dp_batch_plan with the statistics given (dp_batch_plan itself reads the batch's own)
+int dp_batch_plan_with(pm_dp_batch *h, const int *stats, hipStream_t stream);
+// after the load has completed: validate against the statistics, choose the kernel variant, cut the batch into chunks of the
+// workspace, send the chunks' offset table on `stream`
+int dp_batch_plan(pm_dp_batch *h, hipStream_t stream);
+int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_path);
+
+} // namespace pm

@@ -408,69 +408,11 @@ __global__ void dp_column_stats_kernel(const u64 *cols, i64 n, int *stats) {
 
 using namespace pm;
 
-struct pm_dp_batch {
-  int device = 0;
-  i64 n_pairs = 0, total_a = 0, total_b = 0;
-  std::vector<i64> off_a, off_b;
-  DevBuf cols_a, cols_b, d_off_a, d_off_b, bnd, scores, ops, n_ops, tb, d_tb_off;
-  std::vector<i64> chunk_first;            // first pair of each chunk, plus n_pairs
-  std::vector<std::vector<i64> > chunk_tb; // per chunk: word offsets of its pairs
-  i64 tb_words_cap = 0;
-  DpParamsD params;
-  i64 cells = 0;
-  int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
-  bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
-  int waves_override = 0; // PM_DP_WAVES=1|2|4|8 forces the waves-per-pair choice
-  bool ckpt = true;       // paths from checkpoints + block recomputation (dp_walk.hip); PM_DP_MODE=bits stores 4 bits per cell
-  int walk_lanes = 0;     // lanes per pair of the checkpoint walk (2, 4, 8, 16); 0 = chosen per launch; PM_DP_WALK_LANES overrides
-  DevBuf pipe_error;
-  hipStream_t last_stream = nullptr;
-  // chunk pipeline (more than one chunk): the workspace is two halves, chunk c uses half c % 2; the path kernel of chunk c runs
-  // on `path_stream` beside the fill kernel of chunk c + 1
-  i64 tb_half_words = 0;
-  hipStream_t path_stream = nullptr;
-  std::vector<hipEvent_t> ev_fill, ev_path;                  // per chunk: fill done / path done
-  std::vector<hipEvent_t> tv_fill0, tv_fill1, tv_path0, tv_path1; // timing events of the profiled run
-  ~pm_dp_batch() {
-    for(std::vector<hipEvent_t> *v : {&ev_fill, &ev_path, &tv_fill0, &tv_fill1, &tv_path0, &tv_path1}) {
-      for(hipEvent_t e : *v) {
-        if(e) {
-          (void)hipEventDestroy(e);
-        }
-      }
-    }
-    if(path_stream) {
-      (void)hipStreamDestroy(path_stream);
-    }
-  }
-};
+#include "dp_batch.hpp"
 
-extern "C" {
+namespace pm {
 
-int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
-                       const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out) {
-  if(!out) {
-    return fail(PM_E_INVALID, "pm_dp_batch_create: null out");
-  }
-  *out = nullptr;
-  if(n_pairs < 0 || !off_a || !off_b || !params) {
-    return fail(PM_E_INVALID, "pm_dp_batch_create: null argument");
-  }
-  int rc = use_device(device);
-  if(rc) {
-    return rc;
-  }
-  if(off_a[0] != 0 || off_b[0] != 0) {
-    return fail(PM_E_INVALID, "pm_dp_batch_create: offsets must start at 0");
-  }
-  for(int64_t k = 0; k < n_pairs; ++k) {
-    if(off_a[k + 1] < off_a[k] || off_b[k + 1] < off_b[k] || off_a[k + 1] - off_a[k] > (1 << 24) || off_b[k + 1] - off_b[k] > (1 << 24)) {
-      return fail(PM_E_INVALID, "pm_dp_batch_create: bad profile length");
-    }
-  }
-  if((off_a[n_pairs] > 0 && !cols_a) || (off_b[n_pairs] > 0 && !cols_b)) {
-    return fail(PM_E_INVALID, "pm_dp_batch_create: null columns");
-  }
+int dp_batch_check_params(const pm_dp_params_t *params) {
   // int16 weights: |sum_b count * sub| must stay below 2^15 (255 rows x |sub| <= 127)
   for(int k = 0; k < 25; ++k) {
     if(params->sub[k] < -127 || params->sub[k] > 127) {
@@ -480,15 +422,10 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   if(params->gap_open < 0 || params->gap_extend < 0 || params->gap_open + params->gap_extend > 32767) {
     return fail(PM_E_INVALID, "pm_dp_batch_create: gap penalties must be >= 0 and gap_open + gap_extend <= 32767");
   }
-  for(int64_t k = 0; k < n_pairs; ++k) {
-    if((off_a[k + 1] - off_a[k] + off_b[k + 1] - off_b[k]) * (int64_t)params->gap_extend >= (1 << 28)) {
-      return fail(PM_E_INVALID, "pm_dp_batch_create: (La + Lb) * gap_extend must stay below 2^28");
-    }
-  }
-  pm_dp_batch *h = new(std::nothrow) pm_dp_batch();
-  if(!h) {
-    return fail(PM_E_INVALID, "out of host memory");
-  }
+  return PM_OK;
+}
+
+int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device) {
   h->device = device;
   if(const char *e = getenv("PM_DP_WAVES")) {
     h->waves_override = atoi(e);
@@ -505,115 +442,242 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
       h->walk_lanes = v;
     }
   }
-  h->n_pairs = n_pairs;
-  h->off_a.assign(off_a, off_a + n_pairs + 1);
-  h->off_b.assign(off_b, off_b + n_pairs + 1);
-  h->total_a = off_a[n_pairs];
-  h->total_b = off_b[n_pairs];
   memcpy(h->params.sub, params->sub, sizeof h->params.sub);
-  int max_sub_acgt = 0, max_sub_all = 0;
-  {
-    // int8 path: counts of A <= 127 and |sum_b B[j][b] * sub[a][b]| <= (rows of B's column) * max|sub[a][.]| <= 127 for a in ACGT
-    int max_sub = 0;
-    for(int a = 0; a < 4; ++a) {
-      for(int b = 0; b < 5; ++b) {
-        max_sub = std::max(max_sub, std::abs(params->sub[a * 5 + b]));
-      }
-    }
-    for(int k = 0; k < 25; ++k) {
-      max_sub_all = std::max(max_sub_all, std::abs(params->sub[k]));
-    }
-    max_sub_acgt = max_sub;
-  }
   h->params.go = params->gap_open;
   h->params.ge = params->gap_extend;
-#define DTRY(x)               \
-  do {                        \
-    int rc_ = (x);            \
-    if(rc_) {                 \
-      pm_dp_batch_destroy(h); \
-      return rc_;             \
-    }                         \
-  } while(0)
-  hipStream_t stream = nullptr;
-  DTRY(h->cols_a.upload(cols_a, (size_t)h->total_a * 8, stream));
-  DTRY(h->cols_b.upload(cols_b, (size_t)h->total_b * 8, stream));
-  DTRY(h->d_off_a.upload(off_a, (size_t)(n_pairs + 1) * 8, stream));
-  DTRY(h->d_off_b.upload(off_b, (size_t)(n_pairs + 1) * 8, stream));
+  // int8 path: counts of A <= 127 and |sum_b B[j][b] * sub[a][b]| <= (rows of B's column) * max|sub[a][.]| <= 127 for a in ACGT
+  h->max_sub_acgt = 0;
+  h->max_sub_all = 0;
+  for(int a = 0; a < 5; ++a) {
+    for(int b = 0; b < 5; ++b) {
+      const int v = std::abs(params->sub[a * 5 + b]);
+      h->max_sub_all = std::max(h->max_sub_all, v);
+      if(a < 4) {
+        h->max_sub_acgt = std::max(h->max_sub_acgt, v);
+      }
+    }
+  }
+  h->tb_budget_bytes = tb_budget_bytes > 0 ? tb_budget_bytes : (int64_t)32 << 30;
+  PM_TRY(h->pipe_error.alloc(4));
+  PM_HIP(hipMemset(h->pipe_error.p, 0, 4));
+  PM_TRY(h->stats.alloc(16));
+  return PM_OK;
+}
+
+static int grow(DevBuf &b, size_t bytes) {
+  if(b.p && b.bytes >= std::max<size_t>(bytes, 16)) {
+    return PM_OK;
+  }
+  return b.alloc(bytes);
+}
+
+int dp_batch_reserve(pm_dp_batch *h, i64 cap_pairs, i64 cap_a, i64 cap_b) {
+  PM_TRY(grow(h->cols_a, (size_t)cap_a * 8));
+  PM_TRY(grow(h->cols_b, (size_t)cap_b * 8));
+  PM_TRY(grow(h->d_off_a, (size_t)(cap_pairs + 1) * 8));
+  PM_TRY(grow(h->d_off_b, (size_t)(cap_pairs + 1) * 8));
+  PM_TRY(grow(h->d_tb_off, (size_t)(cap_pairs + 1) * 8));
+  PM_TRY(grow(h->bnd, (size_t)cap_a * 8));
+  PM_TRY(grow(h->scores, (size_t)cap_pairs * 4));
+  PM_TRY(grow(h->n_ops, (size_t)cap_pairs * 4));
+  PM_TRY(grow(h->ops, (size_t)(cap_a + cap_b)));
+  return PM_OK;
+}
+
+int dp_batch_load(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
+                  int64_t n_pairs, hipStream_t stream) {
+  const int64_t a0 = off_a[0], b0 = off_b[0];
+  for(int64_t k = 0; k < n_pairs; ++k) {
+    if(off_a[k + 1] < off_a[k] || off_b[k + 1] < off_b[k] || off_a[k + 1] - off_a[k] > (1 << 24) || off_b[k + 1] - off_b[k] > (1 << 24)) {
+      return fail(PM_E_INVALID, "pm_dp_batch_create: bad profile length");
+    }
+    if((off_a[k + 1] - off_a[k] + off_b[k + 1] - off_b[k]) * (int64_t)h->params.ge >= (1 << 28)) {
+      return fail(PM_E_INVALID, "pm_dp_batch_create: (La + Lb) * gap_extend must stay below 2^28");
+    }
+  }
+  h->n_pairs = n_pairs;
+  h->seg_first.clear();
+  h->seg_events_armed = false;
+  h->off_a.resize((size_t)n_pairs + 1);
+  h->off_b.resize((size_t)n_pairs + 1);
+  for(int64_t k = 0; k <= n_pairs; ++k) {
+    h->off_a[(size_t)k] = off_a[k] - a0;
+    h->off_b[(size_t)k] = off_b[k] - b0;
+  }
+  h->total_a = h->off_a[(size_t)n_pairs];
+  h->total_b = h->off_b[(size_t)n_pairs];
+  if((h->total_a > 0 && !cols_a) || (h->total_b > 0 && !cols_b)) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: null columns");
+  }
+  PM_TRY(dp_batch_reserve(h, n_pairs, h->total_a, h->total_b));
+  // the offsets go through pinned staging when the batch has it (so that the copy is asynchronous), else straight from the vectors
+  const i64 *src_a = h->off_a.data(), *src_b = h->off_b.data();
+  if(h->pinned && h->pinned_bytes >= (size_t)(3 * (n_pairs + 1)) * 8 + 64) {
+    i64 *pa = (i64 *)h->pinned, *pb = pa + (n_pairs + 1);
+    memcpy(pa, src_a, (size_t)(n_pairs + 1) * 8);
+    memcpy(pb, src_b, (size_t)(n_pairs + 1) * 8);
+    src_a = pa;
+    src_b = pb;
+  }
+  PM_HIP(hipMemcpyAsync(h->d_off_a.p, src_a, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
+  PM_HIP(hipMemcpyAsync(h->d_off_b.p, src_b, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
+  if(h->total_a > 0) {
+    PM_HIP(hipMemcpyAsync(h->cols_a.p, cols_a + a0 * 8, (size_t)h->total_a * 8, hipMemcpyHostToDevice, stream));
+  }
+  if(h->total_b > 0) {
+    PM_HIP(hipMemcpyAsync(h->cols_b.p, cols_b + b0 * 8, (size_t)h->total_b * 8, hipMemcpyHostToDevice, stream));
+  }
+  // the ranges of the uploaded columns, found on the device (four 4-byte words back)
+  PM_HIP(hipMemsetAsync(h->stats.p, 0, 16, stream));
+  if(h->total_a > 0) {
+    dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_a.p, h->total_a, (int *)h->stats.p);
+  }
+  if(h->total_b > 0) {
+    dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_b.p, h->total_b, (int *)h->stats.p + 2);
+  }
+  PM_HIP(hipGetLastError());
+  int *dst = h->host_stats;
+  if(h->pinned) {
+    dst = (int *)((char *)h->pinned + h->pinned_bytes - 16);
+  }
+  PM_HIP(hipMemcpyAsync(dst, h->stats.p, 16, hipMemcpyDeviceToHost, stream));
+  return PM_OK;
+}
+
+int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
+                           int64_t n_pairs, int segments, int *stats_first, hipStream_t stream) {
+  const int64_t a0 = off_a[0], b0 = off_b[0];
+  for(int64_t k = 0; k < n_pairs; ++k) {
+    if(off_a[k + 1] < off_a[k] || off_b[k + 1] < off_b[k] || off_a[k + 1] - off_a[k] > (1 << 24) || off_b[k + 1] - off_b[k] > (1 << 24)) {
+      return fail(PM_E_INVALID, "pm_dp_batch_create: bad profile length");
+    }
+    if((off_a[k + 1] - off_a[k] + off_b[k + 1] - off_b[k]) * (int64_t)h->params.ge >= (1 << 28)) {
+      return fail(PM_E_INVALID, "pm_dp_batch_create: (La + Lb) * gap_extend must stay below 2^28");
+    }
+  }
+  h->n_pairs = n_pairs;
+  h->off_a.resize((size_t)n_pairs + 1);
+  h->off_b.resize((size_t)n_pairs + 1);
+  for(int64_t k = 0; k <= n_pairs; ++k) {
+    h->off_a[(size_t)k] = off_a[k] - a0;
+    h->off_b[(size_t)k] = off_b[k] - b0;
+  }
+  h->total_a = h->off_a[(size_t)n_pairs];
+  h->total_b = h->off_b[(size_t)n_pairs];
+  if((h->total_a > 0 && !cols_a) || (h->total_b > 0 && !cols_b)) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: null columns");
+  }
+  PM_TRY(dp_batch_reserve(h, n_pairs, h->total_a, h->total_b));
+  if(!h->pinned || h->pinned_bytes < (size_t)(3 * (n_pairs + 1)) * 8 + 64 + 16) { // offsets, workspace offsets, statistics
+    if(h->pinned) {
+      (void)hipHostFree(h->pinned);
+      h->pinned = nullptr;
+    }
+    h->pinned_bytes = (size_t)(3 * (n_pairs + 1)) * 8 + 64 + 16;
+    PM_HIP(hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault));
+  }
+  i64 *pa = (i64 *)h->pinned, *pb = pa + (n_pairs + 1);
+  memcpy(pa, h->off_a.data(), (size_t)(n_pairs + 1) * 8);
+  memcpy(pb, h->off_b.data(), (size_t)(n_pairs + 1) * 8);
+  PM_HIP(hipMemcpyAsync(h->d_off_a.p, pa, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
+  PM_HIP(hipMemcpyAsync(h->d_off_b.p, pb, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
+  PM_HIP(hipMemsetAsync(h->stats.p, 0, 16, stream));
+  // segments of about equal numbers of columns (A + B), cut at pair boundaries
+  segments = (int)std::max<int64_t>(1, std::min<int64_t>(segments, std::max<int64_t>(n_pairs, 1)));
+  h->seg_first.assign(1, 0);
   {
-    // the ranges of the uploaded columns, found on the device (two 4-byte words back)
-    DevBuf stats;
-    DTRY(stats.alloc(16));
-    int st[4] = {0, 0, 0, 0};
-    if(hipMemset(stats.p, 0, 16) != hipSuccess) {
-      pm_dp_batch_destroy(h);
-      return fail(PM_E_HIP, "hipMemset failed");
-    }
-    if(h->total_a > 0) {
-      dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_a.p, h->total_a, (int *)stats.p);
-    }
-    if(h->total_b > 0) {
-      dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_b.p, h->total_b, (int *)stats.p + 2);
-    }
-    if(hipGetLastError() != hipSuccess || hipMemcpy(st, stats.p, 16, hipMemcpyDeviceToHost) != hipSuccess) {
-      pm_dp_batch_destroy(h);
-      return fail(PM_E_HIP, "column statistics failed");
-    }
-    const int max_a = st[0], max_colsum_b = st[3];
-    if((int64_t)max_colsum_b * max_sub_all > 32767) { // the column weights are int16 lanes of v_dot2_i32_i16
-      pm_dp_batch_destroy(h);
-      return fail(PM_E_INVALID, "pm_dp_batch_create: (rows of a column of B) x max|sub| exceeds 32767");
-    }
-    // every score the kernel carries must stay within +-2^28 (the skewed H~ = H + (i + j) * gap_extend as well, and the
-    // decision bits are signs of 32-bit differences against the -2^29 sentinel): bound the largest magnitude any cell can
-    // reach from the column statistics and refuse the batch otherwise
-    {
-      const int64_t max_colsum_a = st[1];
-      int64_t worst = 0;
-      for(int64_t k = 0; k < n_pairs; ++k) {
-        const int64_t la = off_a[k + 1] - off_a[k], lb = off_b[k + 1] - off_b[k];
-        const int64_t m = max_colsum_a * max_colsum_b * max_sub_all * std::min(la, lb) + (la + lb) * (int64_t)params->gap_extend +
-                          2 * (int64_t)params->gap_open;
-        worst = std::max(worst, m);
+    const i64 total = h->total_a + h->total_b;
+    for(int sgi = 1; sgi < segments; ++sgi) {
+      const i64 want = total * sgi / segments;
+      i64 k = h->seg_first.back();
+      while(k < n_pairs && h->off_a[(size_t)k] + h->off_b[(size_t)k] < want) {
+        ++k;
       }
-      if(worst >= ((int64_t)1 << 28)) {
-        pm_dp_batch_destroy(h);
-        return fail(PM_E_INVALID, "pm_dp_batch_create: scores could leave +-2^28 (rows(A) x rows(B) x max|sub| x min(La, Lb) + (La + Lb) x gap_extend "
-                                  "+ 2 x gap_open too large)");
+      if(k > h->seg_first.back() && k < n_pairs) {
+        h->seg_first.push_back(k);
       }
     }
-    h->dot4 = max_a <= 127 && max_colsum_b * max_sub_acgt <= 127;
-    if(const char *e = getenv("PM_DP_DOT4")) {
-      h->dot4 = h->dot4 && atoi(e) != 0;
+    h->seg_first.push_back(n_pairs);
+  }
+  const size_t nseg = h->seg_first.size() - 1;
+  while(h->ev_seg.size() < nseg) {
+    hipEvent_t e = nullptr;
+    PM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->ev_seg.push_back(e);
+  }
+  for(size_t sgi = 0; sgi < nseg; ++sgi) {
+    const i64 lo = h->seg_first[sgi], hi = h->seg_first[sgi + 1];
+    const i64 sa0 = h->off_a[(size_t)lo], sa1 = h->off_a[(size_t)hi], sb0 = h->off_b[(size_t)lo], sb1 = h->off_b[(size_t)hi];
+    if(sa1 > sa0) {
+      PM_HIP(hipMemcpyAsync((char *)h->cols_a.p + sa0 * 8, cols_a + (a0 + sa0) * 8, (size_t)(sa1 - sa0) * 8, hipMemcpyHostToDevice, stream));
+      dp_column_stats_kernel<<<256, 256, 0, stream>>>((const u64 *)h->cols_a.p + sa0, sa1 - sa0, (int *)h->stats.p);
+    }
+    if(sb1 > sb0) {
+      PM_HIP(hipMemcpyAsync((char *)h->cols_b.p + sb0 * 8, cols_b + (b0 + sb0) * 8, (size_t)(sb1 - sb0) * 8, hipMemcpyHostToDevice, stream));
+      dp_column_stats_kernel<<<256, 256, 0, stream>>>((const u64 *)h->cols_b.p + sb0, sb1 - sb0, (int *)h->stats.p + 2);
+    }
+    PM_HIP(hipGetLastError());
+    if(sgi == 0 && stats_first) {
+      PM_HIP(hipMemcpyAsync(stats_first, h->stats.p, 16, hipMemcpyDeviceToHost, stream));
+    }
+    if(sgi + 1 == nseg) {
+      PM_HIP(hipMemcpyAsync((char *)h->pinned + h->pinned_bytes - 16, h->stats.p, 16, hipMemcpyDeviceToHost, stream));
+    }
+    PM_HIP(hipEventRecord(h->ev_seg[sgi], stream));
+  }
+  h->seg_events_armed = true;
+  return PM_OK;
+}
+
+int dp_batch_plan(pm_dp_batch *h, hipStream_t stream) {
+  return dp_batch_plan_with(h, h->pinned ? (const int *)((char *)h->pinned + h->pinned_bytes - 16) : h->host_stats, stream);
+}
+
+int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
+  const i64 n_pairs = h->n_pairs;
+  const int max_a = st[0], max_colsum_b = st[3];
+  if((int64_t)max_colsum_b * h->max_sub_all > 32767) { // the column weights are int16 lanes of v_dot2_i32_i16
+    return fail(PM_E_INVALID, "pm_dp_batch_create: (rows of a column of B) x max|sub| exceeds 32767");
+  }
+  // every score the kernel carries must stay within +-2^28 (the skewed H~ = H + (i + j) * gap_extend as well, and the
+  // decision bits are signs of 32-bit differences against the -2^29 sentinel): bound the largest magnitude any cell can
+  // reach from the column statistics and refuse the batch otherwise
+  {
+    const int64_t max_colsum_a = st[1];
+    int64_t worst = 0;
+    for(int64_t k = 0; k < n_pairs; ++k) {
+      const int64_t la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+      const int64_t m = max_colsum_a * max_colsum_b * h->max_sub_all * std::min(la, lb) + (la + lb) * (int64_t)h->params.ge +
+                        2 * (int64_t)h->params.go;
+      worst = std::max(worst, m);
+    }
+    if(worst >= ((int64_t)1 << 28)) {
+      return fail(PM_E_INVALID, "pm_dp_batch_create: scores could leave +-2^28 (rows(A) x rows(B) x max|sub| x min(La, Lb) + (La + Lb) x gap_extend "
+                                "+ 2 x gap_open too large)");
     }
   }
-  DTRY(h->bnd.alloc((size_t)h->total_a * 8));
-  DTRY(h->scores.alloc((size_t)n_pairs * 4));
-  DTRY(h->pipe_error.alloc(4));
-  if(hipMemset(h->pipe_error.p, 0, 4) != hipSuccess) {
-    pm_dp_batch_destroy(h);
-    return fail(PM_E_HIP, "hipMemset failed");
+  h->dot4 = max_a <= 127 && max_colsum_b * h->max_sub_acgt <= 127;
+  if(const char *e = getenv("PM_DP_DOT4")) {
+    h->dot4 = h->dot4 && atoi(e) != 0;
   }
-  DTRY(h->n_ops.alloc((size_t)n_pairs * 4));
-  DTRY(h->ops.alloc((size_t)(h->total_a + h->total_b)));
   // chunks: consecutive pairs whose workspace fits the budget.  A batch that fits is one chunk; otherwise the budget is cut
   // in two halves that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernel
   // of the next (dp_run)
-  if(tb_budget_bytes <= 0) {
-    tb_budget_bytes = (int64_t)32 << 30;
-  }
   auto need_words = [&](i64 k) {
-    i64 la = off_a[k + 1] - off_a[k], lb = off_b[k + 1] - off_b[k];
+    i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
     return h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane) : dp_tb_words(la, lb, h->cols_per_lane);
   };
   i64 total_words = 0;
+  h->cells = 0;
   for(i64 k = 0; k < n_pairs; ++k) {
     total_words += need_words(k);
-    h->cells += (off_a[k + 1] - off_a[k]) * (off_b[k + 1] - off_b[k]);
+    h->cells += (h->off_a[k + 1] - h->off_a[k]) * (h->off_b[k + 1] - h->off_b[k]);
   }
-  const bool one_chunk = total_words <= tb_budget_bytes / 4;
-  i64 budget_words = one_chunk ? tb_budget_bytes / 4 : tb_budget_bytes / 8;
-  h->chunk_first.push_back(0);
+  const bool one_chunk = total_words <= h->tb_budget_bytes / 4;
+  const i64 budget_words = one_chunk ? h->tb_budget_bytes / 4 : h->tb_budget_bytes / 8;
+  h->chunk_first.assign(1, 0);
+  h->chunk_tb.clear();
+  h->tb_words_cap = 0;
   std::vector<i64> cur;
   i64 used = 0;
   for(i64 k = 0; k < n_pairs; ++k) {
@@ -633,38 +697,93 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   h->tb_words_cap = std::max(h->tb_words_cap, used);
   const bool pipelined = h->chunk_tb.size() > 1;
   h->tb_half_words = pipelined ? ((h->tb_words_cap + 63) / 64) * 64 : 0;
-  DTRY(h->tb.alloc((size_t)(pipelined ? 2 * h->tb_half_words : h->tb_words_cap) * 4));
+  PM_TRY(grow(h->tb, (size_t)(pipelined ? 2 * h->tb_half_words : h->tb_words_cap) * 4));
   if(pipelined) {
-    if(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking) != hipSuccess) {
-      pm_dp_batch_destroy(h);
-      return fail(PM_E_HIP, "hipStreamCreate failed");
+    if(!h->path_stream) {
+      PM_HIP(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking));
     }
-    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+    while(h->ev_fill.size() < h->chunk_tb.size()) {
       hipEvent_t a = nullptr, b = nullptr;
-      if(hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
-        pm_dp_batch_destroy(h);
-        return fail(PM_E_HIP, "hipEventCreate failed");
-      }
+      PM_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
       h->ev_fill.push_back(a);
+      PM_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
       h->ev_path.push_back(b);
     }
   }
   // per-chunk offset tables live back to back in one device array
   {
-    std::vector<i64> flat;
-    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
-      flat.insert(flat.end(), h->chunk_tb[c].begin(), h->chunk_tb[c].end());
+    i64 *flat = nullptr;
+    std::vector<i64> tmp;
+    if(h->pinned && h->pinned_bytes >= (size_t)(3 * (n_pairs + 1)) * 8 + 64) {
+      flat = (i64 *)h->pinned + 2 * (n_pairs + 1);
     }
-    DTRY(h->d_tb_off.upload(flat.data(), flat.size() * 8, stream));
+    else {
+      tmp.resize((size_t)std::max<i64>(n_pairs, 1));
+      flat = tmp.data();
+    }
+    size_t at = 0;
+    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+      for(i64 v : h->chunk_tb[c]) {
+        flat[at++] = v;
+      }
+    }
+    if(at > 0) {
+      if(tmp.empty()) {
+        PM_HIP(hipMemcpyAsync(h->d_tb_off.p, flat, at * 8, hipMemcpyHostToDevice, stream));
+      }
+      else { // pageable source: a blocking copy, the vector dies with this scope
+        PM_HIP(hipStreamSynchronize(stream));
+        PM_HIP(hipMemcpy(h->d_tb_off.p, flat, at * 8, hipMemcpyHostToDevice));
+      }
+    }
   }
-#undef DTRY
+  return PM_OK;
+}
+
+} // namespace pm
+
+extern "C" {
+
+int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
+                       const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out) {
+  if(!out) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: null out");
+  }
+  *out = nullptr;
+  if(n_pairs < 0 || !off_a || !off_b || !params) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: null argument");
+  }
+  PM_TRY(use_device(device));
+  if(off_a[0] != 0 || off_b[0] != 0) {
+    return fail(PM_E_INVALID, "pm_dp_batch_create: offsets must start at 0");
+  }
+  PM_TRY(dp_batch_check_params(params));
+  pm_dp_batch *h = new(std::nothrow) pm_dp_batch();
+  if(!h) {
+    return fail(PM_E_INVALID, "out of host memory");
+  }
+  int rc = dp_batch_init(h, params, tb_budget_bytes, device);
+  if(!rc) {
+    rc = dp_batch_load(h, cols_a, off_a, cols_b, off_b, n_pairs, nullptr);
+  }
+  if(!rc && hipStreamSynchronize(nullptr) != hipSuccess) {
+    rc = fail(PM_E_HIP, "upload failed");
+  }
+  if(!rc) {
+    rc = dp_batch_plan(h, nullptr);
+  }
+  if(rc) {
+    pm_dp_batch_destroy(h);
+    return rc;
+  }
   *out = h;
   return PM_OK;
 }
 
+} // extern "C"
+
 // The fill kernel of chunk c into workspace `tbw`.
-static int dp_launch_fill(pm_dp_batch *h, size_t c, unsigned *tbw, int traceback, hipStream_t stream) {
-  const i64 first = h->chunk_first[c], n = h->chunk_first[c + 1] - first;
+static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int traceback, hipStream_t stream) {
   const i64 *tb_off = (const i64 *)h->d_tb_off.p + first;
   // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
   // have several stripes to pipeline
@@ -773,10 +892,13 @@ static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStre
 // on the batch's own stream, chunk c's path beside chunk c + 1's fill (the two halves of the workspace alternate); `stream`
 // ends up waiting for the last path kernels, so the caller sees one asynchronous operation on its stream.
 // Timed: device time of the fill and of the path kernels, summed over the chunks (events around every launch on its stream).
-static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_path) {
+namespace pm {
+int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_path) {
   const size_t nc = h->chunk_tb.size();
   const bool timed = ms_fill || ms_path;
   const bool pipelined = nc > 1 && h->path_stream && traceback;
+  const bool ext = !pipelined && nc == 1 && traceback && h->ext_path_stream && h->ev_ext_fill && h->ev_ext_path;
+  h->ext_path_used = ext;
   if(timed && h->tv_fill0.size() < nc) {
     for(std::vector<hipEvent_t> *v : {&h->tv_fill0, &h->tv_fill1, &h->tv_path0, &h->tv_path1}) {
       while(v->size() < nc) {
@@ -792,14 +914,32 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
       continue;
     }
     unsigned *tbw = tb + (h->tb_half_words ? (c & 1) * h->tb_half_words : 0);
-    hipStream_t ps = pipelined ? h->path_stream : stream;
+    hipStream_t ps = pipelined ? h->path_stream : (ext ? h->ext_path_stream : stream);
     if(pipelined && c >= 2) {
       PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c - 2], 0)); // the half is free again
     }
     if(timed) {
       PM_HIP(hipEventRecord(h->tv_fill0[c], stream));
     }
-    PM_TRY(dp_launch_fill(h, c, tbw, traceback, stream));
+    // the chunk's pairs, one launch per upload segment (a batch that was loaded in one piece has none: one launch)
+    {
+      const i64 c_lo = h->chunk_first[c], c_hi = h->chunk_first[c + 1];
+      i64 at = c_lo;
+      for(size_t sg = 0; sg + 1 < h->seg_first.size() && at < c_hi; ++sg) {
+        const i64 s_hi = std::min(h->seg_first[sg + 1], c_hi);
+        if(s_hi <= at) {
+          continue;
+        }
+        if(sg < h->ev_seg.size() && h->seg_events_armed) {
+          PM_HIP(hipStreamWaitEvent(stream, h->ev_seg[sg], 0)); // the segment's columns are in HBM
+        }
+        PM_TRY(dp_launch_fill(h, at, s_hi - at, tbw, traceback, stream));
+        at = s_hi;
+      }
+      if(at < c_hi) {
+        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream));
+      }
+    }
     if(timed) {
       PM_HIP(hipEventRecord(h->tv_fill1[c], stream));
     }
@@ -807,6 +947,10 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
       if(pipelined) {
         PM_HIP(hipEventRecord(h->ev_fill[c], stream));
         PM_HIP(hipStreamWaitEvent(ps, h->ev_fill[c], 0));
+      }
+      if(ext) {
+        PM_HIP(hipEventRecord(h->ev_ext_fill, stream));
+        PM_HIP(hipStreamWaitEvent(ps, h->ev_ext_fill, 0));
       }
       if(timed) {
         PM_HIP(hipEventRecord(h->tv_path0[c], ps));
@@ -817,6 +961,9 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
       }
       if(pipelined) {
         PM_HIP(hipEventRecord(h->ev_path[c], ps));
+      }
+      if(ext) {
+        PM_HIP(hipEventRecord(h->ev_ext_path, ps));
       }
     }
   }
@@ -850,6 +997,9 @@ static int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_f
   }
   return PM_OK;
 }
+} // namespace pm
+
+extern "C" {
 
 int pm_dp_batch_run(pm_dp_batch_t *h, int traceback, void *hip_stream) {
   if(!h) {

@@ -59,16 +59,14 @@ __global__ void dp_pack_kernel(i64 n_cols, i64 n_blocks, const i64 *__restrict__
   cols[g] = acc;
 }
 
-// flags for the scans: a[k] = op k consumes a column of A (M or D), b[k] = of B (M or I)
-__global__ void dp_op_flags_kernel(i64 n, const unsigned char *__restrict__ ops, int *__restrict__ fa, int *__restrict__ fb, int *bad) {
+// flags for the scans: a[k] = op k consumes a column of A (M or D), b[k] = of B (M or I).  Bytes between two paths (the unused
+// heads of pm_dp_batch_fetch's slots) get flags too; only differences inside one path are ever used.
+__global__ void dp_op_flags_kernel(i64 n, const unsigned char *__restrict__ ops, int *__restrict__ fa, int *__restrict__ fb) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(g >= n) {
     return;
   }
   const unsigned char op = ops[g];
-  if(op > 2) {
-    atomicOr(bad, 1);
-  }
   fa[g] = op != 1;
   fb[g] = op != 2;
 }
@@ -89,6 +87,9 @@ __global__ void dp_emit_kernel(i64 n_out, i64 n_pairs, const i64 *__restrict__ o
   const i64 r = (g - out_off[p]) / len, k = (g - out_off[p]) % len;
   const i64 o = ops_off[p] + k;
   const unsigned char op = ops[o];
+  if(op > 2) {
+    atomicOr(bad, 1);
+  }
   const i64 ra = block_row_a[p + 1] - block_row_a[p];
   unsigned char ch = '-';
   if(r < ra) {
@@ -331,8 +332,7 @@ int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_ro
   PM_TRY(d_out.alloc((size_t)n_out));
   PM_TRY(d_bad.alloc(4));
   PM_HIP(hipMemset(d_bad.p, 0, 4));
-  dp_op_flags_kernel<<<(unsigned)((ops_end + 255) / 256), 256>>>(ops_end, (const unsigned char *)d_ops.p, (int *)d_fa.p, (int *)d_fb.p,
-                                                                 (int *)d_bad.p);
+  dp_op_flags_kernel<<<(unsigned)((ops_end + 255) / 256), 256>>>(ops_end, (const unsigned char *)d_ops.p, (int *)d_fa.p, (int *)d_fb.p);
   PM_HIP(hipGetLastError());
   size_t tmp_bytes = 0;
   PM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));

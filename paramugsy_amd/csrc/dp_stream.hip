@@ -1,0 +1,197 @@
+// dp_stream.hip -- the profile DP fed from host memory: the columns of a batch go up in segments on one HIP stream while the
+// fill kernel already runs on the segments that have arrived, and the results come back on a third stream (gfx950).
+//
+// NO REFERENCE COUNTERPART.  pm_dp_batch_* keeps a batch resident in HBM (that is what bench.py's `value`
+// measures); a caller that starts from host buffers pays upload -> kernels -> download one after the other there.  Here one
+// reusable batch is loaded in `segments` pieces of consecutive pairs:
+//     upload stream    offsets, then per segment its columns + the column-statistics kernel + an event
+//     compute stream   dp_fill_kernel per segment, each behind its segment's event; then ONE path kernel per workspace chunk
+//                      (its latency-bound chain is paid once per chunk, not once per segment)
+//     download stream  scores, paths and path lengths into the caller's arrays (same layout as pm_dp_batch_fetch)
+// The kernel variant (int8 or int16 column weights) depends on the largest counts in the data, which only the device sees:
+// it is chosen from the first segment's statistics and checked against the whole batch's once the last segment is up; a batch
+// whose later segments break the choice is simply run again (rare: the counts of a batch's profiles are alike).
+// Copies are asynchronous only from / to pinned host memory (pm_dp_host_alloc).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "dp_batch.hpp"
+
+using namespace pm;
+
+struct pm_dp_stream {
+  int device = 0;
+  int segments = 4;
+  pm_dp_batch *b = nullptr;
+  hipStream_t up = nullptr, comp = nullptr, down = nullptr;
+  hipEvent_t ev_comp = nullptr;
+  int *host_words = nullptr; // pinned: [0..3] statistics of the first segment, [4] the fill kernel's pipe error
+  ~pm_dp_stream() {
+    delete b;
+    if(ev_comp) {
+      (void)hipEventDestroy(ev_comp);
+    }
+    for(hipStream_t s : {up, comp, down}) {
+      if(s) {
+        (void)hipStreamDestroy(s);
+      }
+    }
+    if(host_words) {
+      (void)hipHostFree(host_words);
+    }
+  }
+};
+
+extern "C" {
+
+int pm_dp_host_alloc(void **ptr, int64_t bytes) {
+  if(!ptr || bytes < 0) {
+    return fail(PM_E_INVALID, "pm_dp_host_alloc: bad argument");
+  }
+  *ptr = nullptr;
+  PM_HIP(hipHostMalloc(ptr, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocDefault));
+  return PM_OK;
+}
+
+void pm_dp_host_free(void *ptr) {
+  if(ptr) {
+    (void)hipHostFree(ptr);
+  }
+}
+
+int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t workspace_bytes, int device, pm_dp_stream_t **out) {
+  if(!out) {
+    return fail(PM_E_INVALID, "pm_dp_stream_create: null out");
+  }
+  *out = nullptr;
+  if(!params || segments < 1) {
+    return fail(PM_E_INVALID, "pm_dp_stream_create: bad argument");
+  }
+  PM_TRY(use_device(device));
+  PM_TRY(dp_batch_check_params(params));
+  pm_dp_stream *s = new(std::nothrow) pm_dp_stream();
+  if(!s) {
+    return fail(PM_E_INVALID, "out of host memory");
+  }
+  s->device = device;
+  s->segments = segments;
+  int rc = PM_OK;
+  auto hipok = [&](hipError_t e, const char *what) {
+    if(e != hipSuccess && !rc) {
+      rc = fail(PM_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+  };
+  for(hipStream_t *st : {&s->up, &s->comp, &s->down}) {
+    hipok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
+  }
+  hipok(hipEventCreateWithFlags(&s->ev_comp, hipEventDisableTiming), "hipEventCreate");
+  hipok(hipHostMalloc((void **)&s->host_words, 8 * sizeof(int), hipHostMallocDefault), "hipHostMalloc");
+  s->b = new(std::nothrow) pm_dp_batch();
+  if(!s->b && !rc) {
+    rc = fail(PM_E_INVALID, "out of host memory");
+  }
+  if(!rc) {
+    rc = dp_batch_init(s->b, params, workspace_bytes, device);
+  }
+  if(rc) {
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return PM_OK;
+}
+
+int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
+                       int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
+  if(!s || n_pairs < 0 || !off_a || !off_b || !scores) {
+    return fail(PM_E_INVALID, "pm_dp_stream_align: null argument");
+  }
+  if((ops == nullptr) != (n_ops == nullptr)) {
+    return fail(PM_E_INVALID, "pm_dp_stream_align: ops and n_ops go together");
+  }
+  PM_TRY(use_device(s->device));
+  if(n_pairs == 0) {
+    return PM_OK;
+  }
+  pm_dp_batch *b = s->b;
+  const int traceback = ops != nullptr;
+  int rc = dp_batch_load_segments(b, cols_a, off_a, cols_b, off_b, n_pairs, s->segments, s->host_words, s->up);
+  auto drain = [&]() {
+    for(hipStream_t st : {s->up, s->comp, s->down}) {
+      hipError_t e = hipStreamSynchronize(st);
+      if(e != hipSuccess && !rc) {
+        rc = fail(PM_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+      }
+    }
+    if(b->path_stream) {
+      (void)hipStreamSynchronize(b->path_stream);
+    }
+  };
+  auto run_and_fetch = [&]() {
+    int r = dp_run(b, s->comp, traceback, nullptr, nullptr);
+    if(r) {
+      return r;
+    }
+    PM_HIP(hipEventRecord(s->ev_comp, s->comp));
+    PM_HIP(hipStreamWaitEvent(s->down, s->ev_comp, 0));
+    PM_HIP(hipMemcpyAsync(scores, b->scores.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s->down));
+    if(traceback) {
+      PM_HIP(hipMemcpyAsync(n_ops, b->n_ops.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s->down));
+      if(b->total_a + b->total_b > 0) {
+        PM_HIP(hipMemcpyAsync(ops, b->ops.p, (size_t)(b->total_a + b->total_b), hipMemcpyDeviceToHost, s->down));
+      }
+    }
+    PM_HIP(hipMemcpyAsync(&s->host_words[4], b->pipe_error.p, 4, hipMemcpyDeviceToHost, s->down));
+    return (int)PM_OK;
+  };
+  if(!rc) {
+    // the first segment's statistics choose the kernel variant; its fill kernel starts while the other segments are on their way
+    hipError_t e = hipEventSynchronize(b->ev_seg[0]);
+    if(e != hipSuccess) {
+      rc = fail(PM_E_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+    }
+  }
+  if(!rc) {
+    rc = dp_batch_plan_with(b, s->host_words, s->comp);
+  }
+  bool first_dot4 = false;
+  if(!rc) {
+    first_dot4 = b->dot4;
+    rc = run_and_fetch();
+  }
+  if(!rc) {
+    // the whole batch's statistics: refuse what pm_dp_batch_create refuses, and run again if they change the variant
+    hipError_t e = hipStreamSynchronize(s->up);
+    if(e != hipSuccess) {
+      rc = fail(PM_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+  }
+  if(!rc) {
+    rc = dp_batch_plan(b, s->comp);
+    if(!rc && b->dot4 != first_dot4) {
+      drain();
+      if(!rc) {
+        rc = run_and_fetch();
+      }
+    }
+  }
+  drain();
+  if(!rc && s->host_words[4]) {
+    rc = fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
+  }
+  return rc;
+}
+
+void pm_dp_stream_destroy(pm_dp_stream_t *s) {
+  if(!s) {
+    return;
+  }
+  (void)hipSetDevice(s->device);
+  delete s;
+}
+
+} // extern "C"

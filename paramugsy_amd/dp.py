@@ -83,6 +83,13 @@ def _lib():
         l.pm_dp_align_maf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PmDpParams), C.c_char_p, C.c_int]
         l.pm_dp_batch_destroy.argtypes = [C.c_void_p]
         l.pm_dp_batch_destroy.restype = None
+        l.pm_dp_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64]
+        l.pm_dp_host_free.argtypes = [C.c_void_p]
+        l.pm_dp_host_free.restype = None
+        l.pm_dp_stream_create.argtypes = [C.POINTER(PmDpParams), C.c_int32, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        l.pm_dp_stream_align.argtypes = [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 3
+        l.pm_dp_stream_destroy.argtypes = [C.c_void_p]
+        l.pm_dp_stream_destroy.restype = None
         l._dp_bound = True
     return l
 
@@ -174,6 +181,78 @@ class DpBatch:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------- the DP fed from host memory (pm_dp_stream_*)
+
+class PinnedArray:
+    """A numpy array over pinned host memory from pm_dp_host_alloc (copies from / to it are asynchronous).  Keep the object alive
+    while `.a` is in use; close() frees the memory."""
+
+    def __init__(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = C.c_void_p()
+        capi.check(_lib().pm_dp_host_alloc(C.byref(self._p), n))
+        buf = (C.c_uint8 * max(n, 1)).from_address(self._p.value)
+        self.a = np.frombuffer(buf, dtype=np.uint8, count=n).view(dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.a = None
+            _lib().pm_dp_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DpStream:
+    """A batch from host memory: uploaded in segments while the fill kernel already runs on those that have arrived; results
+    back on a third stream (pm_dp_stream_*)."""
+
+    def __init__(self, params: PmDpParams, segments: int = 4, workspace_bytes: int = 0, device: int = 0):
+        h = C.c_void_p()
+        capi.check(_lib().pm_dp_stream_create(C.byref(params), segments, workspace_bytes, device, C.byref(h)))
+        self._h = h
+
+    def align(self, inputs: DpInputs, scores: np.ndarray = None, ops: np.ndarray = None, n_ops: np.ndarray = None, with_paths: bool = True):
+        """Returns (scores, ops, n_ops) in pm_dp_batch_fetch's layout; pass pinned output arrays to keep the downloads asynchronous."""
+        n = inputs.n_pairs
+        oa = np.ascontiguousarray(inputs.off_a, dtype=np.int64)
+        ob = np.ascontiguousarray(inputs.off_b, dtype=np.int64)
+        ca = inputs.cols_a if inputs.cols_a.flags.c_contiguous else np.ascontiguousarray(inputs.cols_a)
+        cb = inputs.cols_b if inputs.cols_b.flags.c_contiguous else np.ascontiguousarray(inputs.cols_b)
+        if scores is None:
+            scores = np.zeros(n, dtype=np.int32)
+        if with_paths and ops is None:
+            ops = np.zeros(max(1, int(oa[-1] + ob[-1])), dtype=np.uint8)
+            n_ops = np.zeros(n, dtype=np.int32)
+        capi.check(_lib().pm_dp_stream_align(self._h, ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, n, scores.ctypes.data,
+                                             ops.ctypes.data if with_paths else None, n_ops.ctypes.data if with_paths else None))
+        return scores, ops, n_ops
+
+    def close(self) -> None:
+        if self._h:
+            _lib().pm_dp_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def paths_of(inputs: DpInputs, ops: np.ndarray, n_ops: np.ndarray) -> List[np.ndarray]:
+    """Per-pair op arrays (first op first) from the right-aligned slots of pm_dp_batch_fetch / pm_dp_stream_align."""
+    out = []
+    for k in range(len(n_ops)):
+        end = int(inputs.off_a[k + 1] + inputs.off_b[k + 1])
+        out.append(ops[end - int(n_ops[k]):end])
+    return out
 
 
 # ---------------------------------------------------------------- MAF blocks in and out (pm_dp_pack_maf / pm_dp_emit_maf)

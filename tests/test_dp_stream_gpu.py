@@ -1,0 +1,102 @@
+"""pm_dp_stream_*: a batch uploaded in segments with the fill kernel running behind the uploads must give exactly what the
+resident batch (pm_dp_batch_*) gives -- which the other tests pin to the scalar oracle -- whatever the number of segments."""
+import numpy as np
+import pytest
+
+from paramugsy_amd import dp
+
+pytestmark = pytest.mark.gpu
+
+
+def resident(inputs, params):
+    b = dp.DpBatch(inputs, params)
+    b.run(True)
+    scores, ops, n_ops = b.fetch()
+    b.close()
+    return scores, ops, n_ops
+
+
+@pytest.mark.parametrize("segments", [1, 2, 5, 17, 1000])
+def test_stream_equals_resident_batch_on_ragged_pairs(segments, oracle_build):
+    import pyoracle
+    la, lb = dp.ragged_lengths(5, 60, median=400, sigma=0.7, lo=1, hi=2500)
+    la[3], lb[3] = 0, 17
+    la[4], lb[4] = 9, 0
+    inputs = dp.synth_batch(6, la, lb, 3, 3)
+    params = dp.make_params(3, 3)
+    r_scores, r_ops, r_nops = resident(inputs, params)
+    st = dp.DpStream(params, segments)
+    for _ in range(2):  # the slots are reused: a second pass over the same engine
+        scores, ops, n_ops = st.align(inputs)
+        assert np.array_equal(scores, r_scores) and np.array_equal(n_ops, r_nops)
+        for p, q in zip(dp.paths_of(inputs, ops, n_ops), dp.paths_of(inputs, r_ops, r_nops)):
+            assert np.array_equal(p, q)
+    s_only, _, _ = st.align(inputs, with_paths=False)
+    assert np.array_equal(s_only, r_scores)
+    st.close()
+    o_scores, o_paths = pyoracle.dp_align(inputs, params)
+    assert np.array_equal(r_scores, o_scores)
+
+
+def test_stream_with_pinned_buffers_and_several_workspace_chunks(oracle_build):
+    """Pinned inputs and outputs (the asynchronous case) and a workspace so small that the batch takes several chunks, each of
+    them spanning several upload segments."""
+    n, rows, L = 600, 2, 500
+    src = dp.synth_pairs_fast(11, n, rows, L)
+    params = dp.make_params(rows, rows)
+    r_scores, r_ops, r_nops = resident(src, params)
+    pa, pb = dp.PinnedArray(src.cols_a.shape, np.uint8), dp.PinnedArray(src.cols_b.shape, np.uint8)
+    pa.a[...] = src.cols_a
+    pb.a[...] = src.cols_b
+    inputs = dp.DpInputs(pa.a, src.off_a, pb.a, src.off_b)
+    ps, po, pn = dp.PinnedArray((n,), np.int32), dp.PinnedArray((2 * n * L,), np.uint8), dp.PinnedArray((n,), np.int32)
+    st = dp.DpStream(params, 7, workspace_bytes=60 << 20)
+    scores, ops, n_ops = st.align(inputs, ps.a, po.a, pn.a)
+    assert np.array_equal(scores, r_scores) and np.array_equal(n_ops, r_nops)
+    for p, q in zip(dp.paths_of(inputs, ops, n_ops), dp.paths_of(inputs, r_ops, r_nops)):  # the slots' unused heads are not compared
+        assert np.array_equal(p, q)
+    st.close()
+    for x in (pa, pb, ps, po, pn):
+        x.close()
+
+
+def test_stream_refuses_what_the_batch_refuses():
+    from paramugsy_amd import capi
+    cols = np.zeros((4, 8), dtype=np.uint8)
+    cols[:, :5] = 255
+    off = np.array([0, 4], dtype=np.int64)
+    p = dp.make_params(1, 1, match=127, mismatch=-127)
+    st = dp.DpStream(p, 2)
+    with pytest.raises(capi.PmError) as e:
+        st.align(dp.DpInputs(cols, off, cols.copy(), off.copy()))
+    assert e.value.code == capi.PM_E_INVALID
+    st.close()
+
+
+def test_variant_chosen_from_the_first_segment_is_corrected(oracle_build):
+    """The first segment's counts fit the int8 kernel, a later segment's do not: the engine must notice once the whole batch is up
+    and run again with int16 weights -- results equal the resident batch's."""
+    rng = np.random.default_rng(9)
+    n, L = 40, 120
+
+    def cols(rows):
+        c = np.zeros((n * L, 8), dtype=np.uint8)
+        pick = rng.integers(0, 5, size=(n * L, 3))
+        for s_ in range(5):
+            c[:, s_] = (pick == s_).sum(axis=1)
+        return c
+    ca, cb = cols(3), cols(3)
+    cb[(n - 3) * L:, 0] = 90  # deep columns at the very end of B: 90 x max|sub| > 127
+    off = np.arange(n + 1, dtype=np.int64) * L
+    inputs = dp.DpInputs(ca, off, cb, off.copy())
+    params = dp.make_params(1, 1, open_per_pair=60, extend_per_pair=5)
+    r_scores, r_ops, r_nops = resident(inputs, params)
+    b = dp.DpBatch(inputs, params)
+    assert not b.variant()["dot4"]
+    b.close()
+    st = dp.DpStream(params, 8)
+    scores, ops, n_ops = st.align(inputs)
+    st.close()
+    assert np.array_equal(scores, r_scores) and np.array_equal(n_ops, r_nops)
+    for p, q in zip(dp.paths_of(inputs, ops, n_ops), dp.paths_of(inputs, r_ops, r_nops)):
+        assert np.array_equal(p, q)
