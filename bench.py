@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--strong-factor", type=int, default=1, help="strong scaling: the fixed batch is this many per-GPU batches")
     ap.add_argument("--no-c1", action="store_true", help="skip the configs[1] ride-along")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the transfer-inclusive pass (pm_dp_stream_align)")
     ap.add_argument("--dry-launch", action="store_true", help="ranks report their environment and exit (no GPU work)")
     # translate workload (per rank): a Mugsy_profile node with 4+4 genomes of 1 Mbp
     ap.add_argument("--tr-genomes", type=int, default=4)
@@ -398,6 +399,31 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
                                       "excluded) against the half-rate VALU issue limit; the issue-slot utilisation is higher"},
                      "note": "max-plus recurrence: the fill kernel is bound by int32 VALU issue, not by HBM; the HBM fraction is reported as measured"},
     }
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        # transfer-inclusive rate (never `value`): the same batch from pinned host buffers through pm_dp_stream_align
+        # (segmented upload behind which the fill kernel runs, results back into pinned host arrays)
+        pa, pb = dpm.PinnedArray(inputs.cols_a.shape, np.uint8), dpm.PinnedArray(inputs.cols_b.shape, np.uint8)
+        pa.a[...] = inputs.cols_a
+        pb.a[...] = inputs.cols_b
+        pin = dpm.DpInputs(pa.a, inputs.off_a, pb.a, inputs.off_b)
+        ps, pn = dpm.PinnedArray((n,), np.int32), dpm.PinnedArray((n,), np.int32)
+        po = dpm.PinnedArray((max(1, int(inputs.off_a[-1] + inputs.off_b[-1])),), np.uint8)
+        st = dpm.DpStream(params, 4, device=local)
+        st.align(pin, ps.a, po.a, pn.a)
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            st.align(pin, ps.a, po.a, pn.a)
+            best = min(best, time.perf_counter() - t0)
+        r_scores, _, r_nops = batch.fetch()
+        out["end_to_end"] = {"value": cells / best / 1e9, "unit": "GCUPS", "ms": best * 1e3,
+                             "what": "pm_dp_stream_align: pinned host columns in (%.0f MB), scores + paths out (%.0f MB), 4 upload segments; "
+                                     "best of 3; results equal the resident batch's: %s"
+                                     % ((pa.a.nbytes + pb.a.nbytes) / 1e6, po.a.nbytes / 1e6,
+                                        bool(np.array_equal(ps.a, r_scores) and np.array_equal(pn.a, r_nops)))}
+        st.close()
+        for x in (pa, pb, ps, pn, po):
+            x.close()
     if with_cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
         # cpu_baseline leg: the oracle's scalar full-matrix aligner on a bounded sample of the same batch
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -175,6 +175,13 @@ int pm_maf_analyzer(const char *maf_path, const char *out_path, int device);
  * per block, m_make.ml:15-45).  <dir> must exist.  Restated from the OCaml source, which cannot be run in this build
  * image: see the header of csrc/profiles_make.hip. */
 int pm_profiles_make(const char *in_maf, const char *out_dir, const char *basename, int device);
+/* make(left) + make(right) + translate of one Mugsy_profile node in ONE process and one HIP context: what
+ * lib/base/mugsy_profiles_task.ml:40-58 runs as three processes.  Writes the same files with the same bytes
+ * (<dir>/profiles, <dir>/sequences.fasta for both sides, out_delta); the rows go from the make stage to the translate stage in
+ * memory.  pm_profiles_make (and this) also write <dir>/profiles.soa, the rows of <dir>/profiles as flat binary arrays: the
+ * translate stage reads it instead of parsing the text when it matches the text file (PM_NO_SOA=1 disables). */
+int pm_stage_files(const char *left_maf, const char *left_dir, const char *left_basename, const char *right_maf, const char *right_dir,
+                   const char *right_basename, const char *const *delta_paths, int n_paths, const char *out_delta, int device);
 /* `mugsy_profiles untranslate -profile_paths_list <file of dirs> -in_maf <maf> -out_maf <maf>`
  * (lib/profiles/m_untranslate.ml:206-221): rewrites a MAF whose `s` lines name profile blocks into one over the real
  * genomes.  profile_dirs: the directories the list file names, in order.  Restated from the OCaml source (see

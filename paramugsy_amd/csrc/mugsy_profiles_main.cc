@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iostream>
 #include <map>
 #include <string>
 #include <vector>
@@ -33,18 +34,18 @@ static void mkdir_p(const std::string &path) { // Shell.mkdir ~p:(), m_make.ml:9
   }
 }
 
-int main(int argc, char **argv) {
-  if(argc < 2) {
-    fprintf(stderr, "usage: mugsy_profiles {make|translate|untranslate} <flags>\n");
-    return 1;
+static std::vector<std::string> read_list(const std::string &path) {
+  std::vector<std::string> out;
+  std::ifstream list(path.c_str());
+  std::string line;
+  while(std::getline(list, line)) {
+    out.push_back(line);
   }
-  std::string cmd = argv[1];
-  std::map<std::string, std::string> flag;
-  for(int k = 2; k + 1 < argc; k += 2) {
-    flag[argv[k]] = argv[k + 1];
-  }
-  const char *dev_env = getenv("PARAMUGSY_DEVICE");
-  int device = dev_env ? atoi(dev_env) : 0;
+  return out;
+}
+
+// One command; returns the process exit code it stands for (0 ok, 2 = uncaught OCaml exception / bad flags).
+static int run_command(const std::string &cmd, std::map<std::string, std::string> &flag, int device) {
   int rc;
   if(cmd == "make") {
     if(flag["-basename"].empty() || flag["-out_dir"].empty() || flag["-in_maf"].empty()) {
@@ -59,12 +60,7 @@ int main(int argc, char **argv) {
       fprintf(stderr, "Must provide -profiles_left, -profiles_right, -nucmer_list and -out_delta\n");
       return 2;
     }
-    std::vector<std::string> paths;
-    std::ifstream list(flag["-nucmer_list"].c_str());
-    std::string line;
-    while(std::getline(list, line)) {
-      paths.push_back(line);
-    }
+    std::vector<std::string> paths = read_list(flag["-nucmer_list"]);
     std::vector<const char *> cpaths;
     for(size_t k = 0; k < paths.size(); ++k) {
       cpaths.push_back(paths[k].c_str());
@@ -72,17 +68,32 @@ int main(int argc, char **argv) {
     rc = pm_translate_files(flag["-profiles_left"].c_str(), flag["-profiles_right"].c_str(), cpaths.data(), (int)cpaths.size(),
                             flag["-out_delta"].c_str(), device);
   }
+  else if(cmd == "stage") {
+    // new in this build: the make + make + translate prefix of lib/base/mugsy_profiles_task.ml:40-58 in one process
+    const char *need[] = {"-left_maf", "-left_dir", "-left_basename", "-right_maf", "-right_dir", "-right_basename", "-nucmer_list", "-out_delta"};
+    for(const char *n : need) {
+      if(flag[n].empty()) {
+        fprintf(stderr, "Must provide -left_maf, -left_dir, -left_basename, -right_maf, -right_dir, -right_basename, -nucmer_list and -out_delta\n");
+        return 2;
+      }
+    }
+    mkdir_p(flag["-left_dir"]);
+    mkdir_p(flag["-right_dir"]);
+    std::vector<std::string> paths = read_list(flag["-nucmer_list"]);
+    std::vector<const char *> cpaths;
+    for(size_t k = 0; k < paths.size(); ++k) {
+      cpaths.push_back(paths[k].c_str());
+    }
+    rc = pm_stage_files(flag["-left_maf"].c_str(), flag["-left_dir"].c_str(), flag["-left_basename"].c_str(), flag["-right_maf"].c_str(),
+                        flag["-right_dir"].c_str(), flag["-right_basename"].c_str(), cpaths.data(), (int)cpaths.size(),
+                        flag["-out_delta"].c_str(), device);
+  }
   else if(cmd == "untranslate") {
     if(flag["-profile_paths_list"].empty() || flag["-in_maf"].empty() || flag["-out_maf"].empty()) {
       fprintf(stderr, "Must provide -profile_paths_list, -in_maf and -out_maf\n"); // m_untranslate.ml:183-188
       return 2;
     }
-    std::vector<std::string> dirs;
-    std::ifstream list(flag["-profile_paths_list"].c_str());
-    std::string line;
-    while(std::getline(list, line)) {
-      dirs.push_back(line);
-    }
+    std::vector<std::string> dirs = read_list(flag["-profile_paths_list"]);
     std::vector<const char *> cdirs;
     for(size_t k = 0; k < dirs.size(); ++k) {
       cdirs.push_back(dirs[k].c_str());
@@ -96,6 +107,63 @@ int main(int argc, char **argv) {
   if(rc != PM_OK) {
     fprintf(stderr, "mugsy_profiles %s: error %d: %s\n", cmd.c_str(), rc, pm_last_error());
     return 2; // an uncaught OCaml exception exits 2
+  }
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if(argc < 2) {
+    fprintf(stderr, "usage: mugsy_profiles {make|translate|untranslate|stage|serve} <flags>\n");
+    return 1;
+  }
+  std::string cmd = argv[1];
+  const char *dev_env = getenv("PARAMUGSY_DEVICE");
+  int device = dev_env ? atoi(dev_env) : 0;
+  int code;
+  if(cmd == "serve") {
+    // new in this build: a resident worker.  The orchestrator starts one short process per tree node
+    // (lib/base/job_processor.ml:184-211) and each pays the HIP runtime's start-up; a worker pays it once.  Protocol: one
+    // command per line on stdin, TAB-separated (`stage<TAB>-left_maf<TAB>path<TAB>...`), answered by `done <exit code>` on stdout;
+    // `quit` or end of input ends the worker.
+    (void)pm_device_count(); // bring the runtime up before the first command
+    std::string line;
+    code = 0;
+    while(std::getline(std::cin, line)) {
+      std::vector<std::string> tok;
+      size_t at = 0;
+      while(at <= line.size()) {
+        size_t e = line.find('\t', at);
+        if(e == std::string::npos) {
+          e = line.size();
+        }
+        tok.push_back(line.substr(at, e - at));
+        at = e + 1;
+      }
+      if(tok.empty() || tok[0].empty()) {
+        continue;
+      }
+      if(tok[0] == "quit") {
+        break;
+      }
+      std::map<std::string, std::string> flag;
+      for(size_t k = 1; k + 1 < tok.size(); k += 2) {
+        flag[tok[k]] = tok[k + 1];
+      }
+      int c = run_command(tok[0], flag, device);
+      code = c ? c : code;
+      printf("done %d\n", c);
+      fflush(stdout);
+    }
+  }
+  else {
+    std::map<std::string, std::string> flag;
+    for(int k = 2; k + 1 < argc; k += 2) {
+      flag[argv[k]] = argv[k + 1];
+    }
+    code = run_command(cmd, flag, device);
+  }
+  if(code) {
+    return code;
   }
   // done: everything this process wrote is flushed below; leave without tearing the HIP runtime down (tens of
   // milliseconds that a short-lived tool has no use for) -- unless a tool library rides along in this process

@@ -18,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pm_internal.hpp"
@@ -197,12 +198,11 @@ static int parse_maf_for_make(const std::string &maf, std::vector<MakeRow> &rows
 
 } // namespace pm
 
-using namespace pm;
+namespace pm {
 
-extern "C" int pm_profiles_make(const char *in_maf, const char *out_dir, const char *basename, int device) {
-  if(!in_maf || !out_dir || !basename) {
-    return fail(PM_E_INVALID, "pm_profiles_make: null argument");
-  }
+// `mugsy_profiles make` (below), handing the rows it wrote back as the flat arrays the translate stage works on (side_out may
+// be null); also writes <out_dir>/profiles.soa, the binary form of the same rows (translate_host.cc).
+int make_profiles(const char *in_maf, const char *out_dir, const char *basename, int device, Side *side_out) {
   int rc = use_device(device);
   if(rc) {
     return rc;
@@ -356,7 +356,97 @@ extern "C" int pm_profiles_make(const char *in_maf, const char *out_dir, const c
     buf += "\n\n";
   }
   fwrite(buf.data(), 1, buf.size(), ff);
-  fclose(fp);
-  fclose(ff);
+  const long long text_bytes = ftell(fp);
+  const bool wrote = fclose(fp) == 0;
+  if(fclose(ff) != 0 || !wrote || text_bytes < 0) {
+    return fail(PM_E_IO, "cannot write the output files in " + dir);
+  }
+  // the same rows as flat arrays: what parse_profiles would read back from the file just written
+  Side side;
+  side.gap_off.assign(gap_off.begin(), gap_off.end());
+  side.gap_start.assign(gap_start.begin(), gap_start.end());
+  side.gap_end.assign(gap_end.begin(), gap_end.end());
+  for(int r = 0; r < n_rows; ++r) {
+    snprintf(major, sizeof major, "%s.%s_%04d", basename, basename, rows[r].block);
+    side.major.push_back(major);
+    side.seq_name.push_back(rows[r].seq_name);
+    side.start.push_back(rows[r].start);
+    side.end.push_back(rows[r].end);
+    side.length.push_back(row_off[(size_t)r + 1] - row_off[r]);
+  }
+  PM_TRY(write_side_soa(dir, side, text_bytes));
+  if(side_out) {
+    *side_out = std::move(side);
+  }
   return PM_OK;
+}
+
+} // namespace pm
+
+using namespace pm;
+
+extern "C" int pm_profiles_make(const char *in_maf, const char *out_dir, const char *basename, int device) {
+  if(!in_maf || !out_dir || !basename) {
+    return fail(PM_E_INVALID, "pm_profiles_make: null argument");
+  }
+  return make_profiles(in_maf, out_dir, basename, device, nullptr);
+}
+
+// make(left) + make(right) + translate in one process and one HIP context (lib/base/mugsy_profiles_task.ml:40-58 runs them as
+// three processes): the two makes and the parsing of the delta files run side by side on host threads, and the rows the makes
+// produce go to the translate stage in memory instead of through the `profiles` text.  Same files written, same bytes.
+extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const char *left_basename, const char *right_maf,
+                              const char *right_dir, const char *right_basename, const char *const *delta_paths, int n_paths,
+                              const char *out_delta, int device) {
+  if(!left_maf || !left_dir || !left_basename || !right_maf || !right_dir || !right_basename || !out_delta || n_paths < 0 ||
+     (n_paths > 0 && !delta_paths)) {
+    return fail(PM_E_INVALID, "pm_stage_files: null argument");
+  }
+  PM_TRY(use_device(device));
+  std::vector<std::string> paths;
+  for(int k = 0; k < n_paths; ++k) {
+    if(!delta_paths[k]) {
+      return fail(PM_E_INVALID, "pm_stage_files: null path");
+    }
+    paths.push_back(delta_paths[k]);
+  }
+  Workload w;
+  int rc_l = PM_OK, rc_r = PM_OK;
+  std::string msg_l, msg_r;
+  std::thread tl([&]() {
+    rc_l = make_profiles(left_maf, left_dir, left_basename, device, &w.left);
+    if(rc_l) {
+      msg_l = pm_last_error(); // the error slot is per thread
+    }
+  });
+  std::thread tr([&]() {
+    rc_r = make_profiles(right_maf, right_dir, right_basename, device, &w.right);
+    if(rc_r) {
+      msg_r = pm_last_error();
+    }
+  });
+  std::thread td([&]() { parse_deltas(paths, w); }); // touches w.table and w.parse_* only
+  tl.join();
+  tr.join();
+  td.join();
+  if(rc_l) {
+    return fail(rc_l, msg_l);
+  }
+  if(rc_r) {
+    return fail(rc_r, msg_r);
+  }
+  index_and_enumerate(w);
+  FILE *f = fopen(out_delta, "wb");
+  if(!f) {
+    return fail(PM_E_IO, std::string("cannot open ") + out_delta);
+  }
+  fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_dir, right_dir); // m_translate_main.cc:35-39
+  int rc = run_workload(w, f, device);
+  if(fclose(f) != 0 && !rc) {
+    rc = fail(PM_E_IO, "close failed");
+  }
+  if(!rc && w.parse_rc) {
+    rc = fail(w.parse_rc, w.parse_msg);
+  }
+  return rc;
 }

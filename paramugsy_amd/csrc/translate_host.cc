@@ -27,6 +27,8 @@
 #include "pm_internal.hpp"
 #include "translate_host.hpp"
 
+#include <sys/stat.h>
+
 namespace pm {
 
 // ------------------------------------------------------------------ small text tools
@@ -173,6 +175,119 @@ int parse_profiles(const std::string &path, Side &side) {
     lines.next(b, e); // the text line, never needed here (lite = true, m_translate.cc:192)
   }
   return PM_OK;
+}
+
+// ------------------------------------------------------------------ binary side file
+// `<dir>/profiles.soa`, written by the make stage next to `<dir>/profiles`: the rows as the flat arrays parse_profiles builds
+// (everything but the row texts), so that the translate stage does not parse 10-100 MB of text it has no use for.  The text
+// file stays the interchange format (untranslate and the reference's own tools read it); the side file is used only when it
+// matches the text file it was written with (size recorded inside, not older than the text file), else the text is parsed.
+// Layout: "PMSOA1\0\0", then int64 {rows, gaps, bytes of names, size of the profiles text file}, then int64 arrays
+// start[rows], end[rows], length[rows], gap_off[rows + 1], gap_start[gaps], gap_end[gaps], then per row "major\0seq\0".
+static const char SOA_MAGIC[8] = {'P', 'M', 'S', 'O', 'A', '1', 0, 0};
+
+int write_side_soa(const std::string &dir, const Side &side, long long profiles_text_bytes) {
+  const std::string path = dir + "/profiles.soa";
+  FILE *f = fopen(path.c_str(), "wb");
+  if(!f) {
+    return fail(PM_E_IO, "cannot create " + path);
+  }
+  std::string names;
+  for(size_t r = 0; r < side.start.size(); ++r) {
+    names += side.major[r];
+    names.push_back('\0');
+    names += side.seq_name[r];
+    names.push_back('\0');
+  }
+  const long long head[4] = {(long long)side.start.size(), (long long)side.gap_start.size(), (long long)names.size(), profiles_text_bytes};
+  bool ok = fwrite(SOA_MAGIC, 1, 8, f) == 8 && fwrite(head, 8, 4, f) == 4;
+  auto put = [&](const std::vector<long long> &v) {
+    ok = ok && (v.empty() || fwrite(v.data(), 8, v.size(), f) == v.size());
+  };
+  put(side.start);
+  put(side.end);
+  put(side.length);
+  put(side.gap_off);
+  put(side.gap_start);
+  put(side.gap_end);
+  ok = ok && (names.empty() || fwrite(names.data(), 1, names.size(), f) == names.size());
+  if(fclose(f) != 0 || !ok) {
+    remove(path.c_str());
+    return fail(PM_E_IO, "cannot write " + path);
+  }
+  return PM_OK;
+}
+
+// true when <dir>/profiles.soa was read into `side`; false (side untouched) when it is absent, stale or malformed
+static bool read_side_soa(const std::string &dir, Side &side) {
+  if(getenv("PM_NO_SOA")) {
+    return false;
+  }
+  struct stat st_txt, st_soa;
+  const std::string txt = dir + "/profiles", soa = dir + "/profiles.soa";
+  if(stat(txt.c_str(), &st_txt) != 0 || stat(soa.c_str(), &st_soa) != 0) {
+    return false;
+  }
+  if(st_soa.st_mtim.tv_sec < st_txt.st_mtim.tv_sec ||
+     (st_soa.st_mtim.tv_sec == st_txt.st_mtim.tv_sec && st_soa.st_mtim.tv_nsec < st_txt.st_mtim.tv_nsec)) {
+    return false; // the text file was rewritten after the side file
+  }
+  std::string blob;
+  if(!read_whole_file(soa, blob) || blob.size() < 40 || memcmp(blob.data(), SOA_MAGIC, 8) != 0) {
+    return false;
+  }
+  long long head[4];
+  memcpy(head, blob.data() + 8, 32);
+  const long long n = head[0], g = head[1], nb = head[2];
+  if(n < 0 || g < 0 || nb < 0 || head[3] != (long long)st_txt.st_size) {
+    return false;
+  }
+  const size_t need = 40 + (size_t)(3 * n + (n + 1) + 2 * g) * 8 + (size_t)nb;
+  if(blob.size() != need) {
+    return false;
+  }
+  Side s;
+  const char *p = blob.data() + 40;
+  auto get = [&](std::vector<long long> &v, long long count) {
+    v.resize((size_t)count);
+    memcpy(v.data(), p, (size_t)count * 8);
+    p += (size_t)count * 8;
+  };
+  get(s.start, n);
+  get(s.end, n);
+  get(s.length, n);
+  get(s.gap_off, n + 1);
+  get(s.gap_start, g);
+  get(s.gap_end, g);
+  if(s.gap_off[0] != 0 || s.gap_off[(size_t)n] != g) {
+    return false;
+  }
+  const char *e = blob.data() + blob.size();
+  s.major.reserve((size_t)n);
+  s.seq_name.reserve((size_t)n);
+  for(long long r = 0; r < n; ++r) {
+    const char *z = (const char *)memchr(p, 0, (size_t)(e - p));
+    if(!z) {
+      return false;
+    }
+    s.major.emplace_back(p, z);
+    p = z + 1;
+    z = (const char *)memchr(p, 0, (size_t)(e - p));
+    if(!z) {
+      return false;
+    }
+    s.seq_name.emplace_back(p, z);
+    p = z + 1;
+  }
+  side = std::move(s);
+  return true;
+}
+
+int load_side(const std::string &dir, Side &side) {
+  if(read_side_soa(dir, side)) {
+    return PM_OK;
+  }
+  return parse_profiles(dir + "/profiles", side);
 }
 
 // m_translate.cc:188-207: rows grouped by sequence name, each group sorted by forward start.
@@ -582,27 +697,43 @@ static pm_deltas_t deltas_view(const DeltaTable &t) {
 // `parse_rc`/`parse_msg` keep a delta-file parse failure: the entries read before it are still in the table,
 // as the reference would have translated them before throwing (m_translate.cc:722-728).
 int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w) {
-  PM_TRY(parse_profiles(left_dir + "/profiles", w.left));
-  PM_TRY(parse_profiles(right_dir + "/profiles", w.right));
-  build_side_index(w.left);
-  build_side_index(w.right);
+  PM_TRY(load_side(left_dir, w.left));
+  PM_TRY(load_side(right_dir, w.right));
+  return load_deltas(delta_paths, w);
+}
+
+// The delta files and the unit list of a workload whose two sides are already in place (read from disk, or handed over in
+// memory by the make stage: pm_stage_files).
+int load_deltas(const std::vector<std::string> &delta_paths, Workload &w) {
+  parse_deltas(delta_paths, w);
+  index_and_enumerate(w);
+  return PM_OK;
+}
+
+// The delta files into w.table, in list order; stops at the first file that fails to parse (its entries up to the failure stay,
+// as the reference translates them before it throws) and records the failure in w.parse_rc / w.parse_msg.  Needs no side.
+void parse_deltas(const std::vector<std::string> &delta_paths, Workload &w) {
   w.table = DeltaTable();
   w.table.ref_gap_off.push_back(0);
   w.table.qry_gap_off.push_back(0);
-  w.units = UnitList();
   w.parse_rc = PM_OK;
   w.parse_msg.clear();
   for(size_t k = 0; k < delta_paths.size(); ++k) {
-    size_t first = w.table.ref_start.size();
     int rc = parse_delta_file(delta_paths[k], w.table);
-    enumerate_units(w.left, w.right, w.table, first, w.units);
     if(rc) {
       w.parse_rc = rc;
       w.parse_msg = pm_last_error();
       break;
     }
   }
-  return PM_OK;
+}
+
+// The per-sequence row index of both sides and the unit list of every parsed entry (m_translate.cc:666-707), in entry order.
+void index_and_enumerate(Workload &w) {
+  build_side_index(w.left);
+  build_side_index(w.right);
+  w.units = UnitList();
+  enumerate_units(w.left, w.right, w.table, 0, w.units);
 }
 
 void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units) {
@@ -656,6 +787,18 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   if(timing) {
     fprintf(stderr, "[pm] parse + enumerate: %.3f s (%zu units)\n", t1 - t0, w.units.delta.size());
   }
+  return run_workload(w, out, device);
+}
+
+// The device part of a translate job and the text of its output: upload + prepare + sizing, one pass, fetch, format + write.
+int run_workload(Workload &w, FILE *out, int device) {
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto now = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+  };
+  double t1 = now();
   std::string last_left, last_right;
   if(!w.units.delta.empty()) {
     pm_rows_t lv, rv;

@@ -51,6 +51,13 @@ void enumerate_units(const Side &left, const Side &right, const DeltaTable &tabl
 int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
                   const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string &last_left,
                   std::string &last_right);
+// <dir>/profiles.soa when it matches <dir>/profiles, else the text file (parse_profiles)
+int load_side(const std::string &dir, Side &side);
+int write_side_soa(const std::string &dir, const Side &side, long long profiles_text_bytes);
+int load_deltas(const std::vector<std::string> &delta_paths, Workload &w);
+void parse_deltas(const std::vector<std::string> &delta_paths, Workload &w);
+void index_and_enumerate(Workload &w);
+int run_workload(Workload &w, FILE *out, int device);
 int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w);
 void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units);
 int translate_to_file(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
