@@ -221,8 +221,11 @@ int pm_dp_batch_run_profiled(pm_dp_batch_t *batch, int traceback, void *hip_stre
  * the LAST n_ops[k] bytes of that slot, first op first (0 = M, 1 = I: column of B against a gap, 2 = D). */
 int pm_dp_batch_fetch(pm_dp_batch_t *batch, int32_t *scores, uint8_t *ops, int32_t *n_ops);
 int pm_dp_batch_info(pm_dp_batch_t *batch, int64_t *cells, int64_t *traceback_bytes_per_run, int64_t *input_bytes, int32_t *n_chunks);
-/* first_pair[c] = first pair of chunk c, first_pair[n_chunks] = n_pairs (at most `capacity` values are written). */
-int pm_dp_batch_chunks(pm_dp_batch_t *batch, int64_t *first_pair, int32_t capacity);
+/* The batch's processing order and its chunks of the path workspace.  The pairs are processed longest first (a launch lasts at
+ * least as long as its longest pair; results are returned in the caller's order all the same): order[q] = the pair at position q
+ * (n_pairs values, may be NULL); chunk c covers positions [first_position[c], first_position[c+1]), first_position[n_chunks] =
+ * n_pairs (at most `capacity` values are written). */
+int pm_dp_batch_chunks(pm_dp_batch_t *batch, int64_t *first_position, int32_t capacity, int32_t *order);
 /* Which kernel variant the batch runs: columns of B per lane (8/16), whether the int8 dot4 path applies, and the VALU
  * instructions per DP cell of that variant (for roofline accounting). */
 int pm_dp_batch_variant(pm_dp_batch_t *batch, int32_t *cols_per_lane, int32_t *dot4, int32_t *valu_ops_per_cell);

@@ -13,9 +13,10 @@ struct pm_dp_batch {
   int device = 0;
   pm::i64 n_pairs = 0, total_a = 0, total_b = 0;
   std::vector<pm::i64> off_a, off_b;
-  pm::DevBuf cols_a, cols_b, d_off_a, d_off_b, bnd, scores, ops, n_ops, tb, d_tb_off, stats;
-  std::vector<pm::i64> chunk_first;            // first pair of each chunk, plus n_pairs
-  std::vector<std::vector<pm::i64> > chunk_tb; // per chunk: word offsets of its pairs
+  pm::DevBuf cols_a, cols_b, d_off_a, d_off_b, bnd, scores, ops, n_ops, tb, d_tb_off, d_order, stats;
+  std::vector<int> order;                      // processing order of the pairs (longest first), a permutation of 0 .. n_pairs - 1
+  std::vector<pm::i64> chunk_first;            // first POSITION in `order` of each chunk, plus n_pairs
+  std::vector<std::vector<pm::i64> > chunk_tb; // per chunk: word offsets of the pairs at its positions
   pm::i64 tb_words_cap = 0;
   pm::i64 tb_budget_bytes = 0;
   pm::DpParamsD params;

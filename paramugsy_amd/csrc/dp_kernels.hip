@@ -75,7 +75,7 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 template <int C, int MODE, bool DOT4, int NW>
 __global__ void __launch_bounds__(64 * NW)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
-               const i64 *__restrict__ off_b, i64 first_pair, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
+               const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
                int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P) {
   static_assert(C % 8 == 0, "whole traceback words per lane per step");
   constexpr bool TRACE = MODE == DP_MODE_BITS;
@@ -89,12 +89,12 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const int lane = threadIdx.x & 63;
   int4 *ring = ring_all[wv];
   unsigned(*tbstage)[TBS] = tbstage_all[wv];
-  const i64 pair = first_pair + blockIdx.x;
+  const i64 pair = order[blockIdx.x]; // the launch's pairs in processing order (dp_batch_plan)
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
   const u64 *A = cols_a + a0;
   const u64 *B = cols_b + b0;
-  unsigned *tbp = (TRACE || CKPT) ? tb + tb_off[blockIdx.x] : nullptr;
+  unsigned *tbp = (TRACE || CKPT) ? tb + tb_off[pair] : nullptr;
   int2 *bp = bnd + a0;
   const int go = P.go, ge = P.ge;
   const int gop = go - ge; // cost of opening over extending, the only gap constant left in skewed coordinates
@@ -300,12 +300,12 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
 // right-aligned into the pair's (la+lb)-byte slot: its last n_ops bytes, first op first.
 template <int C>
 __global__ void __launch_bounds__(64)
-dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b, i64 first_pair, const i64 *__restrict__ tb_off,
+dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off,
                     const unsigned *__restrict__ tb, unsigned char *__restrict__ ops, int *__restrict__ n_ops) {
   const int lane = threadIdx.x;
-  const i64 pair = first_pair + blockIdx.x;
+  const i64 pair = order[blockIdx.x];
   const int la = (int)(off_a[pair + 1] - off_a[pair]), lb = (int)(off_b[pair + 1] - off_b[pair]);
-  const unsigned *tbp = tb + tb_off[blockIdx.x];
+  const unsigned *tbp = tb + tb_off[pair];
   unsigned char *out = ops + off_a[pair] + off_b[pair];
   constexpr int W = 64 * C;
   const i64 tiles = (la + 63 + 3) / 4;
@@ -512,7 +512,7 @@ int dp_batch_load(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, c
   PM_TRY(dp_batch_reserve(h, n_pairs, h->total_a, h->total_b));
   // the offsets go through pinned staging when the batch has it (so that the copy is asynchronous), else straight from the vectors
   const i64 *src_a = h->off_a.data(), *src_b = h->off_b.data();
-  if(h->pinned && h->pinned_bytes >= (size_t)(3 * (n_pairs + 1)) * 8 + 64) {
+  if(h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 16) {
     i64 *pa = (i64 *)h->pinned, *pb = pa + (n_pairs + 1);
     memcpy(pa, src_a, (size_t)(n_pairs + 1) * 8);
     memcpy(pb, src_b, (size_t)(n_pairs + 1) * 8);
@@ -568,12 +568,12 @@ int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t 
     return fail(PM_E_INVALID, "pm_dp_batch_create: null columns");
   }
   PM_TRY(dp_batch_reserve(h, n_pairs, h->total_a, h->total_b));
-  if(!h->pinned || h->pinned_bytes < (size_t)(3 * (n_pairs + 1)) * 8 + 64 + 16) { // offsets, workspace offsets, statistics
+  if(!h->pinned || h->pinned_bytes < (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 16) { // offsets, workspace offsets, order, statistics
     if(h->pinned) {
       (void)hipHostFree(h->pinned);
       h->pinned = nullptr;
     }
-    h->pinned_bytes = (size_t)(3 * (n_pairs + 1)) * 8 + 64 + 16;
+    h->pinned_bytes = (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 16;
     PM_HIP(hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault));
   }
   i64 *pa = (i64 *)h->pinned, *pb = pa + (n_pairs + 1);
@@ -667,6 +667,22 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
     return h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane) : dp_tb_words(la, lb, h->cols_per_lane);
   };
+  // processing order: a wavefront works through its pair's stripes one after the other, so a launch lasts at least as long as
+  // its longest pair; pairs are therefore taken longest first (stripes x steps, ties in input order), which also puts pairs of
+  // like length into the same chunk, where the waves-per-pair choice of dp_launch_fill can split the long ones.  A batch
+  // whose columns arrive in segments (dp_stream.hip) keeps the input order: its fill kernels follow the uploads.
+  h->order.resize((size_t)n_pairs);
+  for(i64 k = 0; k < n_pairs; ++k) {
+    h->order[(size_t)k] = (int)k;
+  }
+  if(h->seg_first.empty() && !getenv("PM_DP_KEEP_ORDER")) {
+    std::vector<i64> cost((size_t)n_pairs);
+    for(i64 k = 0; k < n_pairs; ++k) {
+      const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+      cost[(size_t)k] = dp_ck_stripes(lb, h->cols_per_lane) * (la + 63);
+    }
+    std::stable_sort(h->order.begin(), h->order.end(), [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
+  }
   i64 total_words = 0;
   h->cells = 0;
   for(i64 k = 0; k < n_pairs; ++k) {
@@ -675,16 +691,17 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   }
   const bool one_chunk = total_words <= h->tb_budget_bytes / 4;
   const i64 budget_words = one_chunk ? h->tb_budget_bytes / 4 : h->tb_budget_bytes / 8;
+  // chunk_first: positions in `order`; chunk_tb: the word offset of every position's pair inside its chunk's workspace
   h->chunk_first.assign(1, 0);
   h->chunk_tb.clear();
   h->tb_words_cap = 0;
   std::vector<i64> cur;
   i64 used = 0;
-  for(i64 k = 0; k < n_pairs; ++k) {
-    i64 need = need_words(k);
+  for(i64 q = 0; q < n_pairs; ++q) {
+    i64 need = need_words(h->order[(size_t)q]);
     if(!cur.empty() && used + need > budget_words) {
       h->chunk_tb.push_back(cur);
-      h->chunk_first.push_back(k);
+      h->chunk_first.push_back(q);
       h->tb_words_cap = std::max(h->tb_words_cap, used);
       cur.clear();
       used = 0;
@@ -710,30 +727,42 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       h->ev_path.push_back(b);
     }
   }
-  // per-chunk offset tables live back to back in one device array
+  // the workspace offset of every pair (indexed by pair) and the processing order go to the device
   {
+    const size_t npad = (size_t)std::max<i64>(n_pairs, 1);
     i64 *flat = nullptr;
+    int *ord = nullptr;
     std::vector<i64> tmp;
-    if(h->pinned && h->pinned_bytes >= (size_t)(3 * (n_pairs + 1)) * 8 + 64) {
+    std::vector<int> tmp_o;
+    const bool staged = h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 16;
+    if(staged) {
       flat = (i64 *)h->pinned + 2 * (n_pairs + 1);
+      ord = (int *)((i64 *)h->pinned + 3 * (n_pairs + 1));
     }
     else {
-      tmp.resize((size_t)std::max<i64>(n_pairs, 1));
+      tmp.resize(npad);
+      tmp_o.resize(npad);
       flat = tmp.data();
+      ord = tmp_o.data();
     }
-    size_t at = 0;
+    size_t q = 0;
     for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
       for(i64 v : h->chunk_tb[c]) {
-        flat[at++] = v;
+        flat[(size_t)h->order[q]] = v;
+        ord[q] = h->order[q];
+        ++q;
       }
     }
-    if(at > 0) {
-      if(tmp.empty()) {
-        PM_HIP(hipMemcpyAsync(h->d_tb_off.p, flat, at * 8, hipMemcpyHostToDevice, stream));
+    PM_TRY(grow(h->d_order, npad * 4));
+    if(n_pairs > 0) {
+      if(staged) {
+        PM_HIP(hipMemcpyAsync(h->d_tb_off.p, flat, (size_t)n_pairs * 8, hipMemcpyHostToDevice, stream));
+        PM_HIP(hipMemcpyAsync(h->d_order.p, ord, (size_t)n_pairs * 4, hipMemcpyHostToDevice, stream));
       }
-      else { // pageable source: a blocking copy, the vector dies with this scope
+      else { // pageable sources: blocking copies, the vectors die with this scope
         PM_HIP(hipStreamSynchronize(stream));
-        PM_HIP(hipMemcpy(h->d_tb_off.p, flat, at * 8, hipMemcpyHostToDevice));
+        PM_HIP(hipMemcpy(h->d_tb_off.p, flat, (size_t)n_pairs * 8, hipMemcpyHostToDevice));
+        PM_HIP(hipMemcpy(h->d_order.p, ord, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
       }
     }
   }
@@ -784,13 +813,15 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
 
 // The fill kernel of chunk c into workspace `tbw`.
 static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int traceback, hipStream_t stream) {
-  const i64 *tb_off = (const i64 *)h->d_tb_off.p + first;
+  const i64 *tb_off = (const i64 *)h->d_tb_off.p;
+  const int *order = (const int *)h->d_order.p + first;
   // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
   // have several stripes to pipeline
   int nw = 1;
   {
     i64 max_stripes = 0, max_la = 0;
-    for(i64 k = first; k < first + n; ++k) {
+    for(i64 q = first; q < first + n; ++q) {
+      const i64 k = h->order[(size_t)q];
       i64 lbk = h->off_b[k + 1] - h->off_b[k];
       max_stripes = std::max(max_stripes, (lbk + 64 * h->cols_per_lane - 1) / (64 * h->cols_per_lane));
       max_la = std::max(max_la, h->off_a[k + 1] - h->off_a[k]);
@@ -808,7 +839,7 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
   }
 #define DP_LAUNCH_FILL(CC, TR, D4, NWV)                                                                                                   \
   dp_fill_kernel<CC, TR, D4, NWV><<<(unsigned)n, 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,             \
-                                                                        (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p, first, tb_off, \
+                                                                        (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p, order, tb_off, \
                                                                         tbw, (int2 *)h->bnd.p, (int *)h->scores.p,                         \
                                                                         (int *)h->pipe_error.p, h->params)
 #define DP_LAUNCH_FILL_D4(CC, TR, NWV) \
@@ -860,7 +891,8 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
 // The path kernel of chunk c from workspace `tbw`: the checkpoint walk, or the walk over stored decision bits.
 static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStream_t stream) {
   const i64 first = h->chunk_first[c], n = h->chunk_first[c + 1] - first;
-  const i64 *tb_off = (const i64 *)h->d_tb_off.p + first;
+  const i64 *tb_off = (const i64 *)h->d_tb_off.p;
+  const int *order = (const int *)h->d_order.p + first;
   if(h->ckpt) {
     // lanes per pair: as few as still give the launch about two wavefronts per SIMD (1 024 SIMDs)
     int lpp = h->walk_lanes;
@@ -874,14 +906,14 @@ static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStre
       }
     }
     return dp_launch_walk(h->cols_per_lane, lpp, h->dot4, (const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
-                          (const i64 *)h->d_off_b.p, first, n, tb_off, tbw, (unsigned char *)h->ops.p, (int *)h->n_ops.p, h->params, stream);
+                          (const i64 *)h->d_off_b.p, order, n, tb_off, tbw, (unsigned char *)h->ops.p, (int *)h->n_ops.p, h->params, stream);
   }
   if(h->cols_per_lane == 16) {
-    dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off, tbw,
+    dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, order, tb_off, tbw,
                                                             (unsigned char *)h->ops.p, (int *)h->n_ops.p);
   }
   else {
-    dp_traceback_kernel<8><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, first, tb_off, tbw,
+    dp_traceback_kernel<8><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, order, tb_off, tbw,
                                                            (unsigned char *)h->ops.p, (int *)h->n_ops.p);
   }
   PM_HIP(hipGetLastError());
@@ -1113,13 +1145,18 @@ int pm_dp_batch_variant(pm_dp_batch_t *h, int32_t *cols_per_lane, int32_t *dot4,
   return PM_OK;
 }
 
-int pm_dp_batch_chunks(pm_dp_batch_t *h, int64_t *first_pair, int32_t capacity) {
-  if(!h || (!first_pair && capacity > 0)) {
+int pm_dp_batch_chunks(pm_dp_batch_t *h, int64_t *first_position, int32_t capacity, int32_t *order) {
+  if(!h || (!first_position && capacity > 0)) {
     return fail(PM_E_INVALID, "pm_dp_batch_chunks: null argument");
   }
   const int32_t nc = (int32_t)h->chunk_tb.size();
   for(int32_t c = 0; c <= nc && c < capacity; ++c) {
-    first_pair[c] = h->chunk_first[c];
+    first_position[c] = h->chunk_first[c];
+  }
+  if(order) {
+    for(i64 q = 0; q < h->n_pairs; ++q) {
+      order[q] = h->order[(size_t)q];
+    }
   }
   return PM_OK;
 }

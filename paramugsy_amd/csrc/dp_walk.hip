@@ -39,7 +39,7 @@ template <> struct BitsWord<4> { typedef unsigned short type; };
 template <int C, int LPP, bool DOT4>
 __global__ void __launch_bounds__(64)
 dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b, const i64 *__restrict__ off_b,
-               i64 first_pair, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
+               const int *__restrict__ order, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
                int *__restrict__ n_ops, DpParamsD P, int ablate) {
   constexpr int R = DP_CK_R;
   constexpr int BW = C * DP_CK_W; // columns of a block
@@ -53,12 +53,12 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const int grp = threadIdx.x / LPP, q = threadIdx.x % LPP;
   const i64 idx = (i64)blockIdx.x * G + grp;
   const bool valid = idx < n;
-  const i64 pair = first_pair + (valid ? idx : 0);
+  const i64 pair = order[valid ? idx : 0]; // the launch's pairs in processing order
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
   const u64 *A = cols_a + a0;
   const u64 *B = cols_b + b0;
-  const unsigned *ckp = ck + tb_off[valid ? idx : 0];
+  const unsigned *ckp = ck + tb_off[pair];
   unsigned char *out = ops + a0 + b0;
   const int go = P.go, ge = P.ge, gop = go - ge;
   int i = la, j = lb, state = 0; // DP coordinates of the walk (cell (i, j) = row i-1 of A against column j-1 of B)
@@ -271,18 +271,18 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
 }
 
 template <int C, int LPP, bool DOT4>
-static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b, i64 first_pair, i64 n, const i64 *tb_off,
+static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b, const int *order, i64 n, const i64 *tb_off,
                        const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, hipStream_t stream) {
   constexpr int G = 64 / LPP;
   const unsigned blocks = (unsigned)((n + G - 1) / G);
   static const int ablate = getenv("PM_DP_WALK_ABLATE") ? atoi(getenv("PM_DP_WALK_ABLATE")) : 0;
-  dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P, ablate);
+  dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, ablate);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
 
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
-                   i64 first_pair, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
+                   const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
                    hipStream_t stream) {
   if(n <= 0) {
     return PM_OK;
@@ -291,8 +291,8 @@ int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *
 #define WALK(CC, LL)                                                                                                        \
   if constexpr((CC * DP_CK_W) % LL == 0 && (CC * DP_CK_W) / LL >= 1 && (CC * DP_CK_W) / LL <= 8 && CC % ((CC * DP_CK_W) / LL) == 0) { \
     if(lanes_per_pair == LL) {                                                                                              \
-      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P, stream) \
-                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, first_pair, n, tb_off, ck, ops, n_ops, P, stream); \
+      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, stream) \
+                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, stream); \
     }                                                                                                                       \
   }
   if(cols_per_lane == 16) {

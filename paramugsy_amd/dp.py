@@ -75,7 +75,7 @@ def _lib():
         l.pm_dp_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_dp_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         l.pm_dp_batch_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-        l.pm_dp_batch_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        l.pm_dp_batch_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         l.pm_dp_batch_path_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.pm_dp_pack_maf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         l.pm_dp_emit_maf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -139,12 +139,13 @@ class DpBatch:
         capi.check(_lib().pm_dp_batch_info(self._h, C.byref(cells), C.byref(tb), C.byref(inp), C.byref(chunks)))
         return {"cells": cells.value, "traceback_bytes": tb.value, "input_bytes": inp.value, "chunks": chunks.value}
 
-    def chunks(self) -> np.ndarray:
-        """First pair of every chunk, plus n_pairs."""
+    def chunks(self):
+        """(first position of every chunk plus n_pairs, processing order): chunk c handles pairs order[first[c]:first[c+1]]."""
         n = self.info()["chunks"]
         first = np.zeros(n + 1, dtype=np.int64)
-        capi.check(_lib().pm_dp_batch_chunks(self._h, first.ctypes.data, n + 1))
-        return first
+        order = np.zeros(len(self._oa) - 1, dtype=np.int32)
+        capi.check(_lib().pm_dp_batch_chunks(self._h, first.ctypes.data, n + 1, order.ctypes.data))
+        return first, order
 
     def variant(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()

@@ -33,16 +33,16 @@ def test_north_star_shape_one_gpu_share_default_budget(oracle_build):
     inputs = dp.synth_batch(20261003, np.full(n, L), np.full(n, L), rows, rows)
     params = dp.make_params(rows, rows)
     batch = dp.DpBatch(inputs, params)
-    chunks = batch.chunks()
+    chunks, order = batch.chunks()
     assert len(chunks) - 1 >= 3, "the default budget must split this batch into several chunks"
     batch.run(traceback=True)
     scores, ops, n_ops = batch.fetch()
     paths = batch.paths(ops, n_ops)
     sample = []
     for c in range(len(chunks) - 1):
-        sample += [chunks[c], chunks[c + 1] - 1]
+        sample += [order[chunks[c]], order[chunks[c + 1] - 1]]
     sample += list(np.random.default_rng(1).integers(0, n, size=6))
-    check_sample(inputs, params, scores, paths, sample, full_paths_for=[chunks[1] - 1, chunks[1]])
+    check_sample(inputs, params, scores, paths, sample, full_paths_for=[order[chunks[1] - 1], order[chunks[1]]])
     assert all(len(p) >= L for p in paths[::97])
     # score-only pass: same scores
     batch.run(traceback=False)
@@ -76,13 +76,15 @@ def test_ragged_segment_batch_stand_in_for_config_2(oracle_build):
     inputs = dp.synth_batch(20261003, la, lb, rows, rows)
     params = dp.make_params(rows, rows)
     batch = dp.DpBatch(inputs, params, tb_budget_bytes=8 << 30)
-    chunks = batch.chunks()
+    chunks, porder = batch.chunks()
     assert len(chunks) - 1 >= 3
+    assert sorted(porder.tolist()) == list(range(n))  # a permutation: longest pairs first
     batch.run(traceback=True)
     scores, ops, n_ops = batch.fetch()
     paths = batch.paths(ops, n_ops)
     order = np.argsort(la * lb)
-    sample = [chunks[1] - 1, chunks[1], chunks[2] - 1, chunks[2], 0, n - 1, order[0], order[-1], order[n // 2]]
+    sample = [porder[chunks[1] - 1], porder[chunks[1]], porder[chunks[2] - 1], porder[chunks[2]], 0, n - 1, order[0], order[-1],
+              order[n // 2], porder[0], porder[-1]]
     small = [int(k) for k in order[:3]] + [int(order[n // 2])]
     check_sample(inputs, params, scores, paths, sample, full_paths_for=small)
     assert any((p != 0).any() for p in paths[:50])  # unequal lengths: the optimal paths carry gaps
