@@ -25,6 +25,25 @@ def test_oracle_matches_hand_derived_fixture():
     assert fasta == open(os.path.join(GOLDEN, "make_handmade.fasta")).read()
 
 
+def test_oracle_matches_second_hand_derived_fixture():
+    """tests/golden/make_handmade2.*: reverse-strand rows, a column gapped in every row, consensus 'N' cases, three blocks with a
+    comment and blank lines between them, a file that ends without a blank line.  Derived by hand from the cited lines:
+      block 0 (6 columns, `a score=3 foo`: the prefix "a score=" is all that is looked at, m_profile_stream.ml:23-32)
+        A.c 4 4 - 30: of_maf Reverse (m_range.ml:60-65) = (30-4, 30-4-3) = (26, 23); AC--GT -> gaps (3,4)
+        B.c 0 4 + 12: (1, 4);  -C-NGT -> gaps (1,1) (3,3)        C.c 2 2 + 9: (3, 4);  ----aN -> gaps (1,4)
+        consensus, combine_text folded over the rows (m_make.ml:15-28,35-45):
+          AC--GT x -C-NGT: A|- -> A, C|C -> C, -|- -> -, -|N -> N, G|G, T|T          = AC-NGT
+          AC-NGT x ----aN: A, C, - (gapped in every row stays '-'), N|- -> N, G|a -> N (both bases, unequal: case counts),
+                           T|N -> N                                                    = AC-NNN
+      block 1: A.c 0 3 + 30 --TTT -> (1,3), gaps (1,2); a one-row block is its own consensus
+      block 2 (after a blank line and a comment, which drop_until_score skips): B.c 5 2 - 12 -> (12-5, 12-5-1) = (7, 6), G-g ->
+        gaps (2,2); C.c 0 1 - 9 -> (9, 9), --T -> gaps (1,2); consensus G|- -> G, -|- -> -, g|T -> N = G-N; the stream ends at
+        end of file with idx > 0 (m_profile_stream.ml:55-56)."""
+    prof, fasta = make_oracle.make(open(os.path.join(GOLDEN, "make_handmade2.maf")).read(), "y")
+    assert prof == open(os.path.join(GOLDEN, "make_handmade2.profiles")).read()
+    assert fasta == open(os.path.join(GOLDEN, "make_handmade2.fasta")).read()
+
+
 def test_oracle_rejects_what_the_reference_rejects():
     with pytest.raises(ValueError):
         make_oracle.make("a score=1\ns\ttabbed 0 1 + 1 A\n", "x")  # "Unknown line": not prefixed by "s "
@@ -54,12 +73,14 @@ def test_profiles_written_by_oracle_are_read_back_by_the_translate_parser(tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["handmade", "synthetic", "empty"])
+@pytest.mark.parametrize("case", ["handmade", "handmade2", "synthetic", "empty"])
 def test_gpu_make_equals_oracle(case, tmp_path):
     import numpy as np
     from paramugsy_amd import capi, synth
     if case == "handmade":
         maf = open(os.path.join(GOLDEN, "make_handmade.maf")).read()
+    elif case == "handmade2":
+        maf = open(os.path.join(GOLDEN, "make_handmade2.maf")).read()
     elif case == "synthetic":
         rng = np.random.default_rng(11)
         maf = synth.side_to_maf_text(synth.gen_side(rng, ["A.c", "B.c", "C.c"], 60000, 80, mean_cols=500, gap_rate=0.03, edge_gap_prob=0.4))
@@ -73,6 +94,10 @@ def test_gpu_make_equals_oracle(case, tmp_path):
     prof, fasta = make_oracle.make(maf, "x")
     assert (out / "profiles").read_text() == prof
     assert (out / "sequences.fasta").read_text() == fasta
+    if case == "handmade2":  # and the hand-derived bytes themselves (the fixture's basename is y)
+        capi.check(capi.lib().pm_profiles_make(str(src).encode(), str(out).encode(), b"y", 0))
+        assert (out / "profiles").read_text() == open(os.path.join(GOLDEN, "make_handmade2.profiles")).read()
+        assert (out / "sequences.fasta").read_text() == open(os.path.join(GOLDEN, "make_handmade2.fasta")).read()
 
 
 @pytest.mark.gpu

@@ -37,6 +37,33 @@ def test_oracle_matches_hand_derived_fixture():
     assert got == open(os.path.join(CASE, "expected.maf")).read()
 
 
+def test_oracle_matches_second_hand_derived_fixture():
+    """tests/golden/untranslate_handmade2 (profiles = tests/golden/make_handmade2.profiles): reverse-strand rows, a row that is all
+    gap in the asked range (dropped), gaps in the line text, one-base ranges (where the reference loses the strand), pass-through
+    of comments / blank lines / `a score=` lines, `##maf` dropped.  Rows: P0 A.c (26,23) gaps (3,4) AC--GT; P1 B.c (1,4) gaps
+    (1,1)(3,3) -C-NGT; P2 C.c (3,4) gaps (1,4) ----aN; y.y_0002: P4 B.c (7,6) gaps (2,2) G-g; P5 C.c (9,9) gaps (1,2) --T.
+    By hand from m_untranslate.ml:38-123 and m_profile.ml:163-264:
+      `s y.y_0000 0 6 + 6 ACGTAC` -> columns (1,6) forward: every row comes back as the MAF row `make` read
+         (P0: seq(1) = 26, seq(6) = 26-3 = 23, real (26,23) on '-': start 30-26 = 4 size 4 ...).
+      `s y.y_0000 1 3 - 6 T-A-C` -> of_maf Reverse (6-1, 6-1-2) = (5,3): reverse overlap, rows clipped to columns (3,5)
+         P0: gap (3,4) starts the range -> seq(5) = 26-2 = 24 twice: real = reverse (24,24) = (24,24), Forward: start 23 size 1,
+             strand of reverse (26,23) = '+'; text --G reversed G--, over T-A-C: G - - - - , complemented      => C----
+         P1: seq(4) = 2, seq(5) = 3 -> real (3,2) Reverse: start 12-3 = 9 size 2, strand of (4,1) = '-'; -NG reversed GN- over
+             T-A-C: G - N - -, complemented                                                                    => C-N--
+         P2: seq(5) = 3 twice -> real (3,3) is FORWARD by get_direction (s <= e) so start = 3-1 = 2 (a '-' row would want
+             9-3 = 6: the reference's one-base quirk), strand of reverse (3,4) = '-'; --a reversed a-- -> a----  => t----
+      `s y.y_0000 2 2 + 6 GT` -> columns (3,4): P0 and P2 are all gap there (subset_profile = None, row dropped);
+         P1: gap (3,3) starts the range -> seq(4) = 2 twice: start 1 size 1; -N over GT                        => -N
+      `s y.y_0002 0 3 + 3 A--CG-` -> columns (1,3): P4: seq(1) = 7, seq(3) = 7-1 = 6, real (7,6) '-': start 12-7 = 5 size 2; G-g
+         over A--CG-: G - - - g -; P5: (9,9) reads Forward (one base): start 8 size 1 '+'; --T over A--CG-: - - - - T -
+      `s y.y_0002 0 1 - 3 c` -> of_maf Reverse (3,3), which is Forward by get_direction: columns (3,3), no reversal;
+         P4: seq(3) = 6: real (6,6) Forward -> start 5, strand of (7,6) = '-'                                  => s B.c 5 1 - 12 g
+         P5: seq(3) = 9: start 8 '+'                                                                           => s C.c 8 1 + 9 T"""
+    case = os.path.join(GOLDEN, "untranslate_handmade2")
+    got = uo.untranslate([open(os.path.join(case, "profiles")).read()], open(os.path.join(case, "in.maf")).read())
+    assert got == open(os.path.join(case, "expected.maf")).read()
+
+
 def synthetic_case(seed):
     """Two profile sets from `make`, and a fake mugsy MAF whose `s` lines cover random column ranges of random blocks on
     either strand, with a few gap columns sprinkled into the line text."""
@@ -81,12 +108,13 @@ def test_oracle_output_is_a_consistent_maf(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["handmade", "synthetic1", "synthetic2"])
+@pytest.mark.parametrize("case", ["handmade", "handmade2", "synthetic1", "synthetic2"])
 def test_gpu_untranslate_equals_oracle(case, tmp_path):
     import ctypes as C
     from paramugsy_amd import capi
-    if case == "handmade":
-        profs, maf = [open(os.path.join(CASE, "profiles")).read()], open(os.path.join(CASE, "in.maf")).read()
+    if case.startswith("handmade"):
+        cdir = os.path.join(GOLDEN, "untranslate_" + case)
+        profs, maf = [open(os.path.join(cdir, "profiles")).read()], open(os.path.join(cdir, "in.maf")).read()
     else:
         profs, maf = synthetic_case(int(case[-1]))
     dirs = []
@@ -99,6 +127,8 @@ def test_gpu_untranslate_equals_oracle(case, tmp_path):
     arr = (C.c_char_p * len(dirs))(*dirs)
     capi.check(capi.lib().pm_untranslate(arr, len(dirs), str(tmp_path / "in.maf").encode(), str(tmp_path / "out.maf").encode(), 0))
     assert (tmp_path / "out.maf").read_text() == uo.untranslate(profs, maf)
+    if case.startswith("handmade"):  # the hand-derived bytes themselves
+        assert (tmp_path / "out.maf").read_text() == open(os.path.join(GOLDEN, "untranslate_" + case, "expected.maf")).read()
     # and through the executable, as the task script calls it
     (tmp_path / "dirs.list").write_text("".join(d.decode() + "\n" for d in dirs))
     r = subprocess.run([os.path.join(ROOT, "bin", "mugsy_profiles"), "untranslate", "-profile_paths_list", str(tmp_path / "dirs.list"),
