@@ -387,12 +387,16 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
                    "name": cfg_name, "pairs_per_rank": n, "rows": rows, "columns": cfg["len"], "cells_per_step_per_rank": cells,
                    "chunks": info["chunks"], "kernel_variant": variant,
                    "reference_counterpart": "none: the reference has no DP (SURVEY.md 0); specification and oracle are this repo's own"},
-        "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_walk_kernel" if variant.get("checkpoints") else "dp_traceback_kernel": ms_tb},
+        "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_walk_kernel" if variant.get("checkpoints") else "dp_traceback_kernel": ms_tb,
+                      "note": "device time summed over the step's launches (one fill and one path launch per workspace chunk; with several "
+                              "chunks the path kernel of chunk c runs beside the fill kernel of chunk c + 1, so the two sums overlap)"},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": measured_traffic("dp_fill_kernel", "dp:%s:%d:%d:%d" % (cfg_name, n, rows, cfg["len"])),
                      "kernel": "dp_fill_kernel",
-                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "launches_per_step": info["chunks"],
+                     "avg_launch_ms": ms_fill / max(1, info["chunks"]),
+                     "algorithmic_bytes_per_launch": alg_bytes // max(1, info["chunks"]),
                      "valu": {"ops_per_cell": ops_per_cell, "achieved_Tops": cells * ops_per_cell / (ms_fill * 1e-3) / 1e12,
                               "peak_Tops": valu_peak / 1e12, "frac": cells * ops_per_cell / (ms_fill * 1e-3) / valu_peak,
                               "note": "useful cell instructions only (per-step overhead, wavefront fill/drain and column padding "

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""After `gpurun -- bash tools/refresh_profiles.sh`: condense gpurun_out/refresh/ into profiles/ (see profiles/README.md)."""
+"""After `gpurun -- bash tools/refresh_profiles.sh`: condense gpurun_out/refresh/ into profiles/ (see profiles/README.md).
+Round tag as first argument (default r02)."""
 import csv
 import json
 import os
@@ -10,28 +11,42 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "refresh")
 P = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 tool = os.path.join(ROOT, "tools", "summarize_prof.py")
-subprocess.run([sys.executable, tool, "stats", os.path.join(O, "stats"), os.path.join(P, "r01_bench_kernel_stats.csv")], check=True)
-subprocess.run([sys.executable, tool, "pmc", "/tmp/pmc_all.json", "fetch=" + os.path.join(O, "fetch"), "write=" + os.path.join(O, "write"),
-                "sq=" + os.path.join(O, "sq")], check=True)
-allk = json.load(open("/tmp/pmc_all.json"))
-keep = ("FETCH_SIZE", "WRITE_SIZE")
-dp = {k: {c: v for c, v in x.items() if c in keep} for k, x in allk.items() if "dp_" in k}
-tr = {k: {c: v for c, v in x.items() if c in keep} for k, x in allk.items() if "translate_" in k or "scatter_live" in k or "rocprim" in k.lower()}
 bench = json.load(open(os.path.join(O, "bench.json")))
-cfg = bench["config"]
-table = {"dp:%d:%d:%d" % (cfg["pairs_per_rank"], cfg["rows"], cfg["columns"]): dp, "translate:4:1000000:2500:16:6000": tr,
-         "_about": "per-kernel means over the dispatches of `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` (two separate runs of "
-                   "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`); units: KB as rocprofv3 reports; bench.py applies the gfx950 x2 "
-                   "correction to FETCH_SIZE"}
-json.dump(table, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
-sq = {k: {c: round(v["mean"]) for c, v in x.items() if c.startswith("SQ_")} for k, x in allk.items() if "dp_fill" in k or "translate_" in k}
-json.dump(sq, open(os.path.join(P, "r01_sq_counters.json"), "w"), indent=1)
-shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "r01_bench_default.json"))
+shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "%s_bench_default.json" % TAG))
+table_path = os.path.join(P, "pmc_traffic.json")
+table = json.load(open(table_path)) if os.path.exists(table_path) else {}
+keep = ("FETCH_SIZE", "WRITE_SIZE")
+sq_all = {}
+keys = {"ns": "dp:ns:%d:%d:%d" % (bench["config"]["pairs_per_rank"], bench["config"]["rows"], bench["config"]["columns"]),
+        "c1": "dp:c1:10000:2:1000", "tr": "translate:4:1000000:2500:16:6000"}
+for name, key in keys.items():
+    if not os.path.isdir(os.path.join(O, name + "_stats")):
+        continue
+    subprocess.run([sys.executable, tool, "stats", os.path.join(O, name + "_stats"), os.path.join(P, "%s_%s_kernel_stats.csv" % (TAG, name))], check=True)
+    subprocess.run([sys.executable, tool, "pmc", "/tmp/pmc_%s.json" % name, "fetch=" + os.path.join(O, name + "_fetch"),
+                    "write=" + os.path.join(O, name + "_write"), "sq=" + os.path.join(O, name + "_sq")], check=True)
+    allk = json.load(open("/tmp/pmc_%s.json" % name))
+    table[key] = {k: {c: v for c, v in x.items() if c in keep} for k, x in allk.items()
+                  if any(t in k for t in ("dp_", "translate_", "scatter_live", "rocprim"))}
+    sq_all[key] = {k: {c: round(v["mean"]) for c, v in x.items() if c.startswith("SQ_")} for k, x in allk.items()
+                   if any(t in k for t in ("dp_fill", "dp_walk", "translate_"))}
+table["_about"] = ("per-kernel means over the dispatches of `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` (separate runs of "
+                   "`python3 bench.py <workload> --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end`, one workload per run: tools/refresh_profiles.sh); "
+                   "units: KB as rocprofv3 reports; bench.py applies the gfx950 x2 correction to FETCH_SIZE")
+json.dump(table, open(table_path, "w"), indent=1)
+json.dump(sq_all, open(os.path.join(P, "%s_sq_counters.json" % TAG), "w"), indent=1)
 print("DP   %.1f GCUPS  %.3f ms/step  %s" % (bench["value"], bench["ms_per_step"], bench["kernel_ms"]))
-t = bench["translate"]
-print("TR   %.3g units/s  %.3f ms/step  %s  frac %.3f  traffic %s" % (t["value"], t["ms_per_step"], t["kernel_ms"], t["roofline"]["frac"], t["roofline"]["traffic"]))
-print("CLI ", t.get("cli_whole_job"), t.get("cpu_baseline", {}).get("value"))
-for r in csv.DictReader(open(os.path.join(P, "r01_bench_kernel_stats.csv"))):
-    if float(r["Percentage"]) > 0.3:
-        print("   %-50s %4s x %8.1f us" % (r["Name"][:50], r["Calls"], float(r["AverageNs"]) / 1e3))
+if "c1" in bench:
+    print("c1   %.1f GCUPS  %.3f ms/step  %s" % (bench["c1"]["value"], bench["c1"]["ms_per_step"], bench["c1"]["kernel_ms"]))
+t = bench.get("translate")
+if t:
+    print("TR   %.3g units/s  %.3f ms/step  %s  frac %.3f" % (t["value"], t["ms_per_step"], t["kernel_ms"], t["roofline"]["frac"]))
+for name in keys:
+    f = os.path.join(P, "%s_%s_kernel_stats.csv" % (TAG, name))
+    if os.path.exists(f):
+        print(name)
+        for r in csv.DictReader(open(f)):
+            if float(r["Percentage"]) > 0.3:
+                print("   %-60s %4s x %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
