@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--dp-pairs", type=int, default=0)
     ap.add_argument("--dp-rows", type=int, default=0)
     ap.add_argument("--dp-len", type=int, default=0)
+    ap.add_argument("--dp-budget-gib", type=float, default=0.0, help="path workspace budget (0: the library's default, 32 GiB)")
     return ap.parse_args()
 
 
@@ -356,7 +357,7 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
     inputs, n_total = dp_inputs_for(cfg_name, cfg, rank, world, args.scaling, args.strong_factor)
     n = inputs.n_pairs
     params = dpm.make_params(rows, rows)
-    batch = dpm.DpBatch(inputs, params, device=local)
+    batch = dpm.DpBatch(inputs, params, device=local, tb_budget_bytes=int(args.dp_budget_gib * (1 << 30)))
     stream = torch.cuda.current_stream().cuda_stream
     dt = timed_region(torch, dist, lambda: batch.run(True, stream), steps, warmup)
     info = batch.info()

@@ -208,8 +208,9 @@ typedef struct pm_dp_params {
 
 typedef struct pm_dp_batch pm_dp_batch_t; /* opaque; owns device memory */
 
-/* Upload a batch (host pointers).  tb_budget_bytes bounds the traceback workspace (<= 0: 32 GiB); pairs are
- * processed in consecutive chunks that fit it. */
+/* Upload a batch (host pointers).  tb_budget_bytes bounds the path workspace (<= 0: 96 GiB, at most 40 % of the device's
+ * memory); a batch that needs more is processed in chunks that fit it, the path kernel of one chunk beside the fill kernel of
+ * the next. */
 int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
                        const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out);
 /* One pass over every pair: fill (scores, and what the path walk needs) and, when traceback != 0, the path walk.
@@ -240,7 +241,7 @@ void pm_dp_batch_destroy(pm_dp_batch_t *batch);
  * brings the results back on a download stream.  Same inputs, same outputs and same output layout as
  * pm_dp_batch_create + run + fetch (ops == n_ops == NULL: scores only); the device buffers are kept from call to call.
  * Copies are asynchronous only from / to pinned host memory: pm_dp_host_alloc / pm_dp_host_free hand it out (pageable buffers
- * work, their copies just serialise on the host).  workspace_bytes: path workspace (<= 0: 32 GiB).  Blocking: returns when
+ * work, their copies just serialise on the host).  workspace_bytes: path workspace (<= 0: as pm_dp_batch_create).  Blocking: returns when
  * every result is in the caller's arrays. */
 typedef struct pm_dp_stream pm_dp_stream_t;
 int pm_dp_host_alloc(void **ptr, int64_t bytes);

@@ -457,7 +457,16 @@ int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budge
       }
     }
   }
-  h->tb_budget_bytes = tb_budget_bytes > 0 ? tb_budget_bytes : (int64_t)32 << 30;
+  // default path workspace: 96 GiB, at most 40 % of the device's memory (288 GB of HBM3E: the north-star's per-GPU share of
+  // 12 500 pairs of 8 x 4 kbp needs 53 GB of checkpoints and then runs as one chunk, one fill launch with every SIMD full)
+  if(tb_budget_bytes <= 0) {
+    size_t free_b = 0, total_b = 0;
+    tb_budget_bytes = (int64_t)96 << 30;
+    if(hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+      tb_budget_bytes = std::min<int64_t>(tb_budget_bytes, (int64_t)(total_b / 10 * 4));
+    }
+  }
+  h->tb_budget_bytes = tb_budget_bytes;
   PM_TRY(h->pipe_error.alloc(4));
   PM_HIP(hipMemset(h->pipe_error.p, 0, 4));
   PM_TRY(h->stats.alloc(16));

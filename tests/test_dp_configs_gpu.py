@@ -26,15 +26,17 @@ def check_sample(inputs, params, scores, paths, sample, full_paths_for=()):
         assert o_scores[0] == scores[k] and np.array_equal(o_paths[0], paths[k]), "oracle path of pair %d" % k
 
 
-def test_north_star_shape_one_gpu_share_default_budget(oracle_build):
-    """12 500 pairs of 8 rows x 4 096 columns (one GPU's eighth of the north-star's 100 k) at the DEFAULT traceback budget, so
-    that several chunks of the workspace really run."""
+@pytest.mark.parametrize("budget_gib", [0, 24])
+def test_north_star_shape_one_gpu_share(budget_gib, oracle_build):
+    """12 500 pairs of 8 rows x 4 096 columns (one GPU's eighth of the north-star's 100 k): at the default workspace budget (one
+    chunk on a 288 GB device) and at 24 GiB, where the chunk pipeline runs (path kernel of chunk c beside fill kernel of c + 1)."""
     n, rows, L = 12500, 8, 4096
     inputs = dp.synth_batch(20261003, np.full(n, L), np.full(n, L), rows, rows)
     params = dp.make_params(rows, rows)
-    batch = dp.DpBatch(inputs, params)
+    batch = dp.DpBatch(inputs, params, tb_budget_bytes=budget_gib << 30)
     chunks, order = batch.chunks()
-    assert len(chunks) - 1 >= 3, "the default budget must split this batch into several chunks"
+    if budget_gib:
+        assert len(chunks) - 1 >= 3, "this budget must split the batch into several chunks"
     batch.run(traceback=True)
     scores, ops, n_ops = batch.fetch()
     paths = batch.paths(ops, n_ops)
@@ -42,7 +44,7 @@ def test_north_star_shape_one_gpu_share_default_budget(oracle_build):
     for c in range(len(chunks) - 1):
         sample += [order[chunks[c]], order[chunks[c + 1] - 1]]
     sample += list(np.random.default_rng(1).integers(0, n, size=6))
-    check_sample(inputs, params, scores, paths, sample, full_paths_for=[order[chunks[1] - 1], order[chunks[1]]])
+    check_sample(inputs, params, scores, paths, sample, full_paths_for=[order[chunks[1] - 1], order[min(chunks[1], n - 1)]])
     assert all(len(p) >= L for p in paths[::97])
     # score-only pass: same scores
     batch.run(traceback=False)
