@@ -227,8 +227,9 @@ int pm_dp_batch_info(pm_dp_batch_t *batch, int64_t *cells, int64_t *traceback_by
  * (n_pairs values, may be NULL); chunk c covers positions [first_position[c], first_position[c+1]), first_position[n_chunks] =
  * n_pairs (at most `capacity` values are written). */
 int pm_dp_batch_chunks(pm_dp_batch_t *batch, int64_t *first_position, int32_t capacity, int32_t *order);
-/* Which kernel variant the batch runs: columns of B per lane (8/16), whether the int8 dot4 path applies, and the VALU
- * instructions per DP cell of that variant (for roofline accounting). */
+/* Which kernel variant the batch runs: columns of B per lane (8/16); *dot4 bit 0 = the int8 dot4 path applies, bit 1 = uniform
+ * depth (every column of A holds the same number of symbols, so the gap row of the score is folded into the base weights and a
+ * per-column constant); and the VALU instructions per DP cell of that variant (for roofline accounting). */
 int pm_dp_batch_variant(pm_dp_batch_t *batch, int32_t *cols_per_lane, int32_t *dot4, int32_t *valu_ops_per_cell);
 /* How the batch gets its paths: checkpoints != 0 -> the fill kernel computes scores only and leaves row/column checkpoints,
  * and the walk re-runs the recurrence inside the block_rows x block_columns blocks the path crosses (the default);

@@ -24,6 +24,7 @@ struct pm_dp_batch {
   pm::i64 cells = 0;
   int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
   bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
+  bool uni = false;       // every column of A holds the same number of symbols: gap row folded into the weights (PM_DP_UNI=0 disables)
   int waves_override = 0; // PM_DP_WAVES=1|2|4|8 forces the waves-per-pair choice
   bool ckpt = true;       // paths from checkpoints + block recomputation (dp_walk.hip); PM_DP_MODE=bits stores 4 bits per cell
   int walk_lanes = 0;     // lanes per pair of the checkpoint walk; 0 = chosen per launch; PM_DP_WALK_LANES overrides
@@ -48,7 +49,7 @@ struct pm_dp_batch {
   // pinned host staging of a reusable batch (dp_stream.hip): offsets, workspace offsets and the column statistics
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
-  int host_stats[4] = {0, 0, 0, 0};
+  int host_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   ~pm_dp_batch() {
     for(std::vector<hipEvent_t> *v : {&ev_fill, &ev_path, &tv_fill0, &tv_fill1, &tv_path0, &tv_path1, &ev_seg}) {
       for(hipEvent_t e : *v) {

@@ -26,6 +26,7 @@ struct DpParamsD {
   int sub[25];
   int go;
   int ge;
+  int rows_a; // the number of symbols every column of A holds when that is one number for the whole batch (UNI kernels), else 0
 };
 
 // Block geometry of the checkpoints (compile-time; -DDP_CK_R=.. -DDP_CK_W=.. for experiments):
@@ -92,6 +93,9 @@ __device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)
 #define PM_CELL_SCORE4 "v_dot4c_i32_i8 %[dp], %[ax], %[w0]\n\t"
 #define PM_CELL_SCORE2 "v_dot2_i32_i16 %[dp], %[ax], %[w0], %[dp]\n\tv_dot2_i32_i16 %[dp], %[az], %[w1], %[dp]\n\t"
 #define PM_CELL_NEXT "v_dot2_i32_i16 %[dn], %[ay], %[w2n], %[hop]\n\t"
+// uniform depth (every column of A holds the same number of symbols): the gap row of the score is folded into the base
+// weights and a per-column constant, so the next cell's diagonal is a plain add (full-rate) instead of a dot2 (half-rate)
+#define PM_CELL_NEXT_U "v_add_u32 %[dn], %[hop], %[w2n]\n\t"
 #define PM_CELL_H "v_max3_i32 %[h], %[dp], %[e], %[f]\n\t"
 #define PM_CELL_H_T                                                                                                    \
   "v_max3_i32 %[h], %[dp], %[e], %[f]\n\tv_sub_u32 %[t], %[dp], %[h]\n\tv_alignbit_b32 %[acc], %[acc], %[t], 31\n\t"   \
@@ -100,53 +104,73 @@ __device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)
 #define PM_CELL_OPERANDS                                                                                               \
   [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t), [h] "=&v"(h)  \
       : [hl] "v"(hl), [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az), [w0] "v"(w0), [w1] "v"(w1), [w2n] "v"(w2n), [gop] "s"(gop)
-template <bool TRACE, bool LAST, bool DOT4>
+template <bool TRACE, bool LAST, bool DOT4, bool UNI = false>
 __device__ __forceinline__ void dp_cell(int &dp, int &dn, int &e, int &f, int &hop, unsigned &acc, int hl, int ax, int ay,
                                         int az, int w0, int w1, int w2n, int gop) {
   int t, h;
+#define PM_CELL_ASM(BODY) asm volatile(BODY : PM_CELL_OPERANDS)
   if(TRACE) {
     if(LAST) { // the trailing s_nop keeps hop two wait states away from the DPP read that follows the step
       if(DOT4) {
-        asm volatile(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1");
       }
       else {
-        asm volatile(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1");
+      }
+    }
+    else if(UNI) {
+      if(DOT4) {
+        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT_U PM_CELL_H_T PM_CELL_OUT);
+      }
+      else {
+        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT_U PM_CELL_H_T PM_CELL_OUT);
       }
     }
     else {
       if(DOT4) {
-        asm volatile(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT : PM_CELL_OPERANDS);
+        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT);
       }
       else {
-        asm volatile(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT : PM_CELL_OPERANDS);
+        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT);
       }
     }
   }
   else { // score only: 6 (7) ops; s_nops stand in for the decision ops that separate the dot ops from their readers
     if(LAST) {
       if(DOT4) {
-        asm volatile(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1");
       }
       else {
-        asm volatile(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1" : PM_CELL_OPERANDS);
+        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1");
+      }
+    }
+    else if(UNI) {
+      if(DOT4) {
+        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT_U "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT);
+      }
+      else {
+        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT_U "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT);
       }
     }
     else {
       if(DOT4) {
-        asm volatile(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT : PM_CELL_OPERANDS);
+        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT);
       }
       else {
-        asm volatile(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT : PM_CELL_OPERANDS);
+        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT);
       }
     }
   }
+#undef PM_CELL_ASM
 }
-
 
 // B's packed column -> the cell's weight registers: w[a] = sum_b count[b] * sub[a][b]; w0/w1 hold the four base weights
 // (four int8 with DOT4, else two int16 pairs), w2 = (w[gap], go + ge): A's third pair is (nGap, 1), the 1 picks up gop + 2 * ge.
-template <bool DOT4>
-__device__ __forceinline__ void dp_column_weights(u64 col, bool in, const DpParamsD &P, int &w0, int &w1, int &w2) {
+// UNI (every column of A holds rows_a symbols, so nGap = rows_a - nA - nC - nG - nT): the score sum_a A[a] * w[a] is rewritten
+// as sum_{a < 4} A[a] * (w[a] - w[gap]) + rows_a * w[gap]; w0/w1 hold the differences and w2 the whole per-column constant
+// rows_a * w[gap] + go + ge (a plain int, added instead of dotted).
+template <bool DOT4, bool UNI = false>
+__device__ __forceinline__ void dp_column_weights(u64 col, bool in, const DpParamsD &P, int &w0, int &w1, int &w2, int rows_a = 0) {
   int cb[5], w[5];
 #pragma unroll
   for(int b = 0; b < 5; ++b) {
@@ -161,6 +185,13 @@ __device__ __forceinline__ void dp_column_weights(u64 col, bool in, const DpPara
     }
     w[a] = acc;
   }
+  if(UNI) {
+    w2 = in ? rows_a * w[4] + P.go + P.ge : 0;
+#pragma unroll
+    for(int a = 0; a < 4; ++a) {
+      w[a] -= w[4];
+    }
+  }
   if(DOT4) {
     w0 = (int)(((unsigned)w[0] & 0xffu) | (((unsigned)w[1] & 0xffu) << 8) | (((unsigned)w[2] & 0xffu) << 16) | ((unsigned)w[3] << 24));
     w1 = 0;
@@ -169,7 +200,9 @@ __device__ __forceinline__ void dp_column_weights(u64 col, bool in, const DpPara
     w0 = pack16(w[0], w[1]);
     w1 = pack16(w[2], w[3]);
   }
-  w2 = pack16(w[4], in ? P.go + P.ge : 0);
+  if(!UNI) {
+    w2 = pack16(w[4], in ? P.go + P.ge : 0);
+  }
 }
 
 // A's packed column -> what the cell reads per row: x = nA, nC, nG, nT as four int8 (DOT4) or (nA, nC) as an int16 pair,

@@ -72,7 +72,7 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 // stripe may start a 64-row block as soon as the stripe to its left has published those rows of its boundary:
 // a pipeline of stripes, synchronised through one progress word per wave in LDS.  Waits are bounded (a timeout sets
 // *pipe_error and lets the wave run on, so the grid always drains).
-template <int C, int MODE, bool DOT4, int NW>
+template <int C, int MODE, bool DOT4, int NW, bool UNI>
 __global__ void __launch_bounds__(64 * NW)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
@@ -125,7 +125,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     for(int c = 0; c < C; ++c) {
       const int j = j0 + c;
       const bool in = j < lb;
-      dp_column_weights<DOT4>(in ? B[j] : 0ull, in, P, w0[c], w1[c], w2[c]);
+      dp_column_weights<DOT4, UNI>(in ? B[j] : 0ull, in, P, w0[c], w1[c], w2[c], P.rows_a);
       hop[c] = -2 * gop;                      // H~[0][j+1] - gop, H~[0][j] = -gop for j >= 1
       f[c] = DP_NEG_INF;
     }
@@ -211,17 +211,22 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         }
         {
           int dd[2];
-          asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(a.y), "v"(w2[0]), "v"(diag_in));
+          if(UNI) {
+            dd[0] = diag_in + w2[0];
+          }
+          else {
+            asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(a.y), "v"(w2[0]), "v"(diag_in));
+          }
 #pragma unroll
           for(int c = 0; c < C; ++c) {
             const int hl = c == 0 ? ho_in : hop[c == 0 ? 0 : c - 1];
             if(c == C - 1) {
-              dp_cell<TRACE, true, DOT4>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, DOT4 ? a.x : a.z,
-                                         w0[c], DOT4 ? w0[c] : w1[c], 0, gop);
+              dp_cell<TRACE, true, DOT4, UNI>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, DOT4 ? a.x : a.z,
+                                              w0[c], DOT4 ? w0[c] : w1[c], 0, gop);
             }
             else {
-              dp_cell<TRACE, false, DOT4>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, DOT4 ? a.x : a.z,
-                                          w0[c], DOT4 ? w0[c] : w1[c], w2[c + 1 < C ? c + 1 : c], gop);
+              dp_cell<TRACE, false, DOT4, UNI>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, DOT4 ? a.x : a.z,
+                                               w0[c], DOT4 ? w0[c] : w1[c], w2[c + 1 < C ? c + 1 : c], gop);
             }
           }
         }
@@ -376,10 +381,11 @@ dp_traceback_kernel(const i64 *__restrict__ off_a, const i64 *__restrict__ off_b
   }
 }
 
-// Largest ACGT count of any column (stats[0]) and largest row total of any column (stats[1]): what decides between
-// the int8 and the int16 weights.  One pass over the packed columns, grid-stride, one atomic per wavefront.
-__global__ void dp_column_stats_kernel(const u64 *cols, i64 n, int *stats) {
-  int max_base = 0, max_rows = 0;
+// Largest ACGT count of any column (stats[0]), largest and smallest symbol total (bytes 0-4) of any column (stats[1], and
+// 2047 - stats[4] so that a zeroed word is the neutral element): what decides between the int8 and the int16 weights and whether
+// every column holds the same number of symbols.  One pass over the packed columns, grid-stride, one atomic per wavefront.
+__global__ void dp_column_stats_kernel(const u64 *cols, i64 n, int *stats, int *stats_min) {
+  int max_base = 0, max_rows = 0, max_inv = 0;
   for(i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) {
     const u64 c = cols[k];
     int sum = 0;
@@ -392,15 +398,18 @@ __global__ void dp_column_stats_kernel(const u64 *cols, i64 n, int *stats) {
       }
     }
     max_rows = max(max_rows, sum);
+    max_inv = max(max_inv, 2047 - sum);
   }
 #pragma unroll
   for(int d = 32; d >= 1; d >>= 1) {
     max_base = max(max_base, __shfl_xor(max_base, d));
     max_rows = max(max_rows, __shfl_xor(max_rows, d));
+    max_inv = max(max_inv, __shfl_xor(max_inv, d));
   }
   if((threadIdx.x & 63) == 0) {
     atomicMax(stats + 0, max_base);
     atomicMax(stats + 1, max_rows);
+    atomicMax(stats_min, max_inv);
   }
 }
 
@@ -469,7 +478,7 @@ int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budge
   h->tb_budget_bytes = tb_budget_bytes;
   PM_TRY(h->pipe_error.alloc(4));
   PM_HIP(hipMemset(h->pipe_error.p, 0, 4));
-  PM_TRY(h->stats.alloc(16));
+  PM_TRY(h->stats.alloc(32));
   return PM_OK;
 }
 
@@ -521,7 +530,7 @@ int dp_batch_load(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, c
   PM_TRY(dp_batch_reserve(h, n_pairs, h->total_a, h->total_b));
   // the offsets go through pinned staging when the batch has it (so that the copy is asynchronous), else straight from the vectors
   const i64 *src_a = h->off_a.data(), *src_b = h->off_b.data();
-  if(h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 16) {
+  if(h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32) {
     i64 *pa = (i64 *)h->pinned, *pb = pa + (n_pairs + 1);
     memcpy(pa, src_a, (size_t)(n_pairs + 1) * 8);
     memcpy(pb, src_b, (size_t)(n_pairs + 1) * 8);
@@ -537,19 +546,19 @@ int dp_batch_load(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, c
     PM_HIP(hipMemcpyAsync(h->cols_b.p, cols_b + b0 * 8, (size_t)h->total_b * 8, hipMemcpyHostToDevice, stream));
   }
   // the ranges of the uploaded columns, found on the device (four 4-byte words back)
-  PM_HIP(hipMemsetAsync(h->stats.p, 0, 16, stream));
+  PM_HIP(hipMemsetAsync(h->stats.p, 0, 32, stream));
   if(h->total_a > 0) {
-    dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_a.p, h->total_a, (int *)h->stats.p);
+    dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_a.p, h->total_a, (int *)h->stats.p, (int *)h->stats.p + 4);
   }
   if(h->total_b > 0) {
-    dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_b.p, h->total_b, (int *)h->stats.p + 2);
+    dp_column_stats_kernel<<<1024, 256, 0, stream>>>((const u64 *)h->cols_b.p, h->total_b, (int *)h->stats.p + 2, (int *)h->stats.p + 5);
   }
   PM_HIP(hipGetLastError());
   int *dst = h->host_stats;
   if(h->pinned) {
-    dst = (int *)((char *)h->pinned + h->pinned_bytes - 16);
+    dst = (int *)((char *)h->pinned + h->pinned_bytes - 32);
   }
-  PM_HIP(hipMemcpyAsync(dst, h->stats.p, 16, hipMemcpyDeviceToHost, stream));
+  PM_HIP(hipMemcpyAsync(dst, h->stats.p, 32, hipMemcpyDeviceToHost, stream));
   return PM_OK;
 }
 
@@ -577,12 +586,12 @@ int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t 
     return fail(PM_E_INVALID, "pm_dp_batch_create: null columns");
   }
   PM_TRY(dp_batch_reserve(h, n_pairs, h->total_a, h->total_b));
-  if(!h->pinned || h->pinned_bytes < (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 16) { // offsets, workspace offsets, order, statistics
+  if(!h->pinned || h->pinned_bytes < (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32) { // offsets, workspace offsets, order, statistics
     if(h->pinned) {
       (void)hipHostFree(h->pinned);
       h->pinned = nullptr;
     }
-    h->pinned_bytes = (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 16;
+    h->pinned_bytes = (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32;
     PM_HIP(hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault));
   }
   i64 *pa = (i64 *)h->pinned, *pb = pa + (n_pairs + 1);
@@ -590,7 +599,7 @@ int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t 
   memcpy(pb, h->off_b.data(), (size_t)(n_pairs + 1) * 8);
   PM_HIP(hipMemcpyAsync(h->d_off_a.p, pa, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
   PM_HIP(hipMemcpyAsync(h->d_off_b.p, pb, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
-  PM_HIP(hipMemsetAsync(h->stats.p, 0, 16, stream));
+  PM_HIP(hipMemsetAsync(h->stats.p, 0, 32, stream));
   // segments of about equal numbers of columns (A + B), cut at pair boundaries
   segments = (int)std::max<int64_t>(1, std::min<int64_t>(segments, std::max<int64_t>(n_pairs, 1)));
   h->seg_first.assign(1, 0);
@@ -619,18 +628,18 @@ int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t 
     const i64 sa0 = h->off_a[(size_t)lo], sa1 = h->off_a[(size_t)hi], sb0 = h->off_b[(size_t)lo], sb1 = h->off_b[(size_t)hi];
     if(sa1 > sa0) {
       PM_HIP(hipMemcpyAsync((char *)h->cols_a.p + sa0 * 8, cols_a + (a0 + sa0) * 8, (size_t)(sa1 - sa0) * 8, hipMemcpyHostToDevice, stream));
-      dp_column_stats_kernel<<<256, 256, 0, stream>>>((const u64 *)h->cols_a.p + sa0, sa1 - sa0, (int *)h->stats.p);
+      dp_column_stats_kernel<<<256, 256, 0, stream>>>((const u64 *)h->cols_a.p + sa0, sa1 - sa0, (int *)h->stats.p, (int *)h->stats.p + 4);
     }
     if(sb1 > sb0) {
       PM_HIP(hipMemcpyAsync((char *)h->cols_b.p + sb0 * 8, cols_b + (b0 + sb0) * 8, (size_t)(sb1 - sb0) * 8, hipMemcpyHostToDevice, stream));
-      dp_column_stats_kernel<<<256, 256, 0, stream>>>((const u64 *)h->cols_b.p + sb0, sb1 - sb0, (int *)h->stats.p + 2);
+      dp_column_stats_kernel<<<256, 256, 0, stream>>>((const u64 *)h->cols_b.p + sb0, sb1 - sb0, (int *)h->stats.p + 2, (int *)h->stats.p + 5);
     }
     PM_HIP(hipGetLastError());
     if(sgi == 0 && stats_first) {
-      PM_HIP(hipMemcpyAsync(stats_first, h->stats.p, 16, hipMemcpyDeviceToHost, stream));
+      PM_HIP(hipMemcpyAsync(stats_first, h->stats.p, 32, hipMemcpyDeviceToHost, stream));
     }
     if(sgi + 1 == nseg) {
-      PM_HIP(hipMemcpyAsync((char *)h->pinned + h->pinned_bytes - 16, h->stats.p, 16, hipMemcpyDeviceToHost, stream));
+      PM_HIP(hipMemcpyAsync((char *)h->pinned + h->pinned_bytes - 32, h->stats.p, 32, hipMemcpyDeviceToHost, stream));
     }
     PM_HIP(hipEventRecord(h->ev_seg[sgi], stream));
   }
@@ -639,7 +648,7 @@ int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t 
 }
 
 int dp_batch_plan(pm_dp_batch *h, hipStream_t stream) {
-  return dp_batch_plan_with(h, h->pinned ? (const int *)((char *)h->pinned + h->pinned_bytes - 16) : h->host_stats, stream);
+  return dp_batch_plan_with(h, h->pinned ? (const int *)((char *)h->pinned + h->pinned_bytes - 32) : h->host_stats, stream);
 }
 
 int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
@@ -666,6 +675,36 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     }
   }
   h->dot4 = max_a <= 127 && max_colsum_b * h->max_sub_acgt <= 127;
+  // uniform depth: every column of A holds the same number of symbols (bytes 0-4), as the rows of a MAF block without N's do;
+  // the gap row of the score then folds into the base weights (w[a] - w[gap]) and a per-column constant (dp_column_weights)
+  {
+    const int min_colsum_a = 2047 - st[4];
+    int max_sub_gap = 0; // max |sub[gap][b]|
+    for(int b = 0; b < 5; ++b) {
+      max_sub_gap = std::max(max_sub_gap, std::abs(h->params.sub[4 * 5 + b]));
+    }
+    const bool uniform = h->total_a > 0 && st[1] == min_colsum_a && st[1] > 0;
+    const int64_t diff_bound = (int64_t)max_colsum_b * (h->max_sub_acgt + max_sub_gap); // |w[a] - w[gap]|
+    h->uni = uniform && diff_bound <= 32767 && (int64_t)st[1] * max_colsum_b * max_sub_gap < (1 << 28);
+    if(h->uni) {
+      // the differences are what the int8 lanes would hold: when they do not fit but the plain weights do, the general int8
+      // kernel (dot4 + dot2) beats the uniform int16 one (2 x dot2 + add)
+      const bool uni_dot4 = max_a <= 127 && diff_bound <= 127;
+      if(!uni_dot4 && h->dot4) {
+        h->uni = false;
+      }
+      else {
+        h->dot4 = uni_dot4;
+      }
+    }
+    if(const char *e = getenv("PM_DP_UNI")) {
+      if(atoi(e) == 0 && h->uni) {
+        h->uni = false;
+        h->dot4 = max_a <= 127 && max_colsum_b * h->max_sub_acgt <= 127;
+      }
+    }
+    h->params.rows_a = h->uni ? st[1] : 0;
+  }
   if(const char *e = getenv("PM_DP_DOT4")) {
     h->dot4 = h->dot4 && atoi(e) != 0;
   }
@@ -743,7 +782,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     int *ord = nullptr;
     std::vector<i64> tmp;
     std::vector<int> tmp_o;
-    const bool staged = h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 16;
+    const bool staged = h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32;
     if(staged) {
       flat = (i64 *)h->pinned + 2 * (n_pairs + 1);
       ord = (int *)((i64 *)h->pinned + 3 * (n_pairs + 1));
@@ -846,17 +885,23 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
       nw = h->waves_override;
     }
   }
-#define DP_LAUNCH_FILL(CC, TR, D4, NWV)                                                                                                   \
-  dp_fill_kernel<CC, TR, D4, NWV><<<(unsigned)n, 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,             \
-                                                                        (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p, order, tb_off, \
-                                                                        tbw, (int2 *)h->bnd.p, (int *)h->scores.p,                         \
-                                                                        (int *)h->pipe_error.p, h->params)
-#define DP_LAUNCH_FILL_D4(CC, TR, NWV) \
-  if(h->dot4) {                        \
-    DP_LAUNCH_FILL(CC, TR, true, NWV);  \
-  }                                    \
-  else {                               \
-    DP_LAUNCH_FILL(CC, TR, false, NWV); \
+#define DP_LAUNCH_FILL(CC, TR, D4, NWV, UN)                                                                                                  \
+  dp_fill_kernel<CC, TR, D4, NWV, UN><<<(unsigned)n, 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,           \
+                                                                            (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p, order, tb_off, \
+                                                                            tbw, (int2 *)h->bnd.p, (int *)h->scores.p,                       \
+                                                                            (int *)h->pipe_error.p, h->params)
+#define DP_LAUNCH_FILL_D4(CC, TR, NWV)         \
+  if(h->dot4 && h->uni) {                      \
+    DP_LAUNCH_FILL(CC, TR, true, NWV, true);   \
+  }                                            \
+  else if(h->dot4) {                           \
+    DP_LAUNCH_FILL(CC, TR, true, NWV, false);  \
+  }                                            \
+  else if(h->uni) {                            \
+    DP_LAUNCH_FILL(CC, TR, false, NWV, true);  \
+  }                                            \
+  else {                                       \
+    DP_LAUNCH_FILL(CC, TR, false, NWV, false); \
   }
 #define DP_LAUNCH_FILL_TR(CC, NWV)                \
   if(traceback && h->ckpt) {                      \
@@ -1144,12 +1189,12 @@ int pm_dp_batch_variant(pm_dp_batch_t *h, int32_t *cols_per_lane, int32_t *dot4,
     *cols_per_lane = h->cols_per_lane;
   }
   if(dot4) {
-    *dot4 = h->dot4 ? 1 : 0;
+    *dot4 = (h->dot4 ? 1 : 0) | (h->uni ? 2 : 0);
   }
   if(valu_ops_per_cell) {
     // per cell: column score (dot4 + dot2 = 2, or 3 x dot2), E 3, F 3, H + two decision bits 5, H - open 1;
     // without the decision bits (checkpoint mode): score 2 or 3, E 1, F 1, H 1, H - open 1
-    *valu_ops_per_cell = h->ckpt ? (h->dot4 ? 2 : 3) + 4 : (h->dot4 ? 2 : 3) + 3 + 3 + 5 + 1;
+    *valu_ops_per_cell = h->ckpt ? (h->dot4 ? 2 : 3) + 4 : (h->dot4 ? 2 : 3) + 3 + 3 + 5 + 1; // UNI: one of them a full-rate add
   }
   return PM_OK;
 }

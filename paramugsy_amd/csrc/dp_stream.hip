@@ -29,7 +29,7 @@ struct pm_dp_stream {
   pm_dp_batch *b = nullptr;
   hipStream_t up = nullptr, comp = nullptr, down = nullptr;
   hipEvent_t ev_comp = nullptr;
-  int *host_words = nullptr; // pinned: [0..3] statistics of the first segment, [4] the fill kernel's pipe error
+  int *host_words = nullptr; // pinned: [0..7] statistics of the first segment, [8] the fill kernel's pipe error
   ~pm_dp_stream() {
     delete b;
     if(ev_comp) {
@@ -89,7 +89,7 @@ int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t 
     hipok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
   }
   hipok(hipEventCreateWithFlags(&s->ev_comp, hipEventDisableTiming), "hipEventCreate");
-  hipok(hipHostMalloc((void **)&s->host_words, 8 * sizeof(int), hipHostMallocDefault), "hipHostMalloc");
+  hipok(hipHostMalloc((void **)&s->host_words, 16 * sizeof(int), hipHostMallocDefault), "hipHostMalloc");
   s->b = new(std::nothrow) pm_dp_batch();
   if(!s->b && !rc) {
     rc = fail(PM_E_INVALID, "out of host memory");
@@ -145,7 +145,7 @@ int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *
         PM_HIP(hipMemcpyAsync(ops, b->ops.p, (size_t)(b->total_a + b->total_b), hipMemcpyDeviceToHost, s->down));
       }
     }
-    PM_HIP(hipMemcpyAsync(&s->host_words[4], b->pipe_error.p, 4, hipMemcpyDeviceToHost, s->down));
+    PM_HIP(hipMemcpyAsync(&s->host_words[8], b->pipe_error.p, 4, hipMemcpyDeviceToHost, s->down));
     return (int)PM_OK;
   };
   if(!rc) {
@@ -158,9 +158,12 @@ int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *
   if(!rc) {
     rc = dp_batch_plan_with(b, s->host_words, s->comp);
   }
-  bool first_dot4 = false;
+  bool first_dot4 = false, first_uni = false;
+  int first_rows = 0;
   if(!rc) {
     first_dot4 = b->dot4;
+    first_uni = b->uni;
+    first_rows = b->params.rows_a;
     rc = run_and_fetch();
   }
   if(!rc) {
@@ -172,7 +175,7 @@ int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *
   }
   if(!rc) {
     rc = dp_batch_plan(b, s->comp);
-    if(!rc && b->dot4 != first_dot4) {
+    if(!rc && (b->dot4 != first_dot4 || b->uni != first_uni || b->params.rows_a != first_rows)) {
       drain();
       if(!rc) {
         rc = run_and_fetch();
@@ -180,7 +183,7 @@ int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *
     }
   }
   drain();
-  if(!rc && s->host_words[4]) {
+  if(!rc && s->host_words[8]) {
     rc = fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
   }
   return rc;

@@ -152,7 +152,8 @@ class DpBatch:
         capi.check(_lib().pm_dp_batch_variant(self._h, C.byref(a), C.byref(b), C.byref(c)))
         ck, br, bc = C.c_int32(), C.c_int32(), C.c_int32()
         capi.check(_lib().pm_dp_batch_path_mode(self._h, C.byref(ck), C.byref(br), C.byref(bc)))
-        return {"cols_per_lane": a.value, "dot4": bool(b.value), "valu_ops_per_cell": c.value, "checkpoints": bool(ck.value),
+        return {"cols_per_lane": a.value, "dot4": bool(b.value & 1), "uniform_depth": bool(b.value & 2), "valu_ops_per_cell": c.value,
+                "checkpoints": bool(ck.value),
                 "block_rows": br.value, "block_columns": bc.value}
 
     def fetch(self, with_paths: bool = True):

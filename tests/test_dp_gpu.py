@@ -138,6 +138,45 @@ def test_int8_path_selection_at_its_boundary(rows, expect_dot4, oracle_build):
     run_and_compare(inputs, params)
 
 
+@pytest.mark.parametrize("dot4", ["1", "0"])
+@pytest.mark.parametrize("mode", ["ckpt", "bits"])
+def test_uniform_depth_variant_and_its_fallbacks(dot4, mode, oracle_build, monkeypatch):
+    """Every column of A holding the same number of symbols (rows of a MAF block without N's) selects the kernels that fold the
+    gap row of the score into the base weights; one column with an N (counted in byte 5, so bytes 0-4 sum to one less) or
+    PM_DP_UNI=0 selects the general kernels.  All equal the oracle."""
+    monkeypatch.setenv("PM_DP_DOT4", dot4)
+    monkeypatch.setenv("PM_DP_MODE", mode)
+    inputs = dp.synth_pairs(61, 14, 4, 1300, indel_rate=0.02, vary_length=True)  # B up to two stripes
+    params = dp.make_params(4, 4)
+    b = dp.DpBatch(inputs, params)
+    assert b.variant()["uniform_depth"] and b.variant()["dot4"] == (dot4 == "1")
+    b.close()
+    run_and_compare(inputs, params)
+    monkeypatch.setenv("PM_DP_UNI", "0")
+    b = dp.DpBatch(inputs, params)
+    assert not b.variant()["uniform_depth"]
+    b.close()
+    run_and_compare(inputs, params)
+    monkeypatch.delenv("PM_DP_UNI")
+    cols_a = inputs.cols_a.copy()
+    cols_a[7, 0:4] = [1, 1, 1, 0]
+    cols_a[7, 4] = 0
+    cols_a[7, 5] = 1  # an N: neither base nor gap
+    ragged = dp.DpInputs(cols_a, inputs.off_a, inputs.cols_b, inputs.off_b)
+    b = dp.DpBatch(ragged, params)
+    assert not b.variant()["uniform_depth"]
+    b.close()
+    run_and_compare(ragged, params)
+    # A uniform, B not: still the uniform kernels (only A's depth matters)
+    cols_b = inputs.cols_b.copy()
+    cols_b[3, 4] = 0
+    half = dp.DpInputs(inputs.cols_a, inputs.off_a, cols_b, inputs.off_b)
+    b = dp.DpBatch(half, params)
+    assert b.variant()["uniform_depth"]
+    b.close()
+    run_and_compare(half, params)
+
+
 def test_weights_beyond_int16_are_refused():
     from paramugsy_amd import capi
     cols = np.zeros((4, 8), dtype=np.uint8)
