@@ -103,8 +103,9 @@ def make_maf_cases() -> None:
             r = subprocess.run([os.path.join(REF, "maf_analyzer"), src], stdout=fout)
         assert r.returncode == 0
         print("maf_%s ok" % name)
-    # BASELINE config 1: the reference's own tests/highly_stitchable.maf.  The input stays in /root/reference
-    # (not copied); only the bytes the reference printed for it are kept.
+    # BASELINE config 1: the reference's own tests/highly_stitchable.maf.  That file is a test vector the reference holds
+    # (data, not source); tests/golden/highly_stitchable.maf is a byte copy of it so that the GPU box, which has no
+    # /root/reference, can run the case.  The expected output is what the reference binary printed for it here.
     ref_maf = "/root/reference/tests/highly_stitchable.maf"
     if os.path.exists(ref_maf):
         with open(os.path.join(HERE, "maf_highly_stitchable.expected"), "w") as fout:
