@@ -132,34 +132,50 @@ def dist_setup(args):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libparamugsy_amd has no CPU path")
+    # PM_BENCH_REHEARSAL=1: every rank on device 0 and gloo instead of RCCL, to rehearse the N-rank flow on a one-GPU box
+    # (the numbers of such a run mean nothing; the line says so)
+    rehearsal = os.environ.get("PM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl")  # RCCL; used only for the timing barrier, the max-over-ranks and the rank census
+        # RCCL; used only for the timing barrier, the max-over-ranks and the rank census
+        dist_mod.init_process_group("gloo" if rehearsal else "nccl")
         dist = dist_mod
     return rank, world, local, torch, dist
+
+
+def comm_device(dist):
+    return "cpu" if dist is not None and dist.get_backend() == "gloo" else "cuda"
+
+
+def barrier(torch, dist):
+    if dist.get_backend() == "gloo":
+        dist.barrier()
+    else:
+        dist.barrier(device_ids=[torch.cuda.current_device()])
 
 
 def timed_region(torch, dist, fn, steps, warmup):
     """W untimed steps, barrier + sync, exactly K steps, sync + barrier; returns the MAX wall time over ranks (s)."""
     for _ in range(warmup):
         fn()
-    dev = torch.cuda.current_device()
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier(device_ids=[dev])
+        barrier(torch, dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
     if dist is not None:
-        dist.barrier(device_ids=[dev])
+        barrier(torch, dist)
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_device(dist))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -168,7 +184,7 @@ def timed_region(torch, dist, fn, steps, warmup):
 def sum_over_ranks(torch, dist, value):
     if dist is None:
         return value
-    t = torch.tensor([float(value)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=comm_device(dist))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -490,6 +506,8 @@ def main():
             c1 = bench_dp(args, "c1", rank, world, local, torch, dist, max(args.steps, 20), args.warmup, False)
     main_part = dp if dp is not None else tr
     result.update(main_part)
+    if os.environ.get("PM_BENCH_REHEARSAL") == "1":
+        result["rehearsal"] = "every rank on device 0, gloo instead of RCCL: the numbers of this line mean nothing"
     result.update({"n_gpus": ran, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": args.scaling,
                    "vs_baseline": None, "data": "synthetic"})
     if c1 is not None:

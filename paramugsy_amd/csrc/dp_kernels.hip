@@ -737,32 +737,44 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     total_words += need_words(k);
     h->cells += (h->off_a[k + 1] - h->off_a[k]) * (h->off_b[k + 1] - h->off_b[k]);
   }
-  const bool one_chunk = total_words <= h->tb_budget_bytes / 4;
-  const i64 budget_words = one_chunk ? h->tb_budget_bytes / 4 : h->tb_budget_bytes / 8;
-  // chunk_first: positions in `order`; chunk_tb: the word offset of every position's pair inside its chunk's workspace
-  h->chunk_first.assign(1, 0);
-  h->chunk_tb.clear();
-  h->tb_words_cap = 0;
-  std::vector<i64> cur;
-  i64 used = 0;
-  for(i64 q = 0; q < n_pairs; ++q) {
-    i64 need = need_words(h->order[(size_t)q]);
-    if(!cur.empty() && used + need > budget_words) {
-      h->chunk_tb.push_back(cur);
-      h->chunk_first.push_back(q);
-      h->tb_words_cap = std::max(h->tb_words_cap, used);
-      cur.clear();
-      used = 0;
+  // the workspace is allocated to what the chunks need; if the device cannot give that much (other allocations beside this
+  // batch) the budget is halved and the batch cut into more chunks, down to 256 MiB
+  bool pipelined = false;
+  for(i64 budget = h->tb_budget_bytes;; budget /= 2) {
+    const bool one_chunk = total_words <= budget / 4;
+    const i64 budget_words = one_chunk ? budget / 4 : budget / 8;
+    // chunk_first: positions in `order`; chunk_tb: the word offset of every position's pair inside its chunk's workspace
+    h->chunk_first.assign(1, 0);
+    h->chunk_tb.clear();
+    h->tb_words_cap = 0;
+    std::vector<i64> cur;
+    i64 used = 0;
+    for(i64 q = 0; q < n_pairs; ++q) {
+      i64 need = need_words(h->order[(size_t)q]);
+      if(!cur.empty() && used + need > budget_words) {
+        h->chunk_tb.push_back(cur);
+        h->chunk_first.push_back(q);
+        h->tb_words_cap = std::max(h->tb_words_cap, used);
+        cur.clear();
+        used = 0;
+      }
+      cur.push_back(used);
+      used += need;
     }
-    cur.push_back(used);
-    used += need;
+    h->chunk_tb.push_back(cur);
+    h->chunk_first.push_back(n_pairs);
+    h->tb_words_cap = std::max(h->tb_words_cap, used);
+    pipelined = h->chunk_tb.size() > 1;
+    h->tb_half_words = pipelined ? ((h->tb_words_cap + 63) / 64) * 64 : 0;
+    const int rc = grow(h->tb, (size_t)(pipelined ? 2 * h->tb_half_words : h->tb_words_cap) * 4);
+    if(rc == PM_OK) {
+      break;
+    }
+    (void)hipGetLastError(); // the failed allocation's sticky error
+    if(budget <= ((i64)256 << 20) || (i64)h->chunk_tb.size() >= n_pairs) {
+      return rc; // one pair per chunk already, or nothing sensible left to try
+    }
   }
-  h->chunk_tb.push_back(cur);
-  h->chunk_first.push_back(n_pairs);
-  h->tb_words_cap = std::max(h->tb_words_cap, used);
-  const bool pipelined = h->chunk_tb.size() > 1;
-  h->tb_half_words = pipelined ? ((h->tb_words_cap + 63) / 64) * 64 : 0;
-  PM_TRY(grow(h->tb, (size_t)(pipelined ? 2 * h->tb_half_words : h->tb_words_cap) * 4));
   if(pipelined) {
     if(!h->path_stream) {
       PM_HIP(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking));
