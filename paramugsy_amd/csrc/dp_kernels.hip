@@ -442,7 +442,8 @@ int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budge
   if(const char *e = getenv("PM_DP_COLS")) {
     h->cols_per_lane = atoi(e) == 8 ? 8 : 16;
   }
-  if(const char *e = getenv("PM_DP_MODE")) {
+  if(const char *e = getenv("PM_DP_MODE")) { // bits | ckpt; anything else (or unset): chosen per batch in dp_batch_plan
+    h->mode_auto = strcmp(e, "bits") != 0 && strcmp(e, "ckpt") != 0;
     h->ckpt = strcmp(e, "bits") != 0;
   }
   if(const char *e = getenv("PM_DP_WALK_LANES")) {
@@ -711,6 +712,27 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // chunks: consecutive pairs whose workspace fits the budget.  A batch that fits is one chunk; otherwise the budget is cut
   // in two halves that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernel
   // of the next (dp_run)
+  // Paths from checkpoints or from stored decision bits?  The checkpoint fill is 2.3x faster per cell but its walk is a chain
+  // of blocks with ~15 us of latency each, whatever the batch size; a small batch is better off storing the bits.  Measured on
+  // MI355X (profiles/r02_dp_mode_sweep.txt): bits 2.3 T cells/s, checkpoint fill 5.2 T cells/s, a lone pair's fill 0.36 us per
+  // step (1.55x that with bits).  Checkpoints when what the fill saves exceeds the walk's chain.
+  if(h->mode_auto) {
+    double cells = 0, chain_blocks = 0, lone_fill_s = 0;
+    const i64 W = 64 * h->cols_per_lane;
+    for(i64 k = 0; k < n_pairs; ++k) {
+      const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+      cells += (double)la * (double)lb;
+      chain_blocks = std::max(chain_blocks, (double)(la / DP_CK_R + lb / (DP_CK_W * h->cols_per_lane) + 1));
+      const i64 stripes = (lb + W - 1) / W;
+      i64 nw = 1;
+      while(nw < 8 && nw * 2 <= stripes && n_pairs * nw < 4096) {
+        nw *= 2;
+      }
+      lone_fill_s = std::max(lone_fill_s, (double)((stripes + nw - 1) / nw) * (double)(la + 63) * 0.36e-6);
+    }
+    const double fill_saved_s = std::max(cells * (1.0 / 2.3e12 - 1.0 / 5.2e12), 0.55 * lone_fill_s);
+    h->ckpt = fill_saved_s > chain_blocks * 15e-6;
+  }
   auto need_words = [&](i64 k) {
     i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
     return h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane) : dp_tb_words(la, lb, h->cols_per_lane);

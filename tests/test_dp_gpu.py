@@ -177,6 +177,26 @@ def test_uniform_depth_variant_and_its_fallbacks(dot4, mode, oracle_build, monke
     run_and_compare(half, params)
 
 
+def test_path_mode_is_chosen_by_batch_size(oracle_build):
+    """A small batch stores decision bits (the checkpoint walk's chain of blocks has a latency that does not shrink with the
+    batch), a large one leaves checkpoints; PM_DP_MODE fixes it either way (the other tests do)."""
+    params = dp.make_params(2, 2)
+    small = dp.DpBatch(dp.synth_pairs_fast(1, 64, 2, 1000), params)
+    assert not small.variant()["checkpoints"]
+    small.close()
+    big_in = dp.synth_pairs_fast(2, 6000, 2, 1000)
+    big = dp.DpBatch(big_in, params)
+    assert big.variant()["checkpoints"]
+    big.run(True)
+    scores, ops, n_ops = big.fetch()
+    big.close()
+    import pyoracle
+    assert np.array_equal(scores, pyoracle.dp_scores(big_in, params))
+    for k in range(0, 6000, 997):
+        rc, s_ = pyoracle.dp_score_of_path(big_in, params, k, dp.paths_of(big_in, ops, n_ops)[k])
+        assert rc == 0 and s_ == scores[k]
+
+
 def test_weights_beyond_int16_are_refused():
     from paramugsy_amd import capi
     cols = np.zeros((4, 8), dtype=np.uint8)

@@ -17,8 +17,9 @@ def resident(inputs, params):
 
 
 @pytest.mark.parametrize("segments", [1, 2, 5, 17, 1000])
-def test_stream_equals_resident_batch_on_ragged_pairs(segments, oracle_build):
+def test_stream_equals_resident_batch_on_ragged_pairs(segments, oracle_build, monkeypatch):
     import pyoracle
+    monkeypatch.setenv("PM_DP_MODE", "ckpt" if segments % 2 else "bits")  # a batch this small would always choose bits
     la, lb = dp.ragged_lengths(5, 60, median=400, sigma=0.7, lo=1, hi=2500)
     la[3], lb[3] = 0, 17
     la[4], lb[4] = 9, 0
@@ -38,7 +39,8 @@ def test_stream_equals_resident_batch_on_ragged_pairs(segments, oracle_build):
     assert np.array_equal(r_scores, o_scores)
 
 
-def test_stream_with_pinned_buffers_and_several_workspace_chunks(oracle_build):
+def test_stream_with_pinned_buffers_and_several_workspace_chunks(oracle_build, monkeypatch):
+    monkeypatch.setenv("PM_DP_MODE", "ckpt")
     """Pinned inputs and outputs (the asynchronous case) and a workspace so small that the batch takes several chunks, each of
     them spanning several upload segments."""
     n, rows, L = 600, 2, 500
