@@ -22,7 +22,8 @@ struct pm_dp_batch {
   pm::DpParamsD params;
   int max_sub_acgt = 0, max_sub_all = 0;
   pm::i64 cells = 0;
-  int cols_per_lane = 16; // columns of B a lane owns per stripe (8 or 16); PM_DP_COLS overrides
+  int cols_per_lane = 16; // columns of B a lane owns per stripe: 16, 8 for small batches (dp_batch_plan); PM_DP_COLS fixes it
+  bool cols_forced = false;
   bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
   bool uni = false;       // every column of A holds the same number of symbols: gap row folded into the weights (PM_DP_UNI=0 disables)
   int waves_override = 0; // PM_DP_WAVES=1|2|4|8 forces the waves-per-pair choice

@@ -441,6 +441,7 @@ int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budge
   }
   if(const char *e = getenv("PM_DP_COLS")) {
     h->cols_per_lane = atoi(e) == 8 ? 8 : 16;
+    h->cols_forced = true;
   }
   if(const char *e = getenv("PM_DP_MODE")) { // bits | ckpt; anything else (or unset): chosen per batch in dp_batch_plan
     h->mode_auto = strcmp(e, "bits") != 0 && strcmp(e, "ckpt") != 0;
@@ -712,6 +713,14 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // chunks: consecutive pairs whose workspace fits the budget.  A batch that fits is one chunk; otherwise the budget is cut
   // in two halves that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernel
   // of the next (dp_run)
+  // Columns of B per lane: 16, or 8 for a batch of a few hundred pairs at most -- twice the stripes, so twice the wavefronts
+  // a pair can keep busy, each with half the work per step (256 pairs of 2 x 1 kbp: 0.60 -> 0.46 ms).
+  if(!h->cols_forced) {
+    h->cols_per_lane = n_pairs <= 512 ? 8 : 16;
+    if(h->walk_lanes && !dp_walk_lanes_ok(h->cols_per_lane, h->walk_lanes)) {
+      h->walk_lanes = 0;
+    }
+  }
   // Paths from checkpoints or from stored decision bits?  The checkpoint fill is 2.3x faster per cell but its walk is a chain
   // of blocks with ~15 us of latency each, whatever the batch size; a small batch is better off storing the bits.  Measured on
   // MI355X (profiles/r02_dp_mode_sweep.txt): bits 2.3 T cells/s, checkpoint fill 5.2 T cells/s, a lone pair's fill 0.36 us per
