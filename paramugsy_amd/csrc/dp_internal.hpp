@@ -45,7 +45,7 @@ static_assert((DP_CK_R & (DP_CK_R - 1)) == 0 && DP_CK_R >= 16, "DP_CK_R is a pow
 static_assert(DP_CK_W == 1 || DP_CK_W == 2 || DP_CK_W == 4, "DP_CK_W in {1, 2, 4}");
 
 // Words (4 bytes) of checkpoint storage one pair needs.  Per stripe (64 lanes x C columns of B):
-//   col[t][group]     int2 {H~ - gop, E~} of the group's last column after the row its last lane was on at step t
+//   col[group][t]     int2 {H~ - gop, E~} of the group's last column after the row its last lane was on at step t
 //   row[m][lane][c]   int2 {H~ - gop, F~} of column c after the lane's (m + 1)-th checkpoint step
 __host__ __device__ inline i64 dp_ck_steps(i64 la) { return la + 63; }
 __host__ __device__ inline i64 dp_ck_nck(i64 la) { return (la + 63) / DP_CK_R; }
@@ -54,9 +54,13 @@ __host__ __device__ inline i64 dp_ck_col_words_per_step() { return (64 / DP_CK_W
 __host__ __device__ inline i64 dp_ck_words(i64 la, i64 lb, int C) {
   return dp_ck_stripes(lb, C) * (dp_ck_steps(la) * dp_ck_col_words_per_step() + dp_ck_nck(la) * 64 * 2 * C);
 }
-// column checkpoint of fill lane `lane` (the last of its group) at step t of stripe s
+// column checkpoint of fill lane `lane` (the last of its group) at step t of stripe s.  Layout [stripe][group][step]: the
+// steps of one group are contiguous, which is how all three readers go through them (the next stripe's seam: lane 63's group,
+// 64 rows at a time; the walk's left edge: one group, the rows of a block); the writer's 16 lanes hit 16 lines per step, each
+// line completed by 16 consecutive steps while it sits in L2.  ([step][group] made the seam read 8 bytes of every 128-byte
+// line: 20 GB of FETCH_SIZE on the headline batch.)
 __host__ __device__ inline i64 dp_ck_col_word(i64 la, i64 s, i64 t, int lane) {
-  return (s * dp_ck_steps(la) + t) * dp_ck_col_words_per_step() + (lane / DP_CK_W) * 2;
+  return ((s * (64 / DP_CK_W) + lane / DP_CK_W) * dp_ck_steps(la) + t) * 2;
 }
 __host__ __device__ inline i64 dp_ck_row_word(i64 la, i64 lb, int C, i64 s, i64 m, int lane) {
   return dp_ck_stripes(lb, C) * dp_ck_steps(la) * dp_ck_col_words_per_step() + ((s * dp_ck_nck(la) + m) * 64 + lane) * 2 * C;
