@@ -10,22 +10,36 @@ pytestmark = pytest.mark.gpu
 
 
 def run_and_compare(inputs, params, tb_budget=0):
+    """Scores and paths of the batch against the oracle's full-matrix aligner -- with the paths taken from checkpoints AND from
+    stored decision bits (a batch as small as the tests' would choose the bits by itself, so both are forced in turn), unless the
+    calling test has fixed PM_DP_MODE itself."""
+    import os
     import pyoracle
-    batch = dp.DpBatch(inputs, params, tb_budget_bytes=tb_budget)
-    batch.run(traceback=True)
-    scores, ops, n_ops = batch.fetch()
     o_scores, o_paths = pyoracle.dp_align(inputs, params)
-    assert np.array_equal(scores, o_scores)
-    paths = batch.paths(ops, n_ops)
-    for k in range(inputs.n_pairs):
-        assert np.array_equal(paths[k], o_paths[k]), "pair %d" % k
-    # score-only pass gives the same scores
-    batch.run(traceback=False)
-    s2, _, _ = batch.fetch(with_paths=False)
-    assert np.array_equal(s2, o_scores)
-    info = batch.info()
-    batch.close()
-    return scores, paths, info
+    preset = os.environ.get("PM_DP_MODE")
+    out = None
+    for mode in ([preset] if preset else ["ckpt", "bits"]):
+        os.environ["PM_DP_MODE"] = mode
+        try:
+            batch = dp.DpBatch(inputs, params, tb_budget_bytes=tb_budget)
+        finally:
+            if preset is None:
+                del os.environ["PM_DP_MODE"]
+        assert batch.variant()["checkpoints"] == (mode == "ckpt")
+        batch.run(traceback=True)
+        scores, ops, n_ops = batch.fetch()
+        assert np.array_equal(scores, o_scores), mode
+        paths = batch.paths(ops, n_ops)
+        for k in range(inputs.n_pairs):
+            assert np.array_equal(paths[k], o_paths[k]), "pair %d (%s)" % (k, mode)
+        # score-only pass gives the same scores
+        batch.run(traceback=False)
+        s2, _, _ = batch.fetch(with_paths=False)
+        assert np.array_equal(s2, o_scores)
+        info = batch.info()
+        batch.close()
+        out = (scores, paths, info)
+    return out
 
 
 @pytest.mark.parametrize("rows,length", [(2, 100), (3, 700), (8, 513), (32, 300)])
