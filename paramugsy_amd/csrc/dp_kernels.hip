@@ -129,8 +129,6 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       hop[c] = -2 * gop;                      // H~[0][j+1] - gop, H~[0][j] = -gop for j >= 1
       f[c] = DP_NEG_INF;
     }
-    // row checkpoints: lane l stores after the steps t with t + 1 - l % DP_CK_W a positive multiple of DP_CK_R
-    int ck_left = DP_CK_R - 1 + (lane & (DP_CK_W - 1)), ck_m = 0;
     int diag_in = (j0 == 0 ? 0 : -gop) - gop; // H~[0][j0] - gop
     int e = DP_NEG_INF; // the running E of this lane's row; between steps: what the lane hands to its right neighbour
     int bin_ho = 0, bin_e = DP_NEG_INF;
@@ -249,15 +247,20 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         }
       }
       if constexpr(CKPT) {
-        // the lane's column state every DP_CK_R steps, the lanes of a group one step apart (after the same row of A):
-        // a per-lane countdown, one VALU op per step
-        if(--ck_left < 0) {
-          ck_left += DP_CK_R;
-          int4 *dst = reinterpret_cast<int4 *>(tbp + dp_ck_row_word(la, lb, C, s, ck_m, lane));
-          ++ck_m;
+        // the lane's column state every DP_CK_R steps, the lanes of a group one step apart (after the same row of A): lane l
+        // stores after the steps t with t + 1 - l % DP_CK_W a positive multiple of DP_CK_R.  A scalar test lets DP_CK_W of
+        // every DP_CK_R steps through to the per-lane test (kept behind it by an opaque asm, or the compiler would hoist the
+        // vector compare into every step).
+        const int tm = (t + 1) & (DP_CK_R - 1);
+        if(tm < DP_CK_W) {
+          int tt;
+          asm volatile("v_sub_u32 %0, %1, %2" : "=v"(tt) : "s"(t + 1), "v"(lane & (DP_CK_W - 1)));
+          if(tt > 0 && (tt & (DP_CK_R - 1)) == 0) {
+            int4 *dst = reinterpret_cast<int4 *>(tbp + dp_ck_row_word(la, lb, C, s, tt / DP_CK_R - 1, lane));
 #pragma unroll
-          for(int c = 0; c < C; c += 2) {
-            dst[c / 2] = make_int4(hop[c], f[c], hop[c + 1], f[c + 1]);
+            for(int c = 0; c < C; c += 2) {
+              dst[c / 2] = make_int4(hop[c], f[c], hop[c + 1], f[c + 1]);
+            }
           }
         }
       }
