@@ -716,10 +716,16 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // chunks: consecutive pairs whose workspace fits the budget.  A batch that fits is one chunk; otherwise the budget is cut
   // in two halves that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernel
   // of the next (dp_run)
-  // Columns of B per lane: 16, or 8 for a batch of a few hundred pairs at most -- twice the stripes, so twice the wavefronts
-  // a pair can keep busy, each with half the work per step (256 pairs of 2 x 1 kbp: 0.60 -> 0.46 ms).
+  // Columns of B per lane: 16, or 8 for a batch of a few hundred pairs at most whose profiles fit one 1 024-column stripe --
+  // two stripes of 512 then, so twice the wavefronts a pair can keep busy, each with half the work per step (256 pairs of
+  // 2 x 1 kbp: 0.60 -> 0.46 ms).  Longer pairs already have stripes to run side by side, and narrower stripes only make the
+  // checkpoint walk's blocks smaller and its chain longer.
   if(!h->cols_forced) {
-    h->cols_per_lane = n_pairs <= 512 ? 8 : 16;
+    i64 max_lb = 0;
+    for(i64 k = 0; k < n_pairs; ++k) {
+      max_lb = std::max(max_lb, h->off_b[k + 1] - h->off_b[k]);
+    }
+    h->cols_per_lane = n_pairs <= 512 && max_lb <= 1024 ? 8 : 16;
     if(h->walk_lanes && !dp_walk_lanes_ok(h->cols_per_lane, h->walk_lanes)) {
       h->walk_lanes = 0;
     }
@@ -737,10 +743,12 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       chain_blocks = std::max(chain_blocks, (double)(la / DP_CK_R + lb / (DP_CK_W * h->cols_per_lane) + 1));
       const i64 stripes = (lb + W - 1) / W;
       i64 nw = 1;
-      while(nw < 8 && nw * 2 <= stripes && n_pairs * nw < 4096) {
+      while(nw < 16 && nw * 2 <= stripes + (nw >= 8 ? 6 : 0) && n_pairs * nw < 4096) {
         nw *= 2;
       }
-      lone_fill_s = std::max(lone_fill_s, (double)((stripes + nw - 1) / nw) * (double)(la + 63) * 0.36e-6);
+      // a pair's waves share one CU: beyond one wave per SIMD they take turns
+      const double share = std::max(1.0, (double)std::min<i64>(nw, stripes) / 4.0);
+      lone_fill_s = std::max(lone_fill_s, (double)((stripes + nw - 1) / nw) * (double)(la + 63) * 0.36e-6 * share);
     }
     const double fill_saved_s = std::max(cells * (1.0 / 2.3e12 - 1.0 / 5.2e12), 0.55 * lone_fill_s);
     h->ckpt = fill_saved_s > chain_blocks * 15e-6;
@@ -923,11 +931,13 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
     bool fits = (max_stripes + 2) * max_la < ((i64)1 << 30); // the progress word is an int
     // enough waves to give every SIMD about four (1 024 SIMDs), as far as the pairs have stripes to run side by side
     if(fits && max_stripes >= 2 && n < 4096) {
-      while(nw < 8 && nw * 2 <= max_stripes && n * nw < 4096) {
+      // 16 waves (one workgroup filling a CU) once a pair has 10 stripes or more: all of them run side by side
+      while(nw < 16 && nw * 2 <= max_stripes + (nw >= 8 ? 6 : 0) && n * nw < 4096) {
         nw *= 2;
       }
     }
-    if(h->waves_override == 1 || ((h->waves_override == 2 || h->waves_override == 4 || h->waves_override == 8) && fits)) {
+    if(h->waves_override == 1 ||
+       ((h->waves_override == 2 || h->waves_override == 4 || h->waves_override == 8 || h->waves_override == 16) && fits)) {
       nw = h->waves_override;
     }
   }
@@ -961,6 +971,9 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
   }
 #define DP_LAUNCH_FILL_NW(CC)    \
   switch(nw) {                   \
+  case 16:                       \
+    DP_LAUNCH_FILL_TR(CC, 16)    \
+    break;                       \
   case 8:                        \
     DP_LAUNCH_FILL_TR(CC, 8)     \
     break;                       \

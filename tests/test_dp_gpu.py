@@ -89,7 +89,7 @@ def test_chunked_workspace_gives_same_results(mode, oracle_build, monkeypatch):
     assert np.array_equal(s1, s2) and all(np.array_equal(a, b) for a, b in zip(p1, p2))
 
 
-@pytest.mark.parametrize("waves", ["1", "2", "4", "8"])
+@pytest.mark.parametrize("waves", ["1", "2", "4", "8", "16"])
 @pytest.mark.parametrize("cols", ["8", "16"])
 @pytest.mark.parametrize("dot4", ["0", "1"])
 @pytest.mark.parametrize("mode", ["bits", "ckpt"])
@@ -102,8 +102,8 @@ def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, mode, ora
     monkeypatch.setenv("PM_DP_DOT4", dot4)
     monkeypatch.setenv("PM_DP_MODE", mode)
     rng = np.random.default_rng(int(waves) * 100 + int(cols) + int(dot4))
-    la = [700, 64, 1300, 129, 2000, 5]
-    lb = [2600, 1025, 1024, 2049, 513, 1100]
+    la = [700, 64, 1300, 129, 2000, 5, 150]
+    lb = [2600, 1025, 1024, 2049, 513, 1100, 9300 if cols == "8" else 12500]  # the last: 19 / 13 stripes, more than 16 waves
     cols_of = lambda n: np.concatenate([rng.integers(0, 3, size=(n, 5)).astype(np.uint8), np.zeros((n, 3), np.uint8)], axis=1)
     inputs = dp.DpInputs(np.concatenate([cols_of(n) for n in la]), np.concatenate([[0], np.cumsum(la)]).astype(np.int64),
                          np.concatenate([cols_of(n) for n in lb]), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
