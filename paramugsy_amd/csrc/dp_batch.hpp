@@ -31,6 +31,10 @@ struct pm_dp_batch {
   bool mode_auto = true;  // ckpt chosen per batch in dp_batch_plan (PM_DP_MODE=bits|ckpt fixes it)
   int walk_lanes = 0;     // lanes per pair of the checkpoint walk; 0 = chosen per launch; PM_DP_WALK_LANES overrides
   pm::DevBuf pipe_error;
+  // the band of the checkpoint walk (dp_internal.hpp), set up by dp_batch_plan for one-chunk batches of few pairs
+  pm::DevBuf d_band_work, d_band_off, band_bits;
+  pm::i64 band_work_items = 0; // 0: no band
+  int band_lanes = 0;          // the lanes per pair the band's blocks are laid out for
   hipStream_t last_stream = nullptr;
   // chunk pipeline (more than one chunk): the workspace is two halves, chunk c uses half c % 2; the path kernel of chunk c runs
   // on `path_stream` beside the fill kernel of chunk c + 1

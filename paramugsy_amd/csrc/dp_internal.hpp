@@ -71,6 +71,37 @@ __host__ __device__ inline i64 dp_ck_bytes_written(i64 la, i64 lb, int C) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The band (dp_walk.hip): for a batch of few pairs the walk is a chain of blocks on one wavefront per pair with the rest of the
+// chip idle, so the decision bits of the DP_BAND_BLOCKS row blocks of every column group that lie around the straight line
+// from (0, 0) to (La, Lb) are computed up front, all at once; the walk reads them and recomputes only where the path leaves
+// the band.  dp_band_row_block: the row block of column group gg (first fill lane l0) that the line crosses at the group's
+// middle column.
+#ifndef DP_BAND_BLOCKS
+#define DP_BAND_BLOCKS 3
+#endif
+__host__ __device__ inline int dp_band_row_block(int la, int lb, int bw, int gg, int l0) {
+  long long jm = (long long)gg * bw + bw / 2;
+  if(jm > lb) {
+    jm = lb;
+  }
+  long long im = lb > 0 ? (jm * la + lb / 2) / lb : 1;
+  im = im < 1 ? 1 : (im > la ? la : im);
+  return (int)((im - 1 + l0) / DP_CK_R);
+}
+// bytes of one block's decisions as the walk keeps them in LDS: DP_CK_R rows of `lanes_per_pair` words holding 4 bits for each
+// of the lane's columns (1, 2 or 4 bytes)
+__host__ __device__ inline int dp_band_block_bytes(int cols_per_lane, int lanes_per_pair) {
+  const int c2 = cols_per_lane * DP_CK_W / lanes_per_pair;
+  return DP_CK_R * lanes_per_pair * (c2 <= 2 ? 1 : (c2 <= 4 ? 2 : 4));
+}
+struct DpBand {          // device pointers; work == nullptr: no band
+  const int *work;       // (pair, column group) of every work item of the band kernel, two ints each
+  i64 n_work;
+  unsigned *bits;        // block b of group gg of pair p at block index off[p] + gg * DP_BAND_BLOCKS + b
+  const i64 *off;        // indexed by pair
+};
+
+// ------------------------------------------------------------------------------------------------------------------
 // Device code shared by the fill kernel and the walk: the hand-scheduled cell of the recurrence.
 #if defined(__HIPCC__)
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -230,7 +261,7 @@ __device__ __forceinline__ int4 dp_expand_row(u64 col) {
 // cols_per_lane (of the fill kernel) in {8, 16}; lanes_per_pair a power of two for which dp_walk_lanes_ok() holds.
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
-                   hipStream_t stream);
+                   const DpBand &band, hipStream_t stream);
 
 bool dp_walk_lanes_ok(int cols_per_lane, int lanes_per_pair);
 

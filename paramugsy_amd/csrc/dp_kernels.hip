@@ -656,6 +656,22 @@ int dp_batch_plan(pm_dp_batch *h, hipStream_t stream) {
   return dp_batch_plan_with(h, h->pinned ? (const int *)((char *)h->pinned + h->pinned_bytes - 32) : h->host_stats, stream);
 }
 
+// lanes per pair of the checkpoint walk for a launch of n pairs: as few as still give the launch about two wavefronts per SIMD
+// (1 024 SIMDs)
+static int dp_walk_lanes_for(const pm_dp_batch *h, i64 n) {
+  int lpp = h->walk_lanes;
+  if(lpp == 0) {
+    lpp = 2;
+    while(!dp_walk_lanes_ok(h->cols_per_lane, lpp)) {
+      lpp *= 2;
+    }
+    while(lpp < 32 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp < 2 * 1024 * 64) {
+      lpp *= 2;
+    }
+  }
+  return lpp;
+}
+
 int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   const i64 n_pairs = h->n_pairs;
   const int max_a = st[0], max_colsum_b = st[3];
@@ -730,6 +746,13 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       h->walk_lanes = 0;
     }
   }
+  // the offset tables go through the batch's pinned staging when it has one (dp_stream.hip)
+  const bool staged = h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32;
+  // The band of the walk (dp_internal.hpp) pays while the walk alone would leave the chip mostly idle: up to one wavefront per
+  // SIMD (measured: 2 048 pairs of 8 x 4 kbp 2.69 -> 1.93 ms, 4 096 pairs 2.74 -> 3.56 ms; 1 000 pairs of 2 x 1 kbp 0.47 -> 0.28 ms,
+  // 4 000 pairs 0.59 -> 0.90 ms)
+  auto band_pays = [](i64 n, int lanes) { return n * lanes <= 1024 * 64; };
+  const int band_env = getenv("PM_DP_BAND") ? atoi(getenv("PM_DP_BAND")) : -1; // 0: never, 1: whenever it fits
   // Paths from checkpoints or from stored decision bits?  The checkpoint fill is 2.3x faster per cell but its walk is a chain
   // of blocks with ~15 us of latency each, whatever the batch size; a small batch is better off storing the bits.  Measured on
   // MI355X (profiles/r02_dp_mode_sweep.txt): bits 2.3 T cells/s, checkpoint fill 5.2 T cells/s, a lone pair's fill 0.36 us per
@@ -751,7 +774,9 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       lone_fill_s = std::max(lone_fill_s, (double)((stripes + nw - 1) / nw) * (double)(la + 63) * 0.36e-6 * share);
     }
     const double fill_saved_s = std::max(cells * (1.0 / 2.3e12 - 1.0 / 5.2e12), 0.55 * lone_fill_s);
-    h->ckpt = fill_saved_s > chain_blocks * 15e-6;
+    // a block of the chain: ~15 us recomputed; ~4 us read back from the band, whose kernel costs a launch more (~30 us)
+    const bool band_likely = !staged && band_env != 0 && (band_env > 0 || band_pays(n_pairs, dp_walk_lanes_for(h, n_pairs)));
+    h->ckpt = fill_saved_s > (band_likely ? 30e-6 + chain_blocks * 4e-6 : chain_blocks * 15e-6);
   }
   auto need_words = [&](i64 k) {
     i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
@@ -836,7 +861,6 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     int *ord = nullptr;
     std::vector<i64> tmp;
     std::vector<int> tmp_o;
-    const bool staged = h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32;
     if(staged) {
       flat = (i64 *)h->pinned + 2 * (n_pairs + 1);
       ord = (int *)((i64 *)h->pinned + 3 * (n_pairs + 1));
@@ -856,6 +880,45 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       }
     }
     PM_TRY(grow(h->d_order, npad * 4));
+    // The band (dp_internal.hpp): a one-chunk batch whose walk would leave most of the chip idle (at most two wavefronts per
+    // SIMD) gets the decisions around every pair's diagonal computed up front.  Not for a batch that is reloaded slice after
+    // slice from pinned staging (dp_stream.hip): its tables would have to follow every slice.
+    h->band_work_items = 0;
+    if(h->ckpt && !staged && h->chunk_tb.size() == 1 && n_pairs > 0 && band_env != 0) {
+      const int lpp = dp_walk_lanes_for(h, n_pairs);
+      const i64 bw = (i64)h->cols_per_lane * DP_CK_W;
+      const i64 block_bytes = dp_band_block_bytes(h->cols_per_lane, lpp);
+      i64 items = 0;
+      for(i64 k = 0; k < n_pairs; ++k) {
+        const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+        items += la > 0 ? (lb + bw - 1) / bw : 0;
+      }
+      const i64 band_bytes = items * DP_BAND_BLOCKS * block_bytes;
+      if(items > 0 && (band_env > 0 || band_pays(n_pairs, lpp)) && band_bytes <= ((i64)(band_env > 0 ? 32 : 4) << 30)) {
+        std::vector<int> work((size_t)items * 2);
+        std::vector<i64> boff((size_t)n_pairs);
+        i64 at = 0;
+        for(i64 q2 = 0; q2 < n_pairs; ++q2) { // in processing order: the longest pairs' blocks first
+          const i64 k = h->order[(size_t)q2];
+          const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+          const i64 groups = la > 0 ? (lb + bw - 1) / bw : 0;
+          boff[(size_t)k] = at * DP_BAND_BLOCKS;
+          for(i64 g = 0; g < groups; ++g) {
+            work[(size_t)(at + g) * 2] = (int)k;
+            work[(size_t)(at + g) * 2 + 1] = (int)g;
+          }
+          at += groups;
+        }
+        PM_TRY(grow(h->d_band_work, (size_t)items * 8));
+        PM_TRY(grow(h->d_band_off, (size_t)n_pairs * 8));
+        PM_TRY(grow(h->band_bits, (size_t)band_bytes));
+        PM_HIP(hipStreamSynchronize(stream));
+        PM_HIP(hipMemcpy(h->d_band_work.p, work.data(), (size_t)items * 8, hipMemcpyHostToDevice));
+        PM_HIP(hipMemcpy(h->d_band_off.p, boff.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice));
+        h->band_work_items = items;
+        h->band_lanes = lpp;
+      }
+    }
     if(n_pairs > 0) {
       if(staged) {
         PM_HIP(hipMemcpyAsync(h->d_tb_off.p, flat, (size_t)n_pairs * 8, hipMemcpyHostToDevice, stream));
@@ -1007,19 +1070,17 @@ static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStre
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
   if(h->ckpt) {
-    // lanes per pair: as few as still give the launch about two wavefronts per SIMD (1 024 SIMDs)
-    int lpp = h->walk_lanes;
-    if(lpp == 0) {
-      lpp = 2;
-      while(!dp_walk_lanes_ok(h->cols_per_lane, lpp)) {
-        lpp *= 2;
-      }
-      while(lpp < 32 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp < 2 * 1024 * 64) {
-        lpp *= 2;
-      }
+    const int lpp = dp_walk_lanes_for(h, n);
+    DpBand band = {nullptr, 0, nullptr, nullptr};
+    if(h->band_work_items > 0 && h->band_lanes == lpp) {
+      band.work = (const int *)h->d_band_work.p;
+      band.n_work = h->band_work_items;
+      band.bits = (unsigned *)h->band_bits.p;
+      band.off = (const i64 *)h->d_band_off.p;
     }
     return dp_launch_walk(h->cols_per_lane, lpp, h->dot4, (const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
-                          (const i64 *)h->d_off_b.p, order, n, tb_off, tbw, (unsigned char *)h->ops.p, (int *)h->n_ops.p, h->params, stream);
+                          (const i64 *)h->d_off_b.p, order, n, tb_off, tbw, (unsigned char *)h->ops.p, (int *)h->n_ops.p, h->params, band,
+                          stream);
   }
   if(h->cols_per_lane == 16) {
     dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, order, tb_off, tbw,

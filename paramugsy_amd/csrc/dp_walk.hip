@@ -40,7 +40,9 @@ template <int C, int LPP, bool DOT4>
 __global__ void __launch_bounds__(64)
 dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b, const i64 *__restrict__ off_b,
                const int *__restrict__ order, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
-               int *__restrict__ n_ops, DpParamsD P, int ablate) {
+               int *__restrict__ n_ops, DpParamsD P, DpBand band, int band_mode, int ablate) {
+  // band_mode 0: the walk, every block recomputed; 1: no walk, the band's blocks computed and stored (work items = the band's
+  // (pair, column group) list); 2: the walk, blocks inside the band read back, the others recomputed
   constexpr int R = DP_CK_R;
   constexpr int BW = C * DP_CK_W; // columns of a block
   constexpr int C2 = BW / LPP;    // columns per lane inside a block
@@ -53,7 +55,16 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const int grp = threadIdx.x / LPP, q = threadIdx.x % LPP;
   const i64 idx = (i64)blockIdx.x * G + grp;
   const bool valid = idx < n;
-  const i64 pair = order[valid ? idx : 0]; // the launch's pairs in processing order
+  i64 pair;
+  int ggw = 0;
+  if(band_mode == 1) {
+    pair = band.work[2 * (valid ? idx : 0)];
+    ggw = band.work[2 * (valid ? idx : 0) + 1];
+  }
+  else {
+    pair = order[valid ? idx : 0]; // the launch's pairs in processing order
+  }
+  constexpr int BLOCK_WORDS = R * LPP * (int)sizeof(bits_t) / 4;
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
   const u64 *A = cols_a + a0;
@@ -64,10 +75,24 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   int i = la, j = lb, state = 0; // DP coordinates of the walk (cell (i, j) = row i-1 of A against column j-1 of B)
   int at = la + lb;
 
-  for(;;) {
-    const bool live = valid && i > 0 && j > 0;
-    if(!__any(live)) {
-      break;
+  for(int pass = 0;; ++pass) {
+    bool live;
+    if(band_mode == 1) { // the band's blocks of this column group, top to bottom; (i, j) = the block's bottom right cell
+      if(pass == DP_BAND_BLOCKS) {
+        break;
+      }
+      const int l0w = (ggw * DP_CK_W) & 63;
+      const int kb = dp_band_row_block(la, lb, BW, ggw, l0w) - DP_BAND_BLOCKS / 2 + pass;
+      const int top = kb * R - l0w;
+      live = valid && kb >= 0 && top < la && top + R >= 1;
+      i = min(la, top + R);
+      j = min(lb, (ggw + 1) * BW);
+    }
+    else {
+      live = valid && i > 0 && j > 0;
+      if(!__any(live)) {
+        break;
+      }
     }
     // ---- the block the walk is in: column group gg (lanes l0 .. l0 + DP_CK_W - 1 of stripe s of the fill kernel), row block k
     const int gg = live ? (j - 1) / BW : 0;
@@ -80,17 +105,26 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     const int nrows = i1 - i0;
     const int j0 = gg * BW;
     const int qmax = live ? (j - 1 - j0) / C2 : -1;
-    const bool mine = live && q <= qmax; // this lane has cells to recompute
+    // a block of the band is read back instead
+    bool in_band = false;
+    i64 band_block = 0;
+    if(band_mode != 0 && live) {
+      const int b = k - dp_band_row_block(la, lb, BW, gg, l0) + DP_BAND_BLOCKS / 2;
+      in_band = band_mode == 2 && b >= 0 && b < DP_BAND_BLOCKS;
+      band_block = band.off[pair] + (i64)gg * DP_BAND_BLOCKS + b;
+    }
+    const bool comp = live && !in_band;
+    const bool mine = comp && q <= qmax; // this lane has cells to recompute
     // ---- this lane's columns: the cell's weight registers, as in dp_fill_kernel
     int w0[C2], w1[C2], w2[C2], hop[C2], f[C2];
 #pragma unroll
     for(int c = 0; c < C2; ++c) {
       const int jc = j0 + q * C2 + c;
-      const bool in = live && jc < lb;
+      const bool in = comp && jc < lb;
       dp_column_weights<DOT4>(in ? B[jc] : 0ull, in, P, w0[c], w1[c], w2[c]);
     }
     // ---- top edge: the state of the lane's columns after row i0 - 1 (the group's row checkpoint k - 1)
-    const bool has_top = live && k * R - l0 >= 1 && !(ablate & 2);
+    const bool has_top = comp && k * R - l0 >= 1 && !(ablate & 2);
     if(has_top) {
       const int lf = (q * C2) / C, cf = (q * C2) % C;
       const int2 *src = reinterpret_cast<const int2 *>(ckp + dp_ck_row_word(la, lb, C, s, k - 1, l0 + lf)) + cf;
@@ -109,7 +143,14 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
     }
     // ---- A's rows and the left edge (rows i0 - 1 .. i1 - 1) into LDS
-    if(live) {
+    if(in_band) {
+      const unsigned *src = band.bits + band_block * BLOCK_WORDS;
+      unsigned *dst = reinterpret_cast<unsigned *>(&sh_bits[grp][0][0]);
+      for(int w = q; w < BLOCK_WORDS; w += LPP) {
+        dst[w] = src[w];
+      }
+    }
+    if(comp) {
       for(int r = q; r < nrows; r += LPP) {
         sh_a[grp][r] = dp_expand_row<DOT4>(A[i0 + r]);
       }
@@ -196,6 +237,17 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
     }
     __syncthreads();
+    if(band_mode == 1) {
+      if(live) {
+        unsigned *dst = band.bits + band_block * BLOCK_WORDS;
+        const unsigned *src = reinterpret_cast<const unsigned *>(&sh_bits[grp][0][0]);
+        for(int w = q; w < BLOCK_WORDS; w += LPP) {
+          dst[w] = src[w];
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     // ---- follow the decisions until the walk leaves the block.  The group's lanes look at the next LPP cells along the
     // current direction (diagonal in state H, along the row in E, along the column in F); a ballot finds how far the run
     // goes and the whole run is emitted at once, lane q writing op q of it.
@@ -257,7 +309,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     __syncthreads();
   }
   // one profile exhausted: the rest is a single gap run
-  if(valid) {
+  if(valid && band_mode != 1) {
     const int rest = i + j;
     const unsigned char op = i == 0 ? 1 : 2;
     for(int k2 = q; k2 < rest; k2 += LPP) {
@@ -272,18 +324,24 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
 
 template <int C, int LPP, bool DOT4>
 static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b, const int *order, i64 n, const i64 *tb_off,
-                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, hipStream_t stream) {
+                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, const DpBand &band, hipStream_t stream) {
   constexpr int G = 64 / LPP;
   const unsigned blocks = (unsigned)((n + G - 1) / G);
   static const int ablate = getenv("PM_DP_WALK_ABLATE") ? atoi(getenv("PM_DP_WALK_ABLATE")) : 0;
-  dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, ablate);
+  const bool with_band = band.work != nullptr && band.n_work > 0;
+  if(with_band) {
+    const unsigned bblocks = (unsigned)((band.n_work + G - 1) / G);
+    dp_walk_kernel<C, LPP, DOT4><<<bblocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, band.n_work, tb_off, ck, ops, n_ops, P, band, 1, ablate);
+    PM_HIP(hipGetLastError());
+  }
+  dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, with_band ? 2 : 0, ablate);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
 
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
-                   hipStream_t stream) {
+                   const DpBand &band, hipStream_t stream) {
   if(n <= 0) {
     return PM_OK;
   }
@@ -291,8 +349,8 @@ int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *
 #define WALK(CC, LL)                                                                                                        \
   if constexpr((CC * DP_CK_W) % LL == 0 && (CC * DP_CK_W) / LL >= 1 && (CC * DP_CK_W) / LL <= 8 && CC % ((CC * DP_CK_W) / LL) == 0) { \
     if(lanes_per_pair == LL) {                                                                                              \
-      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, stream) \
-                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, stream); \
+      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, stream) \
+                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, stream); \
     }                                                                                                                       \
   }
   if(cols_per_lane == 16) {

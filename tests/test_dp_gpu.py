@@ -129,6 +129,58 @@ def test_checkpoint_walk_with_every_group_size(lanes, cols, oracle_build, monkey
     run_and_compare(inputs, dp.make_params(3, 3))
 
 
+def shifted_pairs(seed, rows):
+    """Pairs whose optimal paths run far from the straight line between the corners: the two profiles share a long core that
+    sits at different offsets in them (junk before it in one, after it in the other, or in the middle)."""
+    rng = np.random.default_rng(seed)
+
+    def one_hot(seq):
+        c = np.zeros((len(seq), 8), np.uint8)
+        c[np.arange(len(seq)), seq] = rows
+        return c
+    A, B = [], []
+    for core, junk, where in [(1200, 400, "ends"), (900, 300, "middle"), (700, 250, "ends"), (1500, 200, "middle"), (300, 500, "ends")]:
+        s = rng.integers(0, 4, size=core)
+        ja, jb = rng.integers(0, 4, size=junk), rng.integers(0, 4, size=junk)
+        if where == "ends":  # B = junk + core, A = core + junk: the path is `junk` columns off the diagonal all along
+            A.append(one_hot(np.concatenate([s, ja])))
+            B.append(one_hot(np.concatenate([jb, s])))
+        else:  # the first half on the diagonal, then B carries an insertion that A makes up for at its end
+            h = core // 2
+            A.append(one_hot(np.concatenate([s, ja])))
+            B.append(one_hot(np.concatenate([s[:h], jb, s[h:]])))
+    la, lb = [len(x) for x in A], [len(x) for x in B]
+    return dp.DpInputs(np.concatenate(A), np.concatenate([[0], np.cumsum(la)]).astype(np.int64), np.concatenate(B),
+                       np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+
+
+@pytest.mark.parametrize("band", ["0", "1"])
+@pytest.mark.parametrize("lanes,cols", [("0", "16"), ("8", "16"), ("64", "16"), ("4", "8"), ("32", "8")])
+def test_walk_band_and_paths_that_leave_it(lanes, cols, band, oracle_build, monkeypatch):
+    """The checkpoint walk reads the blocks around the straight corner-to-corner line from the band computed up front and
+    recomputes the others: paths that stay in the band, paths hundreds of columns away from it, and paths that enter and leave
+    it must all equal the oracle's, with the band on (forced) and off."""
+    monkeypatch.setenv("PM_DP_MODE", "ckpt")
+    monkeypatch.setenv("PM_DP_BAND", band)
+    monkeypatch.setenv("PM_DP_COLS", cols)
+    if lanes != "0":
+        monkeypatch.setenv("PM_DP_WALK_LANES", lanes)
+    inputs = shifted_pairs(11 + int(lanes), 3)
+    scores, paths, _ = run_and_compare(inputs, dp.make_params(3, 3))
+    # the paths do run far from the line: at least 150 rows off somewhere
+    far = 0
+    for k, path in enumerate(paths):
+        la = int(inputs.off_a[k + 1] - inputs.off_a[k])
+        lb = int(inputs.off_b[k + 1] - inputs.off_b[k])
+        i = np.cumsum(path != 1)
+        j = np.cumsum(path != 2)
+        far = max(far, int(np.abs(i - j * la / lb).max()))
+    assert far >= 150
+    # and pairs that stay near it
+    inputs = dp.synth_pairs(500 + int(lanes), 20, 3, 900, indel_rate=0.02, vary_length=True)
+    run_and_compare(inputs, dp.make_params(3, 3))
+
+
 @pytest.mark.parametrize("rows,expect_dot4", [(25, True), (26, False), (200, False)])
 def test_int8_path_selection_at_its_boundary(rows, expect_dot4, oracle_build):
     """rows x max|sub| = 125 fits int8 (dot4 path), 130 does not (int16 path); 200-row columns exercise counts above
@@ -192,12 +244,26 @@ def test_uniform_depth_variant_and_its_fallbacks(dot4, mode, oracle_build, monke
 
 
 def test_path_mode_is_chosen_by_batch_size(oracle_build):
-    """A small batch stores decision bits (the checkpoint walk's chain of blocks has a latency that does not shrink with the
-    batch), a large one leaves checkpoints; PM_DP_MODE fixes it either way (the other tests do)."""
+    """A batch of a few short pairs stores decision bits (the checkpoint walk's chain of blocks and its extra launches have a
+    latency that does not shrink with the batch), as does a mid-size one when the walk has no band to read (PM_DP_BAND=0); a
+    large one leaves checkpoints; PM_DP_MODE fixes it either way (the other tests do)."""
     params = dp.make_params(2, 2)
-    small = dp.DpBatch(dp.synth_pairs_fast(1, 64, 2, 1000), params)
+    small = dp.DpBatch(dp.synth_pairs_fast(1, 64, 2, 150), params)
     assert not small.variant()["checkpoints"]
     small.close()
+    import os
+    params8 = dp.make_params(8, 8)
+    mid_in = dp.synth_pairs_fast(1, 64, 8, 4096)
+    mid = dp.DpBatch(mid_in, params8)
+    assert mid.variant()["checkpoints"]
+    mid.close()
+    os.environ["PM_DP_BAND"] = "0"
+    try:
+        mid = dp.DpBatch(mid_in, params8)
+    finally:
+        del os.environ["PM_DP_BAND"]
+    assert not mid.variant()["checkpoints"]
+    mid.close()
     big_in = dp.synth_pairs_fast(2, 6000, 2, 1000)
     big = dp.DpBatch(big_in, params)
     assert big.variant()["checkpoints"]
