@@ -80,13 +80,12 @@ __host__ __device__ inline i64 dp_ck_bytes_written(i64 la, i64 lb, int C) {
 #define DP_BAND_BLOCKS 3
 #endif
 __host__ __device__ inline int dp_band_row_block(int la, int lb, int bw, int gg, int l0) {
-  long long jm = (long long)gg * bw + bw / 2;
-  if(jm > lb) {
-    jm = lb;
-  }
-  long long im = lb > 0 ? (jm * la + lb / 2) / lb : 1;
+  // (only the two kernels of dp_walk.hip call this, with the same arguments, so all that matters is that it is a function of
+  // them: double arithmetic instead of a 64-bit integer division, which costs the walk kernel some 70 registers)
+  const double jm = fmin((double)gg * bw + bw / 2, (double)lb);
+  int im = (int)(jm * (double)la / (double)(lb > 0 ? lb : 1) + 0.5);
   im = im < 1 ? 1 : (im > la ? la : im);
-  return (int)((im - 1 + l0) / DP_CK_R);
+  return (im - 1 + l0) / DP_CK_R;
 }
 // bytes of one block's decisions as the walk keeps them in LDS: DP_CK_R rows of `lanes_per_pair` words holding 4 bits for each
 // of the lane's columns (1, 2 or 4 bytes)

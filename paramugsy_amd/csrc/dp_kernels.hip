@@ -729,30 +729,29 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   if(const char *e = getenv("PM_DP_DOT4")) {
     h->dot4 = h->dot4 && atoi(e) != 0;
   }
-  // chunks: consecutive pairs whose workspace fits the budget.  A batch that fits is one chunk; otherwise the budget is cut
-  // in two halves that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernel
-  // of the next (dp_run)
   // Columns of B per lane: 16, or 8 for a batch of a few hundred pairs at most whose profiles fit one 1 024-column stripe --
   // two stripes of 512 then, so twice the wavefronts a pair can keep busy, each with half the work per step (256 pairs of
   // 2 x 1 kbp: 0.60 -> 0.46 ms).  Longer pairs already have stripes to run side by side, and narrower stripes only make the
-  // checkpoint walk's blocks smaller and its chain longer.
+  // checkpoint walk's blocks smaller and its chain longer -- which stops mattering once the walk reads its blocks from the
+  // band: batches with fewer pairs than the chip has CUs take 8 columns whatever their length (128 pairs of 32 x 10 kbp: fill
+  // 7.7 -> 6.9 ms, walk 0.85 -> 1.16 ms; from ~250 pairs up 16 columns win again).
+  // the offset tables go through the batch's pinned staging when it has one (dp_stream.hip)
+  const bool staged = h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32;
+  const int band_env = getenv("PM_DP_BAND") ? atoi(getenv("PM_DP_BAND")) : -1; // 0: never, 1: whenever it fits
   if(!h->cols_forced) {
     i64 max_lb = 0;
     for(i64 k = 0; k < n_pairs; ++k) {
       max_lb = std::max(max_lb, h->off_b[k + 1] - h->off_b[k]);
     }
-    h->cols_per_lane = n_pairs <= 512 && max_lb <= 1024 ? 8 : 16;
+    h->cols_per_lane = (n_pairs <= 512 && max_lb <= 1024) || (n_pairs <= 200 && !staged && band_env != 0) ? 8 : 16;
     if(h->walk_lanes && !dp_walk_lanes_ok(h->cols_per_lane, h->walk_lanes)) {
       h->walk_lanes = 0;
     }
   }
-  // the offset tables go through the batch's pinned staging when it has one (dp_stream.hip)
-  const bool staged = h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32;
   // The band of the walk (dp_internal.hpp) pays while the walk alone would leave the chip mostly idle: up to one wavefront per
   // SIMD (measured: 2 048 pairs of 8 x 4 kbp 2.69 -> 1.93 ms, 4 096 pairs 2.74 -> 3.56 ms; 1 000 pairs of 2 x 1 kbp 0.47 -> 0.28 ms,
   // 4 000 pairs 0.59 -> 0.90 ms)
   auto band_pays = [](i64 n, int lanes) { return n * lanes <= 1024 * 64; };
-  const int band_env = getenv("PM_DP_BAND") ? atoi(getenv("PM_DP_BAND")) : -1; // 0: never, 1: whenever it fits
   // Paths from checkpoints or from stored decision bits?  The checkpoint fill is 2.3x faster per cell but its walk is a chain
   // of blocks with ~15 us of latency each, whatever the batch size; a small batch is better off storing the bits.  Measured on
   // MI355X (profiles/r02_dp_mode_sweep.txt): bits 2.3 T cells/s, checkpoint fill 5.2 T cells/s, a lone pair's fill 0.36 us per
@@ -804,6 +803,9 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     total_words += need_words(k);
     h->cells += (h->off_a[k + 1] - h->off_a[k]) * (h->off_b[k + 1] - h->off_b[k]);
   }
+  // chunks: consecutive pairs whose workspace fits the budget.  A batch that fits is one chunk; otherwise the budget is cut
+  // in two halves that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernel
+  // of the next (dp_run)
   // the workspace is allocated to what the chunks need; if the device cannot give that much (other allocations beside this
   // batch) the budget is halved and the batch cut into more chunks, down to 256 MiB
   bool pipelined = false;

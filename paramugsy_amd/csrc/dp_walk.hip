@@ -19,6 +19,7 @@
 // fill kernel (the groups of a launch keep every SIMD busy), so what counts is instructions per recomputed cell.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "dp_internal.hpp"
@@ -35,6 +36,8 @@ template <int N> struct BitsWord { typedef unsigned type; };
 template <> struct BitsWord<1> { typedef unsigned char type; };
 template <> struct BitsWord<2> { typedef unsigned char type; };
 template <> struct BitsWord<4> { typedef unsigned short type; };
+template <bool DOT4> struct RowWord { typedef int4 type; };
+template <> struct RowWord<true> { typedef int2 type; };
 
 template <int C, int LPP, bool DOT4>
 __global__ void __launch_bounds__(64)
@@ -49,31 +52,49 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   constexpr int G = 64 / LPP;     // pairs per wavefront
   static_assert(C2 >= 1 && C2 <= 8 && C % C2 == 0 && C2 * LPP == BW, "a lane's columns lie in one lane of the fill kernel");
   typedef typename BitsWord<C2>::type bits_t;
-  __shared__ int4 sh_a[G][R]; // A's rows of the block, expanded as the cell reads them
+  typedef typename RowWord<DOT4>::type arow_t;
+  __shared__ arow_t sh_a[G][R]; // A's rows of the block, expanded as the cell reads them (the int8 path reads 8 bytes of the 16)
   __shared__ int2 sh_left[G][R + 1];
   __shared__ bits_t sh_bits[G][R][LPP];
   const int grp = threadIdx.x / LPP, q = threadIdx.x % LPP;
-  const i64 idx = (i64)blockIdx.x * G + grp;
-  const bool valid = idx < n;
-  i64 pair;
-  int ggw = 0;
-  if(band_mode == 1) {
-    pair = band.work[2 * (valid ? idx : 0)];
-    ggw = band.work[2 * (valid ? idx : 0) + 1];
-  }
-  else {
-    pair = order[valid ? idx : 0]; // the launch's pairs in processing order
-  }
   constexpr int BLOCK_WORDS = R * LPP * (int)sizeof(bits_t) / 4;
-  const i64 a0 = off_a[pair], b0 = off_b[pair];
-  const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
-  const u64 *A = cols_a + a0;
-  const u64 *B = cols_b + b0;
-  const unsigned *ckp = ck + tb_off[pair];
-  unsigned char *out = ops + a0 + b0;
   const int go = P.go, ge = P.ge, gop = go - ge;
-  int i = la, j = lb, state = 0; // DP coordinates of the walk (cell (i, j) = row i-1 of A against column j-1 of B)
-  int at = la + lb;
+  // the group's current pair
+  bool have = false;
+  i64 pair = 0;
+  int ggw = 0, la = 0, lb = 0;
+  const u64 *A = cols_a, *B = cols_b;
+  const unsigned *ckp = ck;
+  unsigned char *out = ops;
+  int i = 0, j = 0, state = 0; // DP coordinates of the walk (cell (i, j) = row i-1 of A against column j-1 of B)
+  int at = 0;
+  auto take = [&](i64 p) {
+    pair = p;
+    const i64 a0 = off_a[p], b0 = off_b[p];
+    la = (int)(off_a[p + 1] - a0);
+    lb = (int)(off_b[p + 1] - b0);
+    A = cols_a + a0;
+    B = cols_b + b0;
+    ckp = ck + tb_off[p];
+    out = ops + a0 + b0;
+    i = la;
+    j = lb;
+    state = 0;
+    at = la + lb;
+    have = true;
+  };
+  {
+    const i64 idx = (i64)blockIdx.x * G + grp;
+    if(band_mode == 1) {
+      if(idx < n) {
+        ggw = band.work[2 * idx + 1];
+        take(band.work[2 * idx]);
+      }
+    }
+    else if(idx < n) {
+      take(order[idx]); // the launch's pairs in processing order
+    }
+  }
 
   for(int pass = 0;; ++pass) {
     bool live;
@@ -84,15 +105,29 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       const int l0w = (ggw * DP_CK_W) & 63;
       const int kb = dp_band_row_block(la, lb, BW, ggw, l0w) - DP_BAND_BLOCKS / 2 + pass;
       const int top = kb * R - l0w;
-      live = valid && kb >= 0 && top < la && top + R >= 1;
+      live = have && kb >= 0 && top < la && top + R >= 1;
       i = min(la, top + R);
       j = min(lb, (ggw + 1) * BW);
     }
     else {
-      live = valid && i > 0 && j > 0;
-      if(!__any(live)) {
+      if(!(have && i > 0 && j > 0)) { // the same for all lanes of the group
+        if(have) { // one profile exhausted: the rest is a single gap run
+          const int rest = i + j;
+          const unsigned char op = i == 0 ? 1 : 2;
+          for(int k2 = q; k2 < rest; k2 += LPP) {
+            out[at - 1 - k2] = op;
+          }
+          at -= rest;
+          if(q == 0) {
+            n_ops[pair] = la + lb - at;
+          }
+          have = false;
+        }
+      }
+      if(!__any(have)) {
         break;
       }
+      live = have && i > 0 && j > 0;
     }
     // ---- the block the walk is in: column group gg (lanes l0 .. l0 + DP_CK_W - 1 of stripe s of the fill kernel), row block k
     const int gg = live ? (j - 1) / BW : 0;
@@ -146,13 +181,20 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     if(in_band) {
       const unsigned *src = band.bits + band_block * BLOCK_WORDS;
       unsigned *dst = reinterpret_cast<unsigned *>(&sh_bits[grp][0][0]);
+#pragma unroll 4
       for(int w = q; w < BLOCK_WORDS; w += LPP) {
         dst[w] = src[w];
       }
     }
     if(comp) {
       for(int r = q; r < nrows; r += LPP) {
-        sh_a[grp][r] = dp_expand_row<DOT4>(A[i0 + r]);
+        const int4 v = dp_expand_row<DOT4>(A[i0 + r]);
+        if constexpr(DOT4) {
+          sh_a[grp][r] = make_int2(v.x, v.y);
+        }
+        else {
+          sh_a[grp][r] = v;
+        }
       }
       const int gl = gg * DP_CK_W - 1, sl = gl >> 6, ll = gl & 63; // the lane left of the group (of the previous stripe for l0 = 0)
       for(int rr = q; rr <= nrows; rr += LPP) {
@@ -177,12 +219,23 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     if(q == 0) {
       diag_in = sh_left[grp][0].x;
     }
-    const int4 *arow = &sh_a[grp][0];
+    const arow_t *arow = &sh_a[grp][0];
     const int2 *lrow = &sh_left[grp][1];
     bits_t *brow = &sh_bits[grp][0][q];
     // A's row and (first lane of the group) the left edge are read one step ahead, so that the reads' latency is not on the
     // step's path; the index is clamped instead of predicated (a row that is read and not used costs nothing)
-    int4 a_nx = arow[min(max(-q, 0), R - 1)];
+    int4 a_nx = make_int4(0, 0, 0, 0);
+    {
+      const int r0 = min(max(-q, 0), R - 1);
+      if constexpr(DOT4) {
+        const int2 t2 = arow[r0];
+        a_nx.x = t2.x;
+        a_nx.y = t2.y;
+      }
+      else {
+        a_nx = arow[r0];
+      }
+    }
     int2 l_nx = lrow[min(max(-q, 0), R - 1)];
     if(ablate & 1) { // timing experiments only (PM_DP_WALK_ABLATE): no recomputation, every decision reads "diagonal"
       for(int r = q; r < R * LPP; r += LPP) {
@@ -197,8 +250,8 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       const int2 lb_ = l_nx;
       {
         const int rn = min(max(r + 1, 0), R - 1);
-        if(DOT4) {
-          const int2 t2 = *reinterpret_cast<const int2 *>(arow + rn);
+        if constexpr(DOT4) {
+          const int2 t2 = arow[rn];
           a_nx.x = t2.x;
           a_nx.y = t2.y;
         }
@@ -241,6 +294,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       if(live) {
         unsigned *dst = band.bits + band_block * BLOCK_WORDS;
         const unsigned *src = reinterpret_cast<const unsigned *>(&sh_bits[grp][0][0]);
+#pragma unroll 4
         for(int w = q; w < BLOCK_WORDS; w += LPP) {
           dst[w] = src[w];
         }
@@ -308,18 +362,6 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     }
     __syncthreads();
   }
-  // one profile exhausted: the rest is a single gap run
-  if(valid && band_mode != 1) {
-    const int rest = i + j;
-    const unsigned char op = i == 0 ? 1 : 2;
-    for(int k2 = q; k2 < rest; k2 += LPP) {
-      out[at - 1 - k2] = op;
-    }
-    at -= rest;
-    if(q == 0) {
-      n_ops[pair] = la + lb - at;
-    }
-  }
 }
 
 template <int C, int LPP, bool DOT4>
@@ -331,10 +373,12 @@ static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, c
   const bool with_band = band.work != nullptr && band.n_work > 0;
   if(with_band) {
     const unsigned bblocks = (unsigned)((band.n_work + G - 1) / G);
-    dp_walk_kernel<C, LPP, DOT4><<<bblocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, band.n_work, tb_off, ck, ops, n_ops, P, band, 1, ablate);
+    dp_walk_kernel<C, LPP, DOT4><<<bblocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, band.n_work, tb_off, ck, ops, n_ops, P, band, 1,
+                                                             ablate);
     PM_HIP(hipGetLastError());
   }
-  dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, with_band ? 2 : 0, ablate);
+  dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, with_band ? 2 : 0,
+                                                          ablate);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
