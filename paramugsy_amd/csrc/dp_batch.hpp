@@ -31,6 +31,7 @@ struct pm_dp_batch {
   bool mode_auto = true;  // ckpt chosen per batch in dp_batch_plan (PM_DP_MODE=bits|ckpt fixes it)
   int walk_lanes = 0;     // lanes per pair of the checkpoint walk; 0 = chosen per launch; PM_DP_WALK_LANES overrides
   pm::DevBuf pipe_error;
+  pm::DevBuf gprog; // progress words of pairs whose stripes run on several workgroups (dp_fill_kernel, NG)
   // the band of the checkpoint walk (dp_internal.hpp), set up by dp_batch_plan for one-chunk batches of few pairs
   pm::DevBuf d_band_work, d_band_off, band_bits;
   pm::i64 band_work_items = 0; // 0: no band

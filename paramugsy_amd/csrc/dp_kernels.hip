@@ -72,11 +72,17 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 // stripe may start a 64-row block as soon as the stripe to its left has published those rows of its boundary:
 // a pipeline of stripes, synchronised through one progress word per wave in LDS.  Waits are bounded (a timeout sets
 // *pipe_error and lets the wave run on, so the grid always drains).
+// NG (run time, `ng`): workgroups per pair.  A workgroup sits on one CU, so with fewer pairs than CUs most of the chip would idle:
+// the pair's stripes are then dealt round robin to the NG * NW waves of NG consecutive workgroups, the progress words live
+// in global memory (`gprog`, zeroed by the host before the launch), and the seam values and the progress words are written and
+// read as agent-scope atomics (sc1: past the XCD's L2), ordered by the wave's own s_waitcnt vmcnt(0) -- agent-scope release /
+// acquire FENCES write back and invalidate the whole L2 of the XCD every time and made 128 pairs of 32 x 10 kbp 3.5x slower.
+// The host only asks for this when all workgroups of the launch are resident at once (n * NG <= CUs).
 template <int C, int MODE, bool DOT4, int NW, bool UNI>
 __global__ void __launch_bounds__(64 * NW)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
-               int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P) {
+               int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P, int ng, int *__restrict__ gprog) {
   static_assert(C % 8 == 0, "whole traceback words per lane per step");
   constexpr bool TRACE = MODE == DP_MODE_BITS;
   constexpr bool CKPT = MODE == DP_MODE_CKPT;
@@ -89,7 +95,12 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const int lane = threadIdx.x & 63;
   int4 *ring = ring_all[wv];
   unsigned(*tbstage)[TBS] = tbstage_all[wv];
-  const i64 pair = order[blockIdx.x]; // the launch's pairs in processing order (dp_batch_plan)
+  const int pos = ng > 1 ? (int)(blockIdx.x / (unsigned)ng) : (int)blockIdx.x;
+  const int team = NW * ng;                                              // waves of this pair
+  const int tw = ng > 1 ? wv * ng + (int)(blockIdx.x % (unsigned)ng) : wv; // this wave's place among them: consecutive stripes go to
+                                                                          // different workgroups
+  int *gp = ng > 1 ? gprog + (i64)pos * team : nullptr;
+  const i64 pair = order[pos]; // the launch's pairs in processing order (dp_batch_plan)
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
   const u64 *A = cols_a + a0;
@@ -106,7 +117,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   int result = 0;
   if(la == 0 || lb == 0) { // one profile empty: a single gap run
     int n = la + lb;
-    if(lane == 0) {
+    if(lane == 0 && tw == 0) {
       scores[pair] = n == 0 ? 0 : -(go + (n - 1) * ge);
     }
     return;
@@ -118,7 +129,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     __syncthreads();
   }
 
-  for(int s = wv; s < n_stripes; s += NW) {
+  for(int s = tw; s < n_stripes; s += team) {
     const int j0 = s * W + lane * C; // this lane's first column of B (0-based)
     int w0[C], w1[C], w2[C], hop[C], f[C];
 #pragma unroll
@@ -134,8 +145,10 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     int bin_ho = 0, bin_e = DP_NEG_INF;
     if(s > 0) {
       // lane 63's stores of the previous stripe must be visible to every lane's loads
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if(ng == 1) { // (several workgroups: the seam is read with agent-scope atomic loads instead)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
     }
 
     for(int t0 = 0; t0 < steps; t0 += 64) {
@@ -147,28 +160,52 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         ring[r & 127] = v;
         if(NW > 1 && s > 0) {
           // rows [t0, t0+63] of the left stripe's boundary must have been published by its wave
-          const int need = ((s - 1) / NW) * la + min(t0 + 64, la);
-          volatile int *word = &progress[(s - 1) % NW];
+          const int need = ((s - 1) / team) * la + min(t0 + 64, la);
           int spins = 0;
-          while(*word < need) {
-            __builtin_amdgcn_s_sleep(2);
-            if(++spins > (1 << 22)) {
-              if(lane == 0) {
-                atomicOr(pipe_error, 1);
+          if(ng > 1) {
+            int *word = gp + (s - 1) % team;
+            while(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+              __builtin_amdgcn_s_sleep(4);
+              if(++spins > (1 << 22)) {
+                if(lane == 0) {
+                  atomicOr(pipe_error, 1);
+                }
+                break;
               }
-              break;
             }
+            asm volatile("" ::: "memory");
           }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          else {
+            volatile int *word = &progress[(s - 1) % NW];
+            while(*word < need) {
+              __builtin_amdgcn_s_sleep(2);
+              if(++spins > (1 << 22)) {
+                if(lane == 0) {
+                  atomicOr(pipe_error, 1);
+                }
+                break;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          }
         }
         if(s > 0) {
           int2 b = make_int2(0, DP_NEG_INF);
           if(r < la) {
+            const int2 *src;
             if constexpr(CKPT) { // lane 63 closes a column group: its column checkpoints of stripe s - 1 are the seam
-              b = *reinterpret_cast<const int2 *>(tbp + dp_ck_col_word(la, s - 1, (i64)r + 63, 63));
+              src = reinterpret_cast<const int2 *>(tbp + dp_ck_col_word(la, s - 1, (i64)r + 63, 63));
             }
             else {
-              b = bp[r];
+              src = bp + r;
+            }
+            if(ng > 1) {
+              const unsigned long long v =
+                  __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              b = make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
+            }
+            else {
+              b = *src;
             }
           }
           // consume the loaded values here, so the wait for them sits in this block (once per 64 steps) and
@@ -237,12 +274,26 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         diag_in = ho_in;
         if constexpr(!CKPT) {
           if(lane == 63 && s + 1 < n_stripes) {
-            bp[ii16 >> 4] = make_int2(hop[C - 1], e);
+            if(ng > 1) {
+              __hip_atomic_store(reinterpret_cast<unsigned long long *>(bp + (ii16 >> 4)),
+                                 (unsigned long long)(unsigned)hop[C - 1] | ((unsigned long long)(unsigned)e << 32), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else {
+              bp[ii16 >> 4] = make_int2(hop[C - 1], e);
+            }
           }
         }
         if constexpr(CKPT) { // what this row hands to the next column group: one coalesced store per step
           if(DP_CK_W == 1 || (lane & (DP_CK_W - 1)) == DP_CK_W - 1) {
-            *reinterpret_cast<int2 *>(tbp + dp_ck_col_word(la, s, t, lane)) = make_int2(hop[C - 1], e);
+            if(NW > 1 && ng > 1 && lane == 63) { // the seam for another workgroup
+              __hip_atomic_store(reinterpret_cast<unsigned long long *>(tbp + dp_ck_col_word(la, s, t, lane)),
+                                 (unsigned long long)(unsigned)hop[C - 1] | ((unsigned long long)(unsigned)e << 32), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else {
+              *reinterpret_cast<int2 *>(tbp + dp_ck_col_word(la, s, t, lane)) = make_int2(hop[C - 1], e);
+            }
           }
         }
       }
@@ -279,9 +330,18 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
       if(NW > 1) {
         // lane 63 has stored the boundary of rows < t1 - 63: publish the count (cumulated over this wave's stripes)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if(lane == 0) {
-          *(volatile int *)&progress[wv] = (s / NW) * la + max(0, min(t1 - 63, la));
+        const int done = (s / team) * la + max(0, min(t1 - 63, la));
+        if(ng > 1) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // lane 63's seam stores have been acknowledged
+          if(lane == 0) {
+            __hip_atomic_store(gp + tw, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        else {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if(lane == 0) {
+            *(volatile int *)&progress[wv] = done;
+          }
         }
       }
     }
@@ -296,7 +356,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       result = __builtin_amdgcn_readlane(hv, jj / C) + gop - (la + lb) * ge; // un-skew
     }
   }
-  if(lane == 0 && wv == (n_stripes - 1) % NW) {
+  if(lane == 0 && tw == (n_stripes - 1) % team) {
     scores[pair] = result;
   }
 }
@@ -911,14 +971,18 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
           }
           at += groups;
         }
-        PM_TRY(grow(h->d_band_work, (size_t)items * 8));
-        PM_TRY(grow(h->d_band_off, (size_t)n_pairs * 8));
-        PM_TRY(grow(h->band_bits, (size_t)band_bytes));
-        PM_HIP(hipStreamSynchronize(stream));
-        PM_HIP(hipMemcpy(h->d_band_work.p, work.data(), (size_t)items * 8, hipMemcpyHostToDevice));
-        PM_HIP(hipMemcpy(h->d_band_off.p, boff.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice));
-        h->band_work_items = items;
-        h->band_lanes = lpp;
+        // the band is an accelerator, not a need: a device that has no room for it walks without
+        if(grow(h->d_band_work, (size_t)items * 8) == PM_OK && grow(h->d_band_off, (size_t)n_pairs * 8) == PM_OK &&
+           grow(h->band_bits, (size_t)band_bytes) == PM_OK) {
+          PM_HIP(hipStreamSynchronize(stream));
+          PM_HIP(hipMemcpy(h->d_band_work.p, work.data(), (size_t)items * 8, hipMemcpyHostToDevice));
+          PM_HIP(hipMemcpy(h->d_band_off.p, boff.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice));
+          h->band_work_items = items;
+          h->band_lanes = lpp;
+        }
+        else {
+          (void)hipGetLastError();
+        }
       }
     }
     if(n_pairs > 0) {
@@ -984,7 +1048,7 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
   const int *order = (const int *)h->d_order.p + first;
   // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
   // have several stripes to pipeline
-  int nw = 1;
+  int nw = 1, ng = 1;
   {
     i64 max_stripes = 0, max_la = 0;
     for(i64 q = first; q < first + n; ++q) {
@@ -1005,12 +1069,44 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
        ((h->waves_override == 2 || h->waves_override == 4 || h->waves_override == 8 || h->waves_override == 16) && fits)) {
       nw = h->waves_override;
     }
+    // workgroups per pair: with at most half as many pairs as CUs, as many as give every workgroup a CU of its own and still two
+    // stripes; the waves of a workgroup then follow from the stripes it gets (consecutive stripes go to different workgroups)
+    static const int cus = [] {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    }();
+    const int groups_env = getenv("PM_DP_GROUPS") ? atoi(getenv("PM_DP_GROUPS")) : -1; // 1: never; 2, 4, ..: that many
+    if(fits && groups_env > 1 && h->waves_override >= 2 && n * groups_env <= cus) { // both forced (tests)
+      ng = groups_env;
+    }
+    else if(fits && max_stripes >= 4 && groups_env != 1 && h->waves_override == 0) {
+      int want = 1;
+      while(want < 16 && n * want * 2 <= cus && want * 4 <= max_stripes) {
+        want *= 2;
+      }
+      if(groups_env > 1) {
+        want = groups_env;
+      }
+      if(want > 1 && n * want <= cus && (i64)want * 2 <= max_stripes) { // every workgroup of the launch must be resident
+        ng = want;
+        const i64 per_group = (max_stripes + ng - 1) / ng;
+        nw = 2;
+        while(nw < 16 && nw < per_group) {
+          nw *= 2;
+        }
+      }
+    }
+  }
+  if(ng > 1) {
+    PM_TRY(grow(h->gprog, (size_t)(n * ng * nw) * sizeof(int)));
+    PM_HIP(hipMemsetAsync(h->gprog.p, 0, (size_t)(n * ng * nw) * sizeof(int), stream));
   }
 #define DP_LAUNCH_FILL(CC, TR, D4, NWV, UN)                                                                                                  \
-  dp_fill_kernel<CC, TR, D4, NWV, UN><<<(unsigned)n, 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,           \
-                                                                            (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p, order, tb_off, \
-                                                                            tbw, (int2 *)h->bnd.p, (int *)h->scores.p,                       \
-                                                                            (int *)h->pipe_error.p, h->params)
+  dp_fill_kernel<CC, TR, D4, NWV, UN><<<(unsigned)(n * ng), 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,    \
+                                                                                   (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p,    \
+                                                                                   order, tb_off, tbw, (int2 *)h->bnd.p, (int *)h->scores.p, \
+                                                                                   (int *)h->pipe_error.p, h->params, ng, (int *)h->gprog.p)
 #define DP_LAUNCH_FILL_D4(CC, TR, NWV)         \
   if(h->dot4 && h->uni) {                      \
     DP_LAUNCH_FILL(CC, TR, true, NWV, true);   \

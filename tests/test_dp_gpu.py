@@ -110,6 +110,27 @@ def test_every_kernel_variant_on_multi_stripe_pairs(waves, cols, dot4, mode, ora
     run_and_compare(inputs, dp.make_params(4, 4))
 
 
+@pytest.mark.parametrize("groups,waves", [("2", "2"), ("4", "2"), ("2", "16"), ("8", "4"), ("16", "2"), ("4", "0")])
+@pytest.mark.parametrize("cols", ["8", "16"])
+@pytest.mark.parametrize("mode", ["bits", "ckpt"])
+def test_stripes_of_a_pair_on_several_workgroups(groups, waves, cols, mode, oracle_build, monkeypatch):
+    """A pair's stripes dealt to the waves of several workgroups (few pairs: fewer workgroups than CUs otherwise), the seam
+    handed over through global memory with agent-scope release / acquire: same scores and paths as the oracle, for teams
+    smaller and larger than the number of stripes, and for the split dp_launch_fill picks by itself (waves "0")."""
+    monkeypatch.setenv("PM_DP_GROUPS", groups)
+    if waves != "0":
+        monkeypatch.setenv("PM_DP_WAVES", waves)
+    monkeypatch.setenv("PM_DP_COLS", cols)
+    monkeypatch.setenv("PM_DP_MODE", mode)
+    rng = np.random.default_rng(int(groups) * 100 + int(waves) + int(cols))
+    la = [700, 64, 1300, 129, 900, 5, 150]
+    lb = [2600, 1025, 4100, 2049, 513, 1100, 9300 if cols == "8" else 17000]
+    cols_of = lambda n: np.concatenate([rng.integers(0, 3, size=(n, 5)).astype(np.uint8), np.zeros((n, 3), np.uint8)], axis=1)
+    inputs = dp.DpInputs(np.concatenate([cols_of(n) for n in la]), np.concatenate([[0], np.cumsum(la)]).astype(np.int64),
+                         np.concatenate([cols_of(n) for n in lb]), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+    run_and_compare(inputs, dp.make_params(4, 4))
+
+
 @pytest.mark.parametrize("lanes,cols", [("8", "16"), ("16", "16"), ("32", "16"), ("64", "16"), ("4", "8"), ("8", "8"), ("16", "8"), ("32", "8")])
 def test_checkpoint_walk_with_every_group_size(lanes, cols, oracle_build, monkeypatch):
     """The checkpoint walk with every group size (lanes per pair) the block width allows, for both column counts of the fill
