@@ -77,7 +77,10 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 // in global memory (`gprog`, zeroed by the host before the launch), and the seam values and the progress words are written and
 // read as agent-scope atomics (sc1: past the XCD's L2), ordered by the wave's own s_waitcnt vmcnt(0) -- agent-scope release /
 // acquire FENCES write back and invalidate the whole L2 of the XCD every time and made 128 pairs of 32 x 10 kbp 3.5x slower.
-// The host only asks for this when all workgroups of the launch are resident at once (n * NG <= CUs).
+// The host asks for this only while every workgroup can have a CU of its own (n * NG <= CUs).  No workgroup can wait for ever on
+// one that has not started: workgroups start in blockIdx order, a pair's are consecutive, earlier pairs never wait on later
+// ones and so finish and free their CUs, and the chip holds any one pair's (at most 16) workgroups at once; the bounded waits
+// above stay as the last line of defence.
 template <int C, int MODE, bool DOT4, int NW, bool UNI>
 __global__ void __launch_bounds__(64 * NW)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
