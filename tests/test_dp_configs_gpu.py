@@ -69,6 +69,33 @@ def test_deep_profiles_32_rows_10k_columns(n_pairs, oracle_build):
     batch.close()
 
 
+@pytest.mark.parametrize("n_pairs,rows,L", [(8, 32, 10000), (48, 32, 10000), (100, 8, 4096)])
+def test_pairs_split_over_workgroups_repeat_exactly(n_pairs, rows, L, oracle_build, monkeypatch):
+    """Fewer pairs than CUs: every pair's stripes run on several workgroups that hand the seam over through agent-scope atomics.
+    Twenty passes over the same batch must give the same scores and the same ops, byte for byte, as the one-workgroup-per-pair
+    launch (PM_DP_GROUPS=1), in both path modes; a sample is checked against the oracle."""
+    inputs = dp.synth_batch(900 + n_pairs, np.full(n_pairs, L), np.full(n_pairs, L), rows, rows)
+    params = dp.make_params(rows, rows)
+    for mode in ("ckpt", "bits"):
+        monkeypatch.setenv("PM_DP_MODE", mode)
+        monkeypatch.setenv("PM_DP_GROUPS", "1")
+        ref = dp.DpBatch(inputs, params)
+        ref.run(traceback=True)
+        r_scores, r_ops, r_n = ref.fetch()
+        ref.close()
+        monkeypatch.delenv("PM_DP_GROUPS")
+        batch = dp.DpBatch(inputs, params)
+        for _ in range(20):
+            batch.run(traceback=True)
+            scores, ops, n_ops = batch.fetch()
+            assert np.array_equal(scores, r_scores) and np.array_equal(n_ops, r_n)
+            p0, p1 = batch.paths(ops, n_ops), dp.paths_of(inputs, r_ops, r_n)
+            assert all(np.array_equal(a, b) for a, b in zip(p0, p1))
+        if mode == "ckpt":
+            check_sample(inputs, params, scores, batch.paths(ops, n_ops), [0, n_pairs - 1])
+        batch.close()
+
+
 def test_ragged_segment_batch_stand_in_for_config_2(oracle_build):
     """Stand-in for BASELINE.json configs[2] ("~100 k segment profile alignments"; nucmer is not in the image): 20 000 ragged
     4-row pairs, lengths log-normal (median 1 500, sigma 0.6, clipped to [200, 8 000]), lb = la * (1 + N(0, 0.05)).  The bench
