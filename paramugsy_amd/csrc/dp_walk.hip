@@ -31,6 +31,9 @@ namespace pm {
 
 // lane l takes lane l-1's value (lane 0 keeps its own); the first lane of every group replaces what it gets
 __device__ __forceinline__ int from_left_lane(int v) { return __builtin_amdgcn_update_dpp(v, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
+// the same inside rows of 16 lanes: the first lane of every row keeps `first` (row_shr:1 without bound_ctrl)
+#define DPP_ROW_SHR1 0x111
+__device__ __forceinline__ int from_left_in_row(int first, int v) { return __builtin_amdgcn_update_dpp(first, v, DPP_ROW_SHR1, 0xf, 0xf, false); }
 
 template <int N> struct BitsWord { typedef unsigned type; };
 template <> struct BitsWord<1> { typedef unsigned char type; };
@@ -213,60 +216,81 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
     }
     __syncthreads();
-    // ---- the block's cells, anti-diagonal over the group's lanes: at step u lane q is on row u - q of the block
+    // ---- the block's cells, anti-diagonal over the group's lanes: at step u lane q is on row r = u - q of the block
     int e = DP_NEG_INF;
-    int diag_in = from_left_lane(hop[C2 - 1]); // H~ - gop above-left of the lane's first column
-    if(q == 0) {
-      diag_in = sh_left[grp][0].x;
-    }
     const arow_t *arow = &sh_a[grp][0];
-    const int2 *lrow = &sh_left[grp][1];
+    const int2 *lrow = &sh_left[grp][1]; // [x]: the left edge of block row x; [-1]: of the row above the block
     bits_t *brow = &sh_bits[grp][0][q];
-    // A's row and (first lane of the group) the left edge are read one step ahead, so that the reads' latency is not on the
-    // step's path; the index is clamped instead of predicated (a row that is read and not used costs nothing)
-    int4 a_nx = make_int4(0, 0, 0, 0);
-    {
-      const int r0 = min(max(-q, 0), R - 1);
-      if constexpr(DOT4) {
-        const int2 t2 = arow[r0];
-        a_nx.x = t2.x;
-        a_nx.y = t2.y;
-      }
-      else {
-        a_nx = arow[r0];
-      }
+    // H~ - gop above-left of the lane's first column
+    int diag_in = LPP == 16 ? from_left_in_row(lrow[-1].x, hop[C2 - 1]) : from_left_lane(hop[C2 - 1]);
+    if(LPP != 16 && q == 0) {
+      diag_in = lrow[-1].x;
     }
-    int2 l_nx = lrow[min(max(-q, 0), R - 1)];
     if(ablate & 1) { // timing experiments only (PM_DP_WALK_ABLATE): no recomputation, every decision reads "diagonal"
       for(int r = q; r < R * LPP; r += LPP) {
         (&sh_bits[grp][0][0])[r] = 0;
       }
     }
-    for(int u = 0; !(ablate & 1) && __any(mine && u - q < nrows); ++u) {
-      int ho_in = from_left_lane(hop[C2 - 1]);
-      int e_in = from_left_lane(e);
-      const int r = u - q;
+    // steps of this block: the longest of the wavefront's groups (rows it recomputes + its lanes' skew), a scalar
+    int trip = 0;
+    {
+      const int need = comp && nrows > 0 ? nrows + qmax : 0; // the same in all lanes of a group
+#pragma unroll
+      for(int g = 0; g < G; ++g) {
+        trip = max(trip, __builtin_amdgcn_readlane(need, g * LPP));
+      }
+      if(ablate & 1) {
+        trip = 0;
+      }
+    }
+    const unsigned rows_mine = mine ? (unsigned)nrows : 0u; // (unsigned)r < rows_mine: this lane is on one of its rows
+    // A's row and the left edge are read one step ahead, so that the reads' latency is not on the step's path; the row index
+    // wraps instead of being clamped or predicated (a row that is read and not used costs nothing), and every lane reads the
+    // left edge although only the group's first uses it (no exec juggling)
+    int r = -q;
+    int4 a_nx = make_int4(0, 0, 0, 0);
+    int2 l_nx;
+    {
+      const int slot = r & (R - 1);
+      if constexpr(DOT4) {
+        const int2 t2 = arow[slot];
+        a_nx.x = t2.x;
+        a_nx.y = t2.y;
+      }
+      else {
+        a_nx = arow[slot];
+      }
+      l_nx = lrow[slot];
+    }
+    for(int u = 0; u < trip; ++u, ++r) {
       const int4 a = a_nx;
       const int2 lb_ = l_nx;
-      {
-        const int rn = min(max(r + 1, 0), R - 1);
-        if constexpr(DOT4) {
-          const int2 t2 = arow[rn];
-          a_nx.x = t2.x;
-          a_nx.y = t2.y;
-        }
-        else {
-          a_nx = arow[rn];
-        }
-        if(q == 0) {
-          l_nx = lrow[rn];
-        }
+      int ho_in, e_in;
+      if(LPP == 16) { // a DPP row is a group: its first lane keeps the `old` operand, the left edge
+        ho_in = from_left_in_row(lb_.x, hop[C2 - 1]);
+        e_in = from_left_in_row(lb_.y, e);
       }
-      if(mine && r >= 0 && r < nrows) {
+      else {
+        ho_in = from_left_lane(hop[C2 - 1]);
+        e_in = from_left_lane(e);
         if(q == 0) {
           ho_in = lb_.x;
           e_in = lb_.y;
         }
+      }
+      {
+        const int slot = (r + 1) & (R - 1);
+        if constexpr(DOT4) {
+          const int2 t2 = arow[slot];
+          a_nx.x = t2.x;
+          a_nx.y = t2.y;
+        }
+        else {
+          a_nx = arow[slot];
+        }
+        l_nx = lrow[slot];
+      }
+      if((unsigned)r < rows_mine) {
         const int ax = a.x, ay = a.y, az = DOT4 ? 0 : a.z;
         unsigned acc;
         asm volatile("" : "=v"(acc)); // every bit that is read gets shifted in below
