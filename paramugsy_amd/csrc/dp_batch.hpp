@@ -48,11 +48,6 @@ struct pm_dp_batch {
   std::vector<pm::i64> seg_first;
   std::vector<hipEvent_t> ev_seg;
   bool seg_events_armed = false;
-  // dp_stream.hip: a one-chunk batch may run its path kernel on a stream of the caller's (`ext_path_stream`) instead of the
-  // fill kernel's stream; dp_run then records `ev_ext_fill` / `ev_ext_path` and leaves the ordering to the caller
-  hipStream_t ext_path_stream = nullptr;
-  hipEvent_t ev_ext_fill = nullptr, ev_ext_path = nullptr;
-  bool ext_path_used = false; // set by dp_run: the last run's results are complete at ev_ext_path, not at the end of its stream
   // pinned host staging of a reusable batch (dp_stream.hip): offsets, workspace offsets and the column statistics
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
@@ -67,11 +62,6 @@ struct pm_dp_batch {
     }
     if(path_stream) {
       (void)hipStreamDestroy(path_stream);
-    }
-    for(hipEvent_t e : {ev_ext_fill, ev_ext_path}) {
-      if(e) {
-        (void)hipEventDestroy(e);
-      }
     }
     if(pinned) {
       (void)hipHostFree(pinned);

@@ -1204,8 +1204,6 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
   const size_t nc = h->chunk_tb.size();
   const bool timed = ms_fill || ms_path;
   const bool pipelined = nc > 1 && h->path_stream && traceback;
-  const bool ext = !pipelined && nc == 1 && traceback && h->ext_path_stream && h->ev_ext_fill && h->ev_ext_path;
-  h->ext_path_used = ext;
   if(timed && h->tv_fill0.size() < nc) {
     for(std::vector<hipEvent_t> *v : {&h->tv_fill0, &h->tv_fill1, &h->tv_path0, &h->tv_path1}) {
       while(v->size() < nc) {
@@ -1221,7 +1219,7 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       continue;
     }
     unsigned *tbw = tb + (h->tb_half_words ? (c & 1) * h->tb_half_words : 0);
-    hipStream_t ps = pipelined ? h->path_stream : (ext ? h->ext_path_stream : stream);
+    hipStream_t ps = pipelined ? h->path_stream : stream;
     if(pipelined && c >= 2) {
       PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c - 2], 0)); // the half is free again
     }
@@ -1255,10 +1253,6 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
         PM_HIP(hipEventRecord(h->ev_fill[c], stream));
         PM_HIP(hipStreamWaitEvent(ps, h->ev_fill[c], 0));
       }
-      if(ext) {
-        PM_HIP(hipEventRecord(h->ev_ext_fill, stream));
-        PM_HIP(hipStreamWaitEvent(ps, h->ev_ext_fill, 0));
-      }
       if(timed) {
         PM_HIP(hipEventRecord(h->tv_path0[c], ps));
       }
@@ -1268,9 +1262,6 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       }
       if(pipelined) {
         PM_HIP(hipEventRecord(h->ev_path[c], ps));
-      }
-      if(ext) {
-        PM_HIP(hipEventRecord(h->ev_ext_path, ps));
       }
     }
   }
