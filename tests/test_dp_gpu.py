@@ -298,6 +298,13 @@ def test_path_mode_is_chosen_by_batch_size(oracle_build):
         assert rc == 0 and s_ == scores[k]
 
 
+def test_published_needleman_wunsch_example_on_the_gpu(oracle_build):
+    from test_dp_oracle import needleman_wunsch_textbook_case
+    inputs, params = needleman_wunsch_textbook_case()
+    scores, paths, _ = run_and_compare(inputs, params)
+    assert scores.tolist() == [0]
+
+
 def test_weights_beyond_int16_are_refused():
     from paramugsy_amd import capi
     cols = np.zeros((4, 8), dtype=np.uint8)

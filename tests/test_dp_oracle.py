@@ -46,6 +46,37 @@ def test_oracle_scores_match_numpy_transcription(seed, oracle_build):
         assert (paths[k] != 1).sum() == len(a) and (paths[k] != 2).sum() == len(b)
 
 
+def needleman_wunsch_textbook_case():
+    """The worked example of the Needleman-Wunsch article most readers know (Wikipedia, "Needleman-Wunsch algorithm"): GCATGCG
+    against GATTACA with match +1, mismatch -1, indel -1 has optimal global score 0.  One-row profiles and gap_open =
+    gap_extend = 1 make this repo's profile DP that very recurrence."""
+    a, b = dp.pack_profile([b"GCATGCG"]), dp.pack_profile([b"GATTACA"])
+    inputs = dp.DpInputs(a, np.array([0, len(a)], np.int64), b, np.array([0, len(b)], np.int64))
+    params = dp.make_params(1, 1, match=1, mismatch=-1, base_gap=-1, open_per_pair=1, extend_per_pair=1)
+    return inputs, params
+
+
+def test_published_needleman_wunsch_example(oracle_build):
+    """The one known answer from outside this repo that the DP's specification can be held against (everything else about the DP
+    is "parity unpinned": SURVEY.md 0)."""
+    import pyoracle
+    inputs, params = needleman_wunsch_textbook_case()
+    scores, paths = pyoracle.dp_align(inputs, params)
+    assert scores.tolist() == [0]
+    assert (paths[0] != 1).sum() == 7 and (paths[0] != 2).sum() == 7
+    # the path re-scores to 0 by hand: +1 per match, -1 per mismatch, -1 per gap column
+    x, y, i, j, total = "GCATGCG", "GATTACA", 0, 0, 0
+    for op in paths[0]:
+        if op == 0:
+            total += 1 if x[i] == y[j] else -1
+            i, j = i + 1, j + 1
+        elif op == 1:
+            total, j = total - 1, j + 1
+        else:
+            total, i = total - 1, i + 1
+    assert total == 0 and numpy_dp(a=inputs.cols_a, b=inputs.cols_b, p=params) == 0
+
+
 def test_pack_profile_counts():
     cols = dp.pack_profile([b"ACGT-N", b"AC-TTa", b"-CGTAa"])
     assert cols[:, :5].tolist() == [[2, 0, 0, 0, 1], [0, 3, 0, 0, 0], [0, 0, 2, 0, 1], [0, 0, 0, 3, 0], [1, 0, 0, 1, 1], [2, 0, 0, 0, 0]]
