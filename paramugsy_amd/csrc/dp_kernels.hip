@@ -728,7 +728,7 @@ static int dp_walk_lanes_for(const pm_dp_batch *h, i64 n) {
     while(!dp_walk_lanes_ok(h->cols_per_lane, lpp)) {
       lpp *= 2;
     }
-    while(lpp < 32 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp < 2 * 1024 * 64) {
+    while(lpp < 32 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp <= 2 * 1024 * 64) {
       lpp *= 2;
     }
   }
