@@ -32,6 +32,7 @@ for name, key in keys.items():
                   if any(t in k for t in ("dp_", "translate_", "scatter_live", "rocprim"))}
     sq_all[key] = {k: {c: round(v["mean"]) for c, v in x.items() if c.startswith("SQ_")} for k, x in allk.items()
                    if any(t in k for t in ("dp_fill", "dp_walk", "translate_"))}
+table = {k: v for k, v in table.items() if k in keys.values()}  # no entries of workloads (or rounds) that are not measured any more
 table["_about"] = ("per-kernel means over the dispatches of `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` (separate runs of "
                    "`python3 bench.py <workload> --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end`, one workload per run: tools/refresh_profiles.sh); "
                    "units: KB as rocprofv3 reports; bench.py applies the gfx950 x2 correction to FETCH_SIZE")
