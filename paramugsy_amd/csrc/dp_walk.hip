@@ -10,9 +10,13 @@
 //      from the column checkpoints of the group to the left; A's rows (expanded as the fill kernel's LDS ring holds them) and
 //      the left edge are staged in LDS;
 //   3. the group re-runs the recurrence inside the block as a small anti-diagonal wavefront (lane q owns BW / LPP columns,
-//      neighbours exchange with v_mov_b32_dpp wave_shr:1) with the fill kernel's own hand-scheduled cell (dp_cell, 14 VALU
-//      instructions with the four decision bits), 4 bits per cell into LDS;
+//      neighbours exchange with v_mov_b32_dpp: row_shr:1 for groups of 16 lanes, which are DPP rows -- the group's first lane
+//      keeps the instruction's `old` operand, the left edge -- and wave_shr:1 plus a select otherwise) with the fill kernel's own
+//      hand-scheduled cell (dp_cell, 14 VALU instructions with the four decision bits), 4 bits per cell into LDS;
 //   4. the walk follows the decisions until it leaves the block through its top or its left edge, a whole run at a time.
+// For launches of few pairs the same kernel runs first in a second mode (band_mode 1) over (pair, column group) work items and
+// computes the blocks around the straight line between the corners, all at once, into global memory; the walk (band_mode 2)
+// then copies such a block's bits into LDS instead of recomputing it (dp_internal.hpp, "The band").
 // Same arithmetic, in the same skewed coordinates, as dp_fill_kernel (V~[i][j] = V[i][j] + (i + j) * gap_extend), so every
 // decision is the one the one-pass kernel would have stored.  A path crosses at most La / R + Lb / BW + 1 blocks, i.e. the
 // walk recomputes about La * BW + Lb * R cells of the La * Lb: 2-6 % at kilobase lengths.  It is bound by VALU issue like the
