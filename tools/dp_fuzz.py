@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the DP on the GPU box: random batches (pair count, lengths, depth, related or unrelated profiles, scoring)
+under random kernel choices (path mode, columns per lane, waves and workgroups per pair, band, walk lanes), every score and every
+path against oracle/dp_oracle.c.  python tools/dp_fuzz.py [seconds] [first seed]; prints one line per case, stops at the
+first mismatch with the environment that reproduces it."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np  # noqa: E402
+import pyoracle  # noqa: E402
+from paramugsy_amd import dp  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+KNOBS = {"PM_DP_MODE": ["ckpt", "ckpt", "bits", None], "PM_DP_COLS": ["8", "16", None], "PM_DP_WAVES": ["1", "2", "4", "8", "16", None, None],
+         "PM_DP_GROUPS": ["1", "2", "4", "8", None, None], "PM_DP_BAND": ["0", "1", None], "PM_DP_WALK_LANES": ["4", "8", "16", "32", None, None]}
+
+
+def random_case(rng):
+    rows = int(rng.choice([1, 2, 3, 4, 8, 13, 32, 60]))
+    n = int(rng.choice([1, 2, 3, 7, 20, 40]))
+    longest = int(rng.choice([40, 300, 1100, 2500, 5000]))
+    cells_left = 6e6
+    la, lb = [], []
+    for _ in range(n):
+        a = int(rng.integers(0 if rng.random() < 0.03 else 1, longest + 1))
+        b = int(rng.integers(0 if rng.random() < 0.03 else 1, longest + 1))
+        if rng.random() < 0.5:  # related lengths
+            b = max(1, int(a * (1 + rng.normal(0, 0.05))))
+        if a * b > cells_left:
+            b = max(1, int(cells_left // max(a, 1)))
+        cells_left = max(cells_left - a * b, 2e4)
+        la.append(a)
+        lb.append(b)
+    related = rng.random() < 0.6
+
+    def cols_random(total):
+        c = np.zeros((total, 8), dtype=np.uint8)
+        pick = rng.integers(0, 5 if rng.random() < 0.5 else 4, size=(total, rows))
+        for s in range(5):
+            c[:, s] = (pick == s).sum(axis=1)
+        return c
+    A = [cols_random(x) for x in la]
+    B = []
+    for k, x in enumerate(lb):
+        if related and la[k] > 0 and x > 0:  # B = A resampled to lb columns with some columns replaced
+            idx = np.minimum((np.arange(x) * la[k]) // x, la[k] - 1)
+            b = A[k][idx].copy()
+            noise = rng.random(x) < 0.1
+            b[noise] = cols_random(int(noise.sum()))
+            B.append(b)
+        else:
+            B.append(cols_random(x))
+    cat = lambda parts: np.concatenate(parts) if sum(len(p) for p in parts) else np.zeros((0, 8), np.uint8)
+    inputs = dp.DpInputs(cat(A), np.concatenate([[0], np.cumsum(la)]).astype(np.int64), cat(B), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+    p = dp.make_params(rows, rows)
+    if rng.random() < 0.5:
+        hi = max(1, min(6, 127 // rows)) if rng.random() < 0.5 else 6
+        for k in range(25):
+            p.sub[k] = int(rng.integers(-hi, hi + 1))
+        p.gap_open = int(rng.integers(0, 30)) * rows
+        p.gap_extend = int(rng.integers(0, 5)) * rows
+    return inputs, p, rows, la, lb
+
+
+t_end = time.time() + budget
+cases = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    inputs, p, rows, la, lb = random_case(rng)
+    env = {k: str(rng.choice([x for x in v if x is not None] + [""] * sum(x is None for x in v))) for k, v in KNOBS.items()}
+    env = {k: v for k, v in env.items() if v}
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        b = dp.DpBatch(inputs, p)
+    except Exception as exc:  # refused batches (score bound) are fine
+        print("seed", seed, "refused:", str(exc)[:80], flush=True)
+        seed += 1
+        continue
+    b.run(True)
+    scores, ops, n_ops = b.fetch()
+    paths = b.paths(ops, n_ops)
+    v = b.variant()
+    b.close()
+    o_scores, o_paths = pyoracle.dp_align(inputs, p)
+    ok = np.array_equal(scores, o_scores) and all(np.array_equal(x, y) for x, y in zip(paths, o_paths))
+    print("seed", seed, "pairs", len(la), "rows", rows, "max", max(la + [0]), "x", max(lb + [0]), env, "ckpt" if v["checkpoints"] else "bits", "cols", v["cols_per_lane"],
+          "OK" if ok else "MISMATCH", flush=True)
+    if not ok:
+        bad = [k for k in range(len(la)) if scores[k] != o_scores[k] or not np.array_equal(paths[k], o_paths[k])]
+        print("  first bad pairs", bad[:5], "la/lb", [(la[k], lb[k]) for k in bad[:5]], flush=True)
+        sys.exit(1)
+    cases += 1
+    seed += 1
+print("cases", cases, "all equal the oracle")
