@@ -49,7 +49,7 @@ extern "C" {
 #define PM_ST_ASSERT_SUB_LENGTHS 5       /* assert(...length() == ...), m_translate.cc:550-551 */
 #define PM_ST_ALREADY_UNNEXT 6           /* Already_unnext_gap, m_translate.cc:74 */
 #define PM_ST_STEP_LIMIT 7               /* merge did not terminate within its step budget */
-#define PM_ST_OFFSET_ORDER 8             /* builder gaps not in writer order: result would differ, so refuse */
+#define PM_ST_OFFSET_ORDER 8             /* reserved: no longer produced (such units are merged as the reference's writer does) */
 #define PM_ST_MALFORMED_INPUT 9          /* unit touches a row / entry whose gap list is not ascending+disjoint */
 #define PM_ST_TEXT_RANGE 10              /* untranslate: String.sub / expand_text index outside a row's text (Invalid_argument) */
 

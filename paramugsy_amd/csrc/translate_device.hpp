@@ -372,9 +372,13 @@ struct PairCursorT {
 };
 
 // Output side of one unit.  COUNT pass: sizes only.  EMIT pass: writes into the unit's exact slot.
-// The builder's two gap lists are never stored: each gap is turned into its signed offsets the moment it is
+// The builder's two gap lists are normally not stored: each gap is turned into its signed offsets the moment it is
 // added, which equals deltas_of_gaps (m_delta_stream_writer.hh:14-53) as long as gaps arrive in that merge's
-// order; the order is checked per gap and a violation ends the unit in PM_ST_OFFSET_ORDER.
+// order.  The COUNT pass checks the order per gap (the counts do not depend on it) and marks a unit whose gaps ever
+// arrive otherwise (`disorder`: only tables that contradict themselves, or a delta entry with a column gapped in both
+// rows, get there).  Such units are emitted a second time by the FIX pass (`fix` != nullptr): the open segment's gaps
+// are recorded in arrival order in a scratch list and commit() writes the writer's own two-list merge of them -- heads
+// compared by start, ties to the query list -- over what the EMIT pass wrote.
 template <bool EMIT, typename I = i64>
 struct Sink {
   I n_ent;     // committed entries
@@ -388,9 +392,12 @@ struct Sink {
   i64 off_base;  // EMIT: this unit's first offset index
   I off_cap;     // EMIT: this unit's offset count (exact, from the COUNT pass)
   I ent_cap;
+  int disorder;  // COUNT: a gap arrived out of the writer's merge order
+  i64 *fix;      // FIX pass: the open segment's gaps in arrival order, two words each {start << 1 | row, end}; else nullptr
+  I fix_n;
 
   PM_HD __forceinline__ void put(I v) {
-    if(EMIT) {
+    if(EMIT && !fix) {
       I at = n_off + pend;
       if(at < off_cap) { // offsets of a segment that is later dropped may run past the exact slot
         off[off_base + at] = v;
@@ -399,16 +406,20 @@ struct Sink {
     ++pend;
   }
   PM_HD __forceinline__ int gap(int row, R2T<I> g) {
-    int st = PM_ST_OK;
-    if(pend > 0 && (g.s < last_start || (g.s == last_start && last_row == 0 && row == 1))) {
-      st = PM_ST_OFFSET_ORDER;
+    if(!EMIT && pend > 0 && (g.s < last_start || (g.s == last_start && last_row == 0 && row == 1))) {
+      disorder = 1;
+    }
+    if(EMIT && fix) {
+      fix[2 * (i64)fix_n] = (i64)g.s * 2 + row;
+      fix[2 * (i64)fix_n + 1] = (i64)g.e;
+      ++fix_n;
     }
     I sign = row ? 1 : -1;
     put(sign * (g.s - wpos));
     // the gap's remaining columns are +-1 each (_push_ones, m_delta_stream_writer.hh:6-11).  Counted
     // arithmetically and written only inside the unit's slot, so a nonsensical gap length cannot stall a lane.
     I ones = rlen(g) - 1;
-    if(EMIT) {
+    if(EMIT && !fix) {
       I at = n_off + pend;
       I room = off_cap - at;
       I n = ones < room ? ones : room;
@@ -420,13 +431,53 @@ struct Sink {
     wpos = g.e;
     last_start = g.s;
     last_row = row;
-    return st;
+    return PM_ST_OK;
   }
   PM_HD __forceinline__ void drop() {
     pend = 0;
     wpos = 0;
+    fix_n = 0;
+  }
+  // FIX pass: deltas_of_gaps over the recorded gaps (m_delta_stream_writer.hh:14-53): two cursors, one per row, each taking
+  // its row's gaps in arrival order; the smaller start goes first, ties to the query row
+  PM_HD __forceinline__ void fix_write(I &at, I v) {
+    if(at < off_cap) {
+      off[off_base + at] = v;
+    }
+    ++at;
+  }
+  PM_HD __forceinline__ I fix_next(I from, int row) const {
+    while(from < fix_n && (int)(fix[2 * (i64)from] & 1) != row) {
+      ++from;
+    }
+    return from;
+  }
+  PM_HD __forceinline__ void fix_merge() {
+    I r = fix_next(0, 0), q = fix_next(0, 1), at = n_off;
+    i64 column = 0;
+    while(r < fix_n || q < fix_n) {
+      const bool take_ref = r < fix_n && (q >= fix_n || (fix[2 * (i64)r] >> 1) < (fix[2 * (i64)q] >> 1));
+      const I k = take_ref ? r : q;
+      const i64 gs = fix[2 * (i64)k] >> 1, ge = fix[2 * (i64)k + 1];
+      const I sign = take_ref ? -1 : 1;
+      fix_write(at, (I)(sign * (gs - column)));
+      for(i64 n = ge - gs; n > 0; --n) {
+        fix_write(at, sign);
+      }
+      column = ge;
+      if(take_ref) {
+        r = fix_next(r + 1, 0);
+      }
+      else {
+        q = fix_next(q + 1, 1);
+      }
+    }
+    fix_write(at, 0);
   }
   PM_HD __forceinline__ void commit(R2T<I> ref, R2T<I> qry) {
+    if(EMIT && fix) {
+      fix_merge();
+    }
     put(0);
     if(EMIT) {
       if(n_ent < ent_cap) {

@@ -205,7 +205,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                  const int *live_units, const int *live_pos, int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off,
                  const i64 *off_off, pm_entry_t *entries, i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow, void *states,
-                 int *narrow_trip) {
+                 int *narrow_trip, int *slow_flag, const int *slow_units, i64 n_slow, i64 *scratch, const i64 *slow_scratch_off) {
+  // slow_flag (COUNT): set for a unit whose gaps arrive out of the writer's merge order (Sink, translate_device.hpp).
+  // slow_units (EMIT only; the FIX pass): the launch covers just those units, one lane each, with a scratch list for the open
+  // segment's gaps at scratch + slow_scratch_off[lane]; it rewrites the offsets the EMIT pass wrote for them.
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(EMIT) {
     if(ent_off[n_units] > ent_cap || off_off[n_units] > off_cap) { // uniform: buffers sized by an older run
@@ -216,10 +219,22 @@ translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, cons
     }
   }
   const i64 n_live = live_pos[n_units];
-  if(k >= n_live) { // the grid covers all units; only the live ones (compacted by the filter pass) have a lane
-    return;
+  i64 *fix = nullptr;
+  i64 u;
+  if(EMIT && slow_units) {
+    if(k >= n_slow) {
+      return;
+    }
+    fix = scratch + slow_scratch_off[k];
+    u = slow_units[k];
+    k = live_pos[u]; // the unit's place among the live ones: where the count pass left its merge start
   }
-  const i64 u = live_units[k];
+  else {
+    if(k >= n_live) { // the grid covers all units; only the live ones (compacted by the filter pass) have a lane
+      return;
+    }
+    u = live_units[k];
+  }
   if(EMIT) {
     if(ent_off[u + 1] == ent_off[u] && off_off[u + 1] == off_off[u]) {
       return; // the count pass found nothing to write for this unit (most left x right pairs of an entry)
@@ -231,6 +246,9 @@ translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, cons
   sink.ent = nullptr;
   sink.off = nullptr;
   sink.off_base = sink.off_cap = sink.ent_cap = 0;
+  sink.disorder = 0;
+  sink.fix = fix;
+  sink.fix_n = 0;
   if(EMIT) {
     sink.ent = entries + ent_off[u];
     sink.ent_cap = (I)(ent_off[u + 1] - ent_off[u]);
@@ -274,6 +292,10 @@ translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, cons
     status[u] = st;
     cnt_ent[u] = sink.n_ent;
     cnt_off[u] = sink.n_off;
+    if(sink.disorder && slow_flag) {
+      slow_flag[u] = 1;
+      slow_flag[n_units] = 1; // "the job has such units"
+    }
   }
 }
 
@@ -502,6 +524,9 @@ struct pm_job {
   DevBuf live_flag, live_pos, live_units, scan_tmp32;
   DevBuf states; // UnitState per live unit (null during the sizing pass of pm_job_create)
   DevBuf maxabs, narrow_trip;
+  // units whose gaps arrive out of the writer's order (Sink): found by the sizing pass, emitted again by the FIX pass
+  DevBuf slow_flag, slow_units, slow_scratch_off, slow_scratch;
+  i64 n_slow = 0;
   bool narrow = false; // the job runs on the int tables (every table value below PM_NARROW_INPUT_LIMIT, no PM_ST_NARROW seen)
   size_t scan_tmp32_bytes = 0;
   size_t scan_tmp_bytes = 0;
@@ -551,7 +576,7 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
 #define PM_COUNT_ARGS                                                                                                              \
   U, (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,                 \
       (const int *)j->live_pos.p, (int *)j->status.p, (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, \
-      0, 0, nullptr, j->states.p, (int *)j->narrow_trip.p
+      0, 0, nullptr, j->states.p, (int *)j->narrow_trip.p, (int *)j->slow_flag.p, nullptr, 0, nullptr, nullptr
     if(j->narrow) {
       translate_kernel<false, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_COUNT_ARGS);
     }
@@ -580,15 +605,31 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   U, (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,                \
       (const int *)j->live_pos.p, nullptr, nullptr, nullptr, (const i64 *)j->ent_off.p, (const i64 *)j->off_off.p,                 \
       (pm_entry_t *)j->entries.p, (i64 *)j->offsets.p, j->ent_cap, j->off_cap, (int *)j->overflow.p, j->states.p,                  \
-      (int *)j->narrow_trip.p
+      (int *)j->narrow_trip.p, nullptr
     if(j->narrow) {
-      translate_kernel<true, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS);
+      translate_kernel<true, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS, nullptr, 0,
+                                                             nullptr, nullptr);
     }
     else {
-      translate_kernel<true, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS);
+      translate_kernel<true, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS, nullptr, 0, nullptr,
+                                                             nullptr);
+    }
+    PM_HIP(hipGetLastError());
+    if(j->n_slow > 0) { // the FIX pass: the few units whose offsets are not what on-the-fly emission gives
+      const unsigned fblocks = (unsigned)((j->n_slow + 63) / 64);
+      if(j->narrow) {
+        translate_kernel<true, int><<<fblocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS,
+                                                                (const int *)j->slow_units.p, j->n_slow, (i64 *)j->slow_scratch.p,
+                                                                (const i64 *)j->slow_scratch_off.p);
+      }
+      else {
+        translate_kernel<true, i64><<<fblocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS,
+                                                                (const int *)j->slow_units.p, j->n_slow, (i64 *)j->slow_scratch.p,
+                                                                (const i64 *)j->slow_scratch_off.p);
+      }
+      PM_HIP(hipGetLastError());
     }
 #undef PM_EMIT_ARGS
-    PM_HIP(hipGetLastError());
   }
   if(ev) {
     PM_HIP(hipEventRecord(ev[4], stream));
@@ -666,6 +707,11 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   JTRY(j->live_flag.alloc((size_t)(U + 1) * 4));
   JTRY(j->live_pos.alloc((size_t)(U + 1) * 4));
   JTRY(j->live_units.alloc((size_t)(U + 1) * 4));
+  JTRY(j->slow_flag.alloc((size_t)(U + 1) * 4));
+  if(hipMemsetAsync(j->slow_flag.p, 0, (size_t)(U + 1) * 4, stream) != hipSuccess) {
+    pm_job_destroy(j);
+    return fail(PM_E_HIP, "hipMemsetAsync failed");
+  }
   if(hipMemsetAsync(j->live_flag.p, 0, (size_t)(U + 1) * 4, stream) != hipSuccess) {
     pm_job_destroy(j);
     return fail(PM_E_HIP, "hipMemsetAsync failed");
@@ -725,6 +771,46 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   }
   j->ent_cap = j->n_entries;
   j->off_cap = j->n_offsets;
+  // units for the FIX pass (none unless the tables contradict themselves): their list, and room for the gaps of a segment --
+  // a gap owns at least one of the unit's offsets, so twice the unit's offset count in words is always enough
+  {
+    int any = 0;
+    if(hipMemcpy(&any, (int *)j->slow_flag.p + U, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      pm_job_destroy(j);
+      return fail(PM_E_HIP, "hipMemcpy failed");
+    }
+    if(any) {
+      std::vector<int> flag((size_t)U);
+      std::vector<i64> cnt((size_t)U);
+      if(hipMemcpy(flag.data(), j->slow_flag.p, (size_t)U * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+         hipMemcpy(cnt.data(), j->cnt_off.p, (size_t)U * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        pm_job_destroy(j);
+        return fail(PM_E_HIP, "hipMemcpy failed");
+      }
+      std::vector<int> list;
+      std::vector<i64> at;
+      i64 words = 0;
+      for(i64 u = 0; u < U; ++u) {
+        if(flag[(size_t)u]) {
+          list.push_back((int)u);
+          at.push_back(words);
+          words += 2 * cnt[(size_t)u] + 2;
+        }
+      }
+      if(words > ((i64)1 << 28)) { // 2 GiB of scratch: not a job anyone means
+        pm_job_destroy(j);
+        return fail(PM_E_INVALID, "pm_job_create: implausible output size (inconsistent input tables)");
+      }
+      j->n_slow = (i64)list.size();
+      JTRY(j->slow_units.upload(list.data(), list.size() * 4, stream));
+      JTRY(j->slow_scratch_off.upload(at.data(), at.size() * 8, stream));
+      JTRY(j->slow_scratch.alloc((size_t)(words > 0 ? words : 1) * 8));
+      if(hipStreamSynchronize(stream) != hipSuccess) { // the uploads read these vectors
+        pm_job_destroy(j);
+        return fail(PM_E_HIP, "hipStreamSynchronize failed");
+      }
+    }
+  }
   {
     int n_live = 0;
     if(hipMemcpy(&n_live, (int *)j->live_pos.p + U, 4, hipMemcpyDeviceToHost) != hipSuccess) {

@@ -153,11 +153,12 @@ def test_failure_classes_equal_oracle(seed, oracle_build, tmp_path):
     assert not res.all_ok and (res.status != 0).sum() >= 3
 
 
-def test_column_gapped_in_both_rows_is_refused(oracle_build):
+def test_column_gapped_in_both_rows_prints_what_the_reference_prints(oracle_build):
     """A delta entry with the same column gapped in its reference row AND its query row cannot come out of a
-    delta file (m_delta.cc:50-68 hands out columns once) and makes the reference's writer emit a stray 0.
-    The builder's gaps then arrive out of the writer's merge order; the library refuses the unit
-    (PM_ST_OFFSET_ORDER) instead of printing something else."""
+    delta file (m_delta.cc:50-68 hands out columns once) and makes the reference's writer emit a stray 0 (its two-list merge
+    takes the query gap first and then finds the reference gap at distance 0).  The builder's gaps arrive out of the writer's
+    merge order here; the FIX pass merges them as the writer does, stray 0 included."""
+    import pyoracle
     from paramugsy_amd.translate import Tables
     i64 = lambda *v: np.array(v, dtype=np.int64)
     left = {"start": i64(1), "end": i64(100), "length": i64(100), "gap_off": i64(0, 0), "gap_start": i64(), "gap_end": i64()}
@@ -166,10 +167,46 @@ def test_column_gapped_in_both_rows_is_refused(oracle_build):
               "ref_gap_off": i64(0, 1), "ref_gap_start": i64(50), "ref_gap_end": i64(50),
               "qry_gap_off": i64(0, 1), "qry_gap_start": i64(50), "qry_gap_end": i64(50)}
     z = np.zeros(1, dtype=np.int32)
-    job = TranslateJob(Tables(left, right, deltas, {"delta": z, "left": z, "right": z}))
+    t = Tables(left, right, deltas, {"delta": z, "left": z, "right": z})
+    job = TranslateJob(t)
     job.run()
     res = job.fetch()
-    assert res.status.tolist() == [capi.PM_ST_OFFSET_ORDER]
+    assert_same_result(res, pyoracle.translate_units(t.left, t.right, t.deltas, t.units))
+    assert res.status.tolist() == [0] and 0 in res.offsets[:-1].tolist()
+    job.close()
+
+
+@pytest.mark.parametrize("seed,mode", [(33, "typical"), (188, "reverse"), (208, "typical"), (219, "gappy"), (298, "reverse")])
+def test_gaps_out_of_the_writers_order_are_merged_as_the_writer_does(seed, mode, oracle_build, tmp_path):
+    """Inconsistent tables whose units hand the builder gaps in another order than the writer's merge takes them (seeds found by
+    tools/translate_fuzz.py; the library used to refuse such units): equal to the oracle, unit by unit, on both table widths."""
+    import pyoracle
+    rng = np.random.default_rng(seed)
+    kw = dict(MODES[mode])
+    assert sorted(MODES)[int(rng.integers(0, len(MODES)))] == mode  # the same draws as the fuzz tool makes for this seed
+    for key, lo, hi in (("gap_rate", 0.0, 0.15), ("indel_rate", 0.0, 0.08), ("rev_prob", 0.0, 0.6), ("delta_rev_prob", 0.0, 0.6),
+                        ("edge_gap_prob", 0.0, 0.6), ("adjacent_prob", 0.0, 0.2)):
+        if rng.random() < 0.5:
+            kw[key] = float(rng.uniform(lo, hi))
+    if mode != "long_rows" and rng.random() < 0.5:
+        kw["entries_per_delta"] = int(rng.integers(5, 200))
+    w = synth.make_workload(str(tmp_path / "job"), seed, **kw)
+    t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+    if rng.random() < 0.5:
+        corrupt_tables(t, rng)
+    ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
+    for wide in ("0", "1"):
+        os.environ["PM_TRANSLATE_WIDE"] = wide
+        try:
+            job = TranslateJob(t)
+        finally:
+            del os.environ["PM_TRANSLATE_WIDE"]
+        job.run()
+        res = job.fetch()
+        assert_same_result(res, ora)
+        job.run()  # and again: the FIX pass rewrites what the EMIT pass wrote, every pass
+        assert_same_result(job.fetch(), ora)
+        job.close()
 
 
 def test_malformed_gap_lists_are_refused_not_miscomputed(tmp_path):

@@ -147,12 +147,14 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
   RowsT<I> lv = L.view(), rv = R.view();
   i64 U = units->n;
   std::vector<i64> cnt_e(U + 1, 0), cnt_o(U + 1, 0);
+  std::vector<char> disorder(U + 1, 0);
   for(i64 u = 0; u < U; ++u) { // COUNT pass
     Sink<false, I> sink;
     memset(&sink, 0, sizeof sink);
     status[u] = run_unit<false>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], sink);
     cnt_e[u] = sink.n_ent;
     cnt_o[u] = sink.n_off;
+    disorder[u] = (char)sink.disorder;
   }
   std::vector<i64> eo(U + 1, 0), oo(U + 1, 0);
   for(i64 u = 0; u < U; ++u) {
@@ -176,6 +178,21 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
     int st = run_unit<true>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], sink);
     if(st != status[u]) {
       return 2; // the two passes must agree
+    }
+    if(disorder[u]) { // the FIX pass of the library: the same unit again, its segments' gaps recorded and merged at commit
+      std::vector<i64> scratch((size_t)(2 * (oo[u + 1] - oo[u]) + 2), 0);
+      Sink<true, I> fx;
+      memset(&fx, 0, sizeof fx);
+      fx.ent = entries + eo[u];
+      fx.ent_cap = (I)(eo[u + 1] - eo[u]);
+      fx.off = (i64 *)offsets;
+      fx.off_base = oo[u];
+      fx.off_cap = (I)(oo[u + 1] - oo[u]);
+      fx.fix = scratch.data();
+      st = run_unit<true>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], fx);
+      if(st != status[u]) {
+        return 2;
+      }
     }
   }
   return 0;

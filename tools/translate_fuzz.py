@@ -22,7 +22,7 @@ from test_translate_gpu import MODES, corrupt_tables  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
-cases = units = failed_units = refused_total = 0
+cases = units = failed_units = 0
 tmp = tempfile.mkdtemp(prefix="trfuzz")
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
@@ -46,18 +46,11 @@ while time.time() < t_end:
     res = job.fetch()
     job.close()
     ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
-    # per unit: same status, same entries, same offsets.  One deviation is by design and only counted: the library emits an
-    # entry's offsets on the fly, which equals the reference writer's two-list merge (m_delta_stream_writer.hh:14-53) only when the
-    # builder's gaps arrive in the writer's order; with inconsistent tables they may not, and the unit is then refused
-    # (PM_ST_OFFSET_ORDER = 8) where the reference prints the merge of whatever it was given.
+    # per unit: same status, same entries, same offsets
     eo_g, eo_o = res.unit_entry_off, ora["unit_entry_off"]
     ok = True
-    refused = 0
     for u in range(t.n_units):
         sg, so = int(res.status[u]), int(ora["status"][u])
-        if sg == 8 and so != 8:
-            refused += 1
-            continue
         ng, no = int(eo_g[u + 1] - eo_g[u]), int(eo_o[u + 1] - eo_o[u])
         same = sg == so and ng == no
         for e in range(ng if same else 0):
@@ -70,16 +63,12 @@ while time.time() < t_end:
             ok = False
             print("  unit", u, "status gpu", sg, "oracle", so, "entries gpu", ng, "oracle", no, flush=True)
             break
-    print("seed", seed, mode, "corrupt" if corrupt else "clean", "units", t.n_units, "failing", int((res.status != 0).sum()), "refused by design", refused,
-          "entries", len(res.entries), "OK" if ok else "MISMATCH", flush=True)
-    if not ok or (refused and not corrupt):
-        print("  (a refusal on consistent tables would be a bug)" if ok else "", flush=True)
+    print("seed", seed, mode, "corrupt" if corrupt else "clean", "units", t.n_units, "failing", int((res.status != 0).sum()), "entries", len(res.entries), "OK" if ok else "MISMATCH", flush=True)
+    if not ok:
         sys.exit(1)
-    refused_total += refused
     cases += 1
     units += t.n_units
     failed_units += int((res.status != 0).sum())
     seed += 1
 shutil.rmtree(tmp, ignore_errors=True)
-print("cases", cases, "units", units, "of which failing as in the reference", failed_units - refused_total, "and refused by design (PM_ST_OFFSET_ORDER)",
-      refused_total, ": everything else equals the oracle")
+print("cases", cases, "units", units, "of which failing (with the reference's failure class)", failed_units, ": every unit equals the oracle")
