@@ -21,9 +21,10 @@ KNOBS = {"PM_DP_MODE": ["ckpt", "ckpt", "bits", None], "PM_DP_COLS": ["8", "16",
 
 
 def random_case(rng):
-    rows = int(rng.choice([1, 2, 3, 4, 8, 13, 32, 60]))
+    extreme = rng.random() < 0.2  # deep columns and large weights, near the int16 / score-bound limits of pm_dp_batch_create
+    rows = int(rng.choice([100, 127, 128, 200, 255])) if extreme else int(rng.choice([1, 2, 3, 4, 8, 13, 32, 60]))
     n = int(rng.choice([1, 2, 3, 7, 20, 40]))
-    longest = int(rng.choice([40, 300, 1100, 2500, 5000]))
+    longest = int(rng.choice([10, 60, 250])) if extreme else int(rng.choice([40, 300, 1100, 2500, 5000]))
     cells_left = 6e6
     la, lb = [], []
     for _ in range(n):
@@ -58,7 +59,13 @@ def random_case(rng):
     cat = lambda parts: np.concatenate(parts) if sum(len(p) for p in parts) else np.zeros((0, 8), np.uint8)
     inputs = dp.DpInputs(cat(A), np.concatenate([[0], np.cumsum(la)]).astype(np.int64), cat(B), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
     p = dp.make_params(rows, rows)
-    if rng.random() < 0.5:
+    if extreme:
+        hi = int(rng.choice([1, 3, 20, 32767 // rows]))
+        for k in range(25):
+            p.sub[k] = int(rng.integers(-hi, hi + 1))
+        p.gap_open = int(rng.integers(0, 32767))
+        p.gap_extend = int(rng.integers(0, min(p.gap_open, 2000) + 1))
+    elif rng.random() < 0.5:
         hi = max(1, min(6, 127 // rows)) if rng.random() < 0.5 else 6
         for k in range(25):
             p.sub[k] = int(rng.integers(-hi, hi + 1))
