@@ -45,10 +45,32 @@ while time.time() < t_end:
                 kw[key] = float(rng.uniform(lo, hi))
         if mode != "long_rows" and rng.random() < 0.5:
             kw["entries_per_delta"] = int(rng.integers(5, 200))
+        if rng.random() < 0.4:  # everything random: genome and block counts, block width, entry length, spacing, file count
+            glen = int(rng.choice([2000, 30000, 300000]))
+            kw = dict(n_left=int(rng.integers(1, 6)), n_right=int(rng.integers(1, 6)), genome_len=glen, n_blocks=int(rng.integers(1, 120)),
+                      n_deltas=int(rng.integers(1, 5)), entries_per_delta=int(rng.integers(1, 300)), mean_cols=int(rng.choice([5, 40, 400, 3000])),
+                      gap_rate=float(rng.choice([0.001, 0.01, 0.1])), mean_gap=float(rng.choice([1.5, 3.0, 12.0])), row_prob=float(rng.choice([0.5, 0.8, 1.0])),
+                      rev_prob=float(rng.choice([0.0, 0.3, 1.0])), edge_gap_prob=float(rng.choice([0.0, 0.3, 0.9])), spacing=int(rng.choice([1, 5, 40, 400])),
+                      mean_len=int(rng.choice([30, 300, 3000])), indel_rate=float(rng.choice([0.001, 0.01, 0.08])), mean_indel=float(rng.choice([1.5, 4.0, 15.0])),
+                      adjacent_prob=float(rng.choice([0.0, 0.1, 0.4])), delta_rev_prob=float(rng.choice([0.0, 0.3, 1.0])), group=int(rng.integers(1, 5)))
+            mode = "wild"
         w = synth.make_workload(os.path.join(d, "job"), seed, **kw)
         rc = subprocess.run([os.path.join(REF, "m_translate"), w.left_dir, w.right_dir, w.list_path, a], capture_output=True).returncode
-        translate(w.left_dir, w.right_dir, w.delta_paths, b)
+        try:
+            translate(w.left_dir, w.right_dir, w.delta_paths, b)
+            failed = False
+        except capi.PmError:
+            failed = True
         what = mode
+        if rc != 0 or failed:  # input the reference dies on (the generator can write a delta file it cannot parse): the library must fail too
+            print("seed", seed, kind, what, "reference exit", rc, "library", "fails" if failed else "succeeds", "AGREE" if (rc != 0) == failed else "DISAGREE",
+                  flush=True)
+            if (rc != 0) != failed:
+                shutil.copytree(d, os.path.join(ROOT, "gpurun_out", "ref_fuzz_seed%d" % seed), dirs_exist_ok=True)
+                sys.exit(1)
+            count["both fail"] = count.get("both fail", 0) + 1
+            seed += 1
+            continue
     elif kind == "sort":
         names_r = [["b", "a", "c", "ab"], ["r1"], ["x.1", "x.10", "x.2"]][int(rng.integers(0, 3))]
         names_q = [["y", "x"], ["q"], ["k2", "k1", "k3"]][int(rng.integers(0, 3))]
