@@ -84,20 +84,32 @@ while time.time() < t_end:
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
+    streamed = rng.random() < 0.25 and inputs.n_pairs > 0  # through the host-fed engine (upload segments, variant re-check)
     try:
-        b = dp.DpBatch(inputs, p)
+        if streamed:
+            st = dp.DpStream(p, segments=int(rng.integers(1, 7)))
+            try:
+                scores, ops, n_ops = st.align(inputs)
+            finally:
+                st.close()
+            paths = dp.paths_of(inputs, ops, n_ops)
+            v = {"checkpoints": "?", "cols_per_lane": "?"}
+        else:
+            b = dp.DpBatch(inputs, p)
+            b.run(True)
+            scores, ops, n_ops = b.fetch()
+            paths = b.paths(ops, n_ops)
+            v = b.variant()
+            b.close()
     except Exception as exc:  # refused batches (score bound) are fine
         print("seed", seed, "refused:", str(exc)[:80], flush=True)
         seed += 1
         continue
-    b.run(True)
-    scores, ops, n_ops = b.fetch()
-    paths = b.paths(ops, n_ops)
-    v = b.variant()
-    b.close()
+    if streamed:
+        env = dict(env, engine="stream")
     o_scores, o_paths = pyoracle.dp_align(inputs, p)
     ok = np.array_equal(scores, o_scores) and all(np.array_equal(x, y) for x, y in zip(paths, o_paths))
-    print("seed", seed, "pairs", len(la), "rows", rows, "max", max(la + [0]), "x", max(lb + [0]), env, "ckpt" if v["checkpoints"] else "bits", "cols", v["cols_per_lane"],
+    print("seed", seed, "pairs", len(la), "rows", rows, "max", max(la + [0]), "x", max(lb + [0]), env, ("ckpt" if v["checkpoints"] else "bits") if v["checkpoints"] != "?" else "-", "cols", v["cols_per_lane"],
           "OK" if ok else "MISMATCH", flush=True)
     if not ok:
         bad = [k for k in range(len(la)) if scores[k] != o_scores[k] or not np.array_equal(paths[k], o_paths[k])]
