@@ -233,9 +233,9 @@ int pm_dp_batch_chunks(pm_dp_batch_t *batch, int64_t *first_position, int32_t ca
 int pm_dp_batch_variant(pm_dp_batch_t *batch, int32_t *cols_per_lane, int32_t *dot4, int32_t *valu_ops_per_cell);
 /* How the batch gets its paths: checkpoints != 0 -> the fill kernel computes scores only and leaves row/column checkpoints,
  * and the walk re-runs the recurrence inside the block_rows x block_columns blocks the path crosses (the default);
- * checkpoints == 0 -> the fill kernel stores 4 decision bits per cell.  Same results; chosen per batch (a small batch is
- * better off storing the bits: the walk's chain of blocks has a latency that does not shrink with the batch), or fixed by the
- * environment PM_DP_MODE=bits|ckpt. */
+ * checkpoints == 0 -> the fill kernel stores 4 decision bits per cell.  Same results; chosen per batch (a batch of a few short
+ * pairs is better off storing the bits: the walk's chain of blocks and its extra launch have a latency that does not shrink
+ * with the batch), or fixed by the environment PM_DP_MODE=bits|ckpt. */
 int pm_dp_batch_path_mode(pm_dp_batch_t *batch, int32_t *checkpoints, int32_t *block_rows, int32_t *block_columns);
 void pm_dp_batch_destroy(pm_dp_batch_t *batch);
 
