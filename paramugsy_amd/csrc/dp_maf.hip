@@ -15,9 +15,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -158,10 +160,17 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
     return fail(PM_E_IO, "cannot open " + path);
   }
   std::string text;
-  char buf[1 << 16];
-  size_t n;
-  while((n = fread(buf, 1, sizeof buf, f)) > 0) {
-    text.append(buf, n);
+  {
+    long size = 0;
+    if(fseek(f, 0, SEEK_END) == 0 && (size = ftell(f)) > 0 && fseek(f, 0, SEEK_SET) == 0) {
+      text.resize((size_t)size);
+      text.resize(fread(&text[0], 1, (size_t)size, f));
+    }
+    char buf[1 << 16]; // whatever a non-seekable source still holds
+    size_t n;
+    while((n = fread(buf, 1, sizeof buf, f)) > 0) {
+      text.append(buf, n);
+    }
   }
   fclose(f);
   out.block_row.clear();
@@ -198,6 +207,12 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
         if(fields == 7) {
           text_at = q;
         }
+        if(fields >= 7) { // the sequence text: long, and blanks in it are rare -- find them with memchr
+          const char *b0 = (const char *)memchr(&text[q], ' ', le - q), *b1 = (const char *)memchr(&text[q], '\t', le - q);
+          const char *stop = b0 && b1 ? (b0 < b1 ? b0 : b1) : (b0 ? b0 : b1);
+          q = stop ? (size_t)(stop - text.data()) : le;
+          continue;
+        }
         while(q < le && text[q] != ' ' && text[q] != '\t') {
           ++q;
         }
@@ -216,7 +231,7 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
         ++te;
       }
       r.text.assign(text, text_at, te - text_at);
-      out.rows.push_back(r);
+      out.rows.push_back(std::move(r));
     }
     p = e + 1;
   }
@@ -361,23 +376,58 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
     return fail(PM_E_INVALID, "pm_dp_align_maf: null argument");
   }
   PM_TRY(use_device(device));
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now();
+  auto lap = [&](const char *what) {
+    if(timing) {
+      const double t1 = now();
+      fprintf(stderr, "pm_dp_align_maf: %-28s %.3f s\n", what, t1 - t0);
+      t0 = t1;
+    }
+  };
   MafDpBlocks A, B;
-  PM_TRY(parse_maf_blocks(maf_a, A));
-  PM_TRY(parse_maf_blocks(maf_b, B));
+  {
+    // the two files are parsed side by side; each parser reports through its own return value (pm_last_error is per thread)
+    int rc_b = PM_OK;
+    std::string err_b;
+    std::thread other([&]() {
+      rc_b = parse_maf_blocks(maf_b, B);
+      if(rc_b) {
+        err_b = pm_last_error();
+      }
+    });
+    const int rc_a = parse_maf_blocks(maf_a, A);
+    other.join();
+    if(rc_a) {
+      return rc_a;
+    }
+    if(rc_b) {
+      return fail(rc_b, err_b);
+    }
+  }
   const int64_t n = (int64_t)A.block_row.size() - 1;
   if(n != (int64_t)B.block_row.size() - 1) {
     return fail(PM_E_INVALID, "pm_dp_align_maf: the two MAF files must hold the same number of blocks (pair k = block k of each)");
   }
+  lap("parse (two threads)");
   std::string ta, tb;
   std::vector<int64_t> roa, rob;
   flatten(A, ta, roa);
   flatten(B, tb, rob);
+  lap("flatten");
+  // a block has as many columns as its first row has bytes: the sizes need no pass of their own
   std::vector<int64_t> coa((size_t)n + 1), cob((size_t)n + 1);
-  PM_TRY(pm_dp_pack_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), n, nullptr, coa.data(), device));
-  PM_TRY(pm_dp_pack_maf((const uint8_t *)tb.data(), rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, nullptr, cob.data(), device));
-  std::vector<uint8_t> ca((size_t)coa[n] * 8 + 8), cb((size_t)cob[n] * 8 + 8);
+  int64_t total_a = 0, total_b = 0;
+  for(int64_t k = 0; k < n; ++k) {
+    const int64_t ra = A.block_row[(size_t)k], rb = B.block_row[(size_t)k];
+    total_a += ra < A.block_row[(size_t)k + 1] ? roa[(size_t)ra + 1] - roa[(size_t)ra] : 0;
+    total_b += rb < B.block_row[(size_t)k + 1] ? rob[(size_t)rb + 1] - rob[(size_t)rb] : 0;
+  }
+  std::vector<uint8_t> ca((size_t)total_a * 8 + 8), cb((size_t)total_b * 8 + 8);
   PM_TRY(pm_dp_pack_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), n, ca.data(), coa.data(), device));
   PM_TRY(pm_dp_pack_maf((const uint8_t *)tb.data(), rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, cb.data(), cob.data(), device));
+  lap("pack (device)");
   pm_dp_batch_t *batch = nullptr;
   PM_TRY(pm_dp_batch_create(ca.data(), coa.data(), cb.data(), cob.data(), n, params, 0, device, &batch));
   std::vector<int32_t> scores((size_t)n), n_ops((size_t)n);
@@ -388,18 +438,21 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
   }
   pm_dp_batch_destroy(batch);
   PM_TRY(rc);
+  lap("DP: create, run, fetch");
   // pair k's path is the last n_ops[k] bytes of its slot
   std::vector<int64_t> ops_off((size_t)n), out_off((size_t)n + 1);
   for(int64_t k = 0; k < n; ++k) {
     ops_off[(size_t)k] = coa[k + 1] + cob[k + 1] - n_ops[(size_t)k];
   }
-  PM_TRY(pm_dp_emit_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), (const uint8_t *)tb.data(),
-                        rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, ops.data(), ops_off.data(), n_ops.data(), nullptr,
-                        out_off.data(), device));
-  std::vector<uint8_t> merged((size_t)out_off[n] + 1);
+  int64_t merged_bytes = 0; // every row of the merged block is as long as the path
+  for(int64_t k = 0; k < n; ++k) {
+    merged_bytes += (A.block_row[(size_t)k + 1] - A.block_row[(size_t)k] + B.block_row[(size_t)k + 1] - B.block_row[(size_t)k]) * (int64_t)n_ops[(size_t)k];
+  }
+  std::vector<uint8_t> merged((size_t)merged_bytes + 1);
   PM_TRY(pm_dp_emit_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), (const uint8_t *)tb.data(),
                         rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, ops.data(), ops_off.data(), n_ops.data(), merged.data(),
                         out_off.data(), device));
+  lap("emit (device)");
   FILE *f = fopen(out_maf, "wb");
   if(!f) {
     return fail(PM_E_IO, std::string("cannot write ") + out_maf);
@@ -426,5 +479,6 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
   if(fclose(f) != 0) {
     return fail(PM_E_IO, std::string("cannot write ") + out_maf);
   }
+  lap("write");
   return PM_OK;
 }
