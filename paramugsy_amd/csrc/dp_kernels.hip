@@ -608,10 +608,11 @@ int dp_batch_load(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, c
   PM_HIP(hipMemcpyAsync(h->d_off_a.p, src_a, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
   PM_HIP(hipMemcpyAsync(h->d_off_b.p, src_b, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
   if(h->total_a > 0) {
-    PM_HIP(hipMemcpyAsync(h->cols_a.p, cols_a + a0 * 8, (size_t)h->total_a * 8, hipMemcpyHostToDevice, stream));
+    // (hipMemcpyDefault: pm_dp_align_maf hands over columns that are already in device memory)
+    PM_HIP(hipMemcpyAsync(h->cols_a.p, cols_a + a0 * 8, (size_t)h->total_a * 8, hipMemcpyDefault, stream));
   }
   if(h->total_b > 0) {
-    PM_HIP(hipMemcpyAsync(h->cols_b.p, cols_b + b0 * 8, (size_t)h->total_b * 8, hipMemcpyHostToDevice, stream));
+    PM_HIP(hipMemcpyAsync(h->cols_b.p, cols_b + b0 * 8, (size_t)h->total_b * 8, hipMemcpyDefault, stream));
   }
   // the ranges of the uploaded columns, found on the device (four 4-byte words back)
   PM_HIP(hipMemsetAsync(h->stats.p, 0, 32, stream));

@@ -18,12 +18,15 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
 
+#include "dp_batch.hpp"
 #include "dp_internal.hpp"
 #include "pm_internal.hpp"
 
@@ -145,11 +148,12 @@ static int check_blocks(const int64_t *row_off, int64_t n_rows, const int64_t *b
 // One `s` line of a MAF block: the six fields in front of the text verbatim, and the text.
 struct MafDpRow {
   std::string head; // "s name start size strand srcSize"
-  std::string text;
 };
 struct MafDpBlocks {
   std::vector<MafDpRow> rows;
   std::vector<int64_t> block_row; // [n_blocks + 1]
+  std::string text;               // the rows' texts back to back, as pm_dp_pack_maf / pm_dp_emit_maf take them
+  std::vector<int64_t> row_off;   // [n_rows + 1]
 };
 
 // `a` opens a block, `s` lines are its rows, anything else (comments, `##maf`, blank lines, other line types) is skipped:
@@ -175,6 +179,9 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
   fclose(f);
   out.block_row.clear();
   out.rows.clear();
+  out.text.clear();
+  out.text.reserve(text.size());
+  out.row_off.assign(1, 0);
   bool open = false;
   size_t p = 0;
   while(p < text.size()) {
@@ -230,7 +237,8 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
       while(te < le && text[te] != ' ' && text[te] != '\t') {
         ++te;
       }
-      r.text.assign(text, text_at, te - text_at);
+      out.text.append(text, text_at, te - text_at);
+      out.row_off.push_back((int64_t)out.text.size());
       out.rows.push_back(std::move(r));
     }
     p = e + 1;
@@ -239,12 +247,60 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
   return PM_OK;
 }
 
-static void flatten(const MafDpBlocks &b, std::string &text, std::vector<int64_t> &row_off) {
-  row_off.assign(1, 0);
-  for(const MafDpRow &r : b.rows) {
-    text += r.text;
-    row_off.push_back((int64_t)text.size());
+// One side's blocks in device memory: the flat text and its tables, and (after pack()) the packed columns.
+struct MafSideDev {
+  DevBuf text, row_off, block_row, col_off, cols;
+  i64 n_blocks = 0, n_cols = 0;
+  int upload(const uint8_t *t, const int64_t *ro, int64_t n_rows, const int64_t *br, int64_t nb, const int64_t *co) {
+    n_blocks = nb;
+    n_cols = co[nb];
+    PM_TRY(text.upload(t, (size_t)ro[n_rows], nullptr));
+    PM_TRY(row_off.upload(ro, (size_t)(n_rows + 1) * 8, nullptr));
+    PM_TRY(block_row.upload(br, (size_t)(nb + 1) * 8, nullptr));
+    PM_TRY(col_off.upload(co, (size_t)(nb + 1) * 8, nullptr));
+    return PM_OK;
   }
+  int pack() {
+    PM_TRY(cols.alloc((size_t)std::max<i64>(n_cols, 1) * 8));
+    if(n_cols > 0) {
+      dp_pack_kernel<<<(unsigned)((n_cols + 255) / 256), 256>>>(n_cols, n_blocks, (const i64 *)col_off.p, (const i64 *)block_row.p,
+                                                                (const i64 *)row_off.p, (const unsigned char *)text.p, (u64 *)cols.p);
+      PM_HIP(hipGetLastError());
+    }
+    return PM_OK;
+  }
+};
+
+// The merged blocks of n_pairs pairs from texts, tables and paths that are all in device memory (d_ops: ops_end bytes, pair p's
+// path at d_ops_off[p], d_n_ops[p] long; d_out_off: where each pair's text goes) into d_out (n_out bytes, allocated here).
+static int emit_device(const MafSideDev &A, const MafSideDev &B, i64 n_pairs, const unsigned char *d_ops, i64 ops_end, const i64 *d_ops_off,
+                       const int *d_n_ops, const i64 *d_out_off, i64 n_out, DevBuf &d_out, const char *who) {
+  DevBuf d_fa, d_fb, d_pa, d_pb, d_bad, d_tmp;
+  PM_TRY(d_fa.alloc((size_t)ops_end * 4));
+  PM_TRY(d_fb.alloc((size_t)ops_end * 4));
+  PM_TRY(d_pa.alloc((size_t)ops_end * 4));
+  PM_TRY(d_pb.alloc((size_t)ops_end * 4));
+  PM_TRY(d_out.alloc((size_t)n_out));
+  PM_TRY(d_bad.alloc(4));
+  PM_HIP(hipMemset(d_bad.p, 0, 4));
+  dp_op_flags_kernel<<<(unsigned)((ops_end + 255) / 256), 256>>>(ops_end, d_ops, (int *)d_fa.p, (int *)d_fb.p);
+  PM_HIP(hipGetLastError());
+  size_t tmp_bytes = 0;
+  PM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+  PM_TRY(d_tmp.alloc(tmp_bytes));
+  PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+  PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fb.p, (int *)d_pb.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+  dp_emit_kernel<<<(unsigned)((n_out + 255) / 256), 256>>>(n_out, n_pairs, d_out_off, d_ops_off, d_n_ops, d_ops, (const int *)d_pa.p,
+                                                           (const int *)d_pb.p, (const i64 *)A.block_row.p, (const i64 *)A.row_off.p,
+                                                           (const unsigned char *)A.text.p, (const i64 *)B.block_row.p, (const i64 *)B.row_off.p,
+                                                           (const unsigned char *)B.text.p, (unsigned char *)d_out.p, (int *)d_bad.p);
+  PM_HIP(hipGetLastError());
+  int bad = 0;
+  PM_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+  if(bad) {
+    return fail(PM_E_INVALID, std::string(who) + ": an op outside {0, 1, 2} or a path that leaves its block");
+  }
+  return PM_OK;
 }
 
 } // namespace pm
@@ -272,16 +328,10 @@ int pm_dp_pack_maf(const uint8_t *text, const int64_t *row_off, int64_t n_rows, 
   if(!text) {
     return fail(PM_E_INVALID, "pm_dp_pack_maf: null text");
   }
-  DevBuf d_text, d_row_off, d_block_row, d_col_off, d_cols;
-  PM_TRY(d_text.upload(text, (size_t)row_off[n_rows], nullptr));
-  PM_TRY(d_row_off.upload(row_off, (size_t)(n_rows + 1) * 8, nullptr));
-  PM_TRY(d_block_row.upload(block_row, (size_t)(n_blocks + 1) * 8, nullptr));
-  PM_TRY(d_col_off.upload(col_off_out, (size_t)(n_blocks + 1) * 8, nullptr));
-  PM_TRY(d_cols.alloc((size_t)n_cols * 8));
-  dp_pack_kernel<<<(unsigned)((n_cols + 255) / 256), 256>>>(n_cols, n_blocks, (const i64 *)d_col_off.p, (const i64 *)d_block_row.p,
-                                                            (const i64 *)d_row_off.p, (const unsigned char *)d_text.p, (u64 *)d_cols.p);
-  PM_HIP(hipGetLastError());
-  PM_HIP(hipMemcpy(cols_out, d_cols.p, (size_t)n_cols * 8, hipMemcpyDeviceToHost));
+  MafSideDev side;
+  PM_TRY(side.upload(text, row_off, n_rows, block_row, n_blocks, col_off_out));
+  PM_TRY(side.pack());
+  PM_HIP(hipMemcpy(cols_out, side.cols.p, (size_t)n_cols * 8, hipMemcpyDeviceToHost));
   return PM_OK;
 }
 
@@ -329,42 +379,17 @@ int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_ro
       return fail(PM_E_INVALID, "pm_dp_emit_maf: a path does not span its pair of blocks");
     }
   }
-  DevBuf d_ta, d_tb, d_roa, d_rob, d_bra, d_brb, d_ops, d_ops_off, d_n_ops, d_out_off, d_fa, d_fb, d_pa, d_pb, d_out, d_bad, d_tmp;
-  PM_TRY(d_ta.upload(text_a, (size_t)row_off_a[n_rows_a], nullptr));
-  PM_TRY(d_tb.upload(text_b, (size_t)row_off_b[n_rows_b], nullptr));
-  PM_TRY(d_roa.upload(row_off_a, (size_t)(n_rows_a + 1) * 8, nullptr));
-  PM_TRY(d_rob.upload(row_off_b, (size_t)(n_rows_b + 1) * 8, nullptr));
-  PM_TRY(d_bra.upload(block_row_a, (size_t)(n_pairs + 1) * 8, nullptr));
-  PM_TRY(d_brb.upload(block_row_b, (size_t)(n_pairs + 1) * 8, nullptr));
+  MafSideDev A, B;
+  std::vector<int64_t> no_cols_a((size_t)n_pairs + 1, 0), no_cols_b((size_t)n_pairs + 1, 0); // the emit side does not need the column offsets
+  PM_TRY(A.upload(text_a, row_off_a, n_rows_a, block_row_a, n_pairs, no_cols_a.data()));
+  PM_TRY(B.upload(text_b, row_off_b, n_rows_b, block_row_b, n_pairs, no_cols_b.data()));
+  DevBuf d_ops, d_ops_off, d_n_ops, d_out_off, d_out;
   PM_TRY(d_ops.upload(ops, (size_t)ops_end, nullptr));
   PM_TRY(d_ops_off.upload(ops_off, (size_t)n_pairs * 8, nullptr));
   PM_TRY(d_n_ops.upload(n_ops, (size_t)n_pairs * 4, nullptr));
   PM_TRY(d_out_off.upload(out_off, (size_t)(n_pairs + 1) * 8, nullptr));
-  PM_TRY(d_fa.alloc((size_t)ops_end * 4));
-  PM_TRY(d_fb.alloc((size_t)ops_end * 4));
-  PM_TRY(d_pa.alloc((size_t)ops_end * 4));
-  PM_TRY(d_pb.alloc((size_t)ops_end * 4));
-  PM_TRY(d_out.alloc((size_t)n_out));
-  PM_TRY(d_bad.alloc(4));
-  PM_HIP(hipMemset(d_bad.p, 0, 4));
-  dp_op_flags_kernel<<<(unsigned)((ops_end + 255) / 256), 256>>>(ops_end, (const unsigned char *)d_ops.p, (int *)d_fa.p, (int *)d_fb.p);
-  PM_HIP(hipGetLastError());
-  size_t tmp_bytes = 0;
-  PM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
-  PM_TRY(d_tmp.alloc(tmp_bytes));
-  PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
-  PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fb.p, (int *)d_pb.p, 0, (size_t)ops_end, rocprim::plus<int>()));
-  dp_emit_kernel<<<(unsigned)((n_out + 255) / 256), 256>>>(n_out, n_pairs, (const i64 *)d_out_off.p, (const i64 *)d_ops_off.p,
-                                                           (const int *)d_n_ops.p, (const unsigned char *)d_ops.p, (const int *)d_pa.p,
-                                                           (const int *)d_pb.p, (const i64 *)d_bra.p, (const i64 *)d_roa.p,
-                                                           (const unsigned char *)d_ta.p, (const i64 *)d_brb.p, (const i64 *)d_rob.p,
-                                                           (const unsigned char *)d_tb.p, (unsigned char *)d_out.p, (int *)d_bad.p);
-  PM_HIP(hipGetLastError());
-  int bad = 0;
-  PM_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
-  if(bad) {
-    return fail(PM_E_INVALID, "pm_dp_emit_maf: an op outside {0, 1, 2} or a path that leaves its block");
-  }
+  PM_TRY(emit_device(A, B, n_pairs, (const unsigned char *)d_ops.p, ops_end, (const i64 *)d_ops_off.p, (const int *)d_n_ops.p,
+                     (const i64 *)d_out_off.p, n_out, d_out, "pm_dp_emit_maf"));
   PM_HIP(hipMemcpy(out_text, d_out.p, (size_t)n_out, hipMemcpyDeviceToHost));
   return PM_OK;
 }
@@ -411,47 +436,72 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
     return fail(PM_E_INVALID, "pm_dp_align_maf: the two MAF files must hold the same number of blocks (pair k = block k of each)");
   }
   lap("parse (two threads)");
-  std::string ta, tb;
-  std::vector<int64_t> roa, rob;
-  flatten(A, ta, roa);
-  flatten(B, tb, rob);
-  lap("flatten");
-  // a block has as many columns as its first row has bytes: the sizes need no pass of their own
-  std::vector<int64_t> coa((size_t)n + 1), cob((size_t)n + 1);
-  int64_t total_a = 0, total_b = 0;
+  // a block has as many columns as its first row has bytes
+  std::vector<int64_t> coa((size_t)n + 1, 0), cob((size_t)n + 1, 0);
   for(int64_t k = 0; k < n; ++k) {
     const int64_t ra = A.block_row[(size_t)k], rb = B.block_row[(size_t)k];
-    total_a += ra < A.block_row[(size_t)k + 1] ? roa[(size_t)ra + 1] - roa[(size_t)ra] : 0;
-    total_b += rb < B.block_row[(size_t)k + 1] ? rob[(size_t)rb + 1] - rob[(size_t)rb] : 0;
+    coa[(size_t)k + 1] = coa[(size_t)k] + (ra < A.block_row[(size_t)k + 1] ? A.row_off[(size_t)ra + 1] - A.row_off[(size_t)ra] : 0);
+    cob[(size_t)k + 1] = cob[(size_t)k] + (rb < B.block_row[(size_t)k + 1] ? B.row_off[(size_t)rb + 1] - B.row_off[(size_t)rb] : 0);
   }
-  std::vector<uint8_t> ca((size_t)total_a * 8 + 8), cb((size_t)total_b * 8 + 8);
-  PM_TRY(pm_dp_pack_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), n, ca.data(), coa.data(), device));
-  PM_TRY(pm_dp_pack_maf((const uint8_t *)tb.data(), rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, cb.data(), cob.data(), device));
-  lap("pack (device)");
-  pm_dp_batch_t *batch = nullptr;
-  PM_TRY(pm_dp_batch_create(ca.data(), coa.data(), cb.data(), cob.data(), n, params, 0, device, &batch));
+  PM_TRY(check_blocks(A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(), n, "pm_dp_align_maf (A)"));
+  PM_TRY(check_blocks(B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, "pm_dp_align_maf (B)"));
+  if(n == 0) { // nothing to align: the header alone
+    FILE *f0 = fopen(out_maf, "wb");
+    if(!f0 || fputs("##maf version=1 scoring=paramugsy_amd\n", f0) < 0 || fclose(f0) != 0) {
+      return fail(PM_E_IO, std::string("cannot write ") + out_maf);
+    }
+    return PM_OK;
+  }
+  // the texts go to the device once; the packed columns, the paths and the merged texts never leave it before the last copy
+  MafSideDev SA, SB;
+  PM_TRY(SA.upload((const uint8_t *)A.text.data(), A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(), n, coa.data()));
+  PM_TRY(SB.upload((const uint8_t *)B.text.data(), B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, cob.data()));
+  PM_TRY(SA.pack());
+  PM_TRY(SB.pack());
+  lap("upload + pack (device)");
+  PM_TRY(dp_batch_check_params(params));
+  std::unique_ptr<pm_dp_batch> batch(new(std::nothrow) pm_dp_batch());
+  if(!batch) {
+    return fail(PM_E_INVALID, "out of host memory");
+  }
+  PM_TRY(dp_batch_init(batch.get(), params, 0, device));
+  PM_TRY(dp_batch_load(batch.get(), (const uint8_t *)SA.cols.p, coa.data(), (const uint8_t *)SB.cols.p, cob.data(), n, nullptr));
+  PM_HIP(hipStreamSynchronize(nullptr));
+  PM_TRY(dp_batch_plan(batch.get(), nullptr));
+  PM_TRY(dp_run(batch.get(), nullptr, 1, nullptr, nullptr));
   std::vector<int32_t> scores((size_t)n), n_ops((size_t)n);
-  std::vector<uint8_t> ops((size_t)(coa[n] + cob[n]) + 1);
-  int rc = pm_dp_batch_run(batch, 1, nullptr);
-  if(!rc) {
-    rc = pm_dp_batch_fetch(batch, scores.data(), ops.data(), n_ops.data());
+  int perr = 0;
+  if(n > 0) {
+    PM_HIP(hipMemcpy(scores.data(), batch->scores.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    PM_HIP(hipMemcpy(n_ops.data(), batch->n_ops.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   }
-  pm_dp_batch_destroy(batch);
-  PM_TRY(rc);
-  lap("DP: create, run, fetch");
-  // pair k's path is the last n_ops[k] bytes of its slot
-  std::vector<int64_t> ops_off((size_t)n), out_off((size_t)n + 1);
+  PM_HIP(hipMemcpy(&perr, batch->pipe_error.p, 4, hipMemcpyDeviceToHost));
+  if(perr) {
+    return fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
+  }
+  lap("DP (device)");
+  // pair k's path is the last n_ops[k] bytes of its slot; every row of its merged block is as long as the path
+  std::vector<int64_t> ops_off((size_t)n), out_off((size_t)n + 1, 0);
   for(int64_t k = 0; k < n; ++k) {
-    ops_off[(size_t)k] = coa[k + 1] + cob[k + 1] - n_ops[(size_t)k];
+    ops_off[(size_t)k] = coa[(size_t)k + 1] + cob[(size_t)k + 1] - n_ops[(size_t)k];
+    out_off[(size_t)k + 1] = out_off[(size_t)k] + (A.block_row[(size_t)k + 1] - A.block_row[(size_t)k] + B.block_row[(size_t)k + 1] - B.block_row[(size_t)k]) *
+                                                       (int64_t)n_ops[(size_t)k];
   }
-  int64_t merged_bytes = 0; // every row of the merged block is as long as the path
-  for(int64_t k = 0; k < n; ++k) {
-    merged_bytes += (A.block_row[(size_t)k + 1] - A.block_row[(size_t)k] + B.block_row[(size_t)k + 1] - B.block_row[(size_t)k]) * (int64_t)n_ops[(size_t)k];
+  const int64_t ops_end = coa[(size_t)n] + cob[(size_t)n];
+  if(ops_end >= ((int64_t)1 << 31)) {
+    return fail(PM_E_INVALID, "pm_dp_align_maf: more than 2^31 columns in one call");
   }
-  std::vector<uint8_t> merged((size_t)merged_bytes + 1);
-  PM_TRY(pm_dp_emit_maf((const uint8_t *)ta.data(), roa.data(), (int64_t)A.rows.size(), A.block_row.data(), (const uint8_t *)tb.data(),
-                        rob.data(), (int64_t)B.rows.size(), B.block_row.data(), n, ops.data(), ops_off.data(), n_ops.data(), merged.data(),
-                        out_off.data(), device));
+  std::vector<uint8_t> merged((size_t)out_off[(size_t)n] + 1);
+  if(out_off[(size_t)n] > 0) {
+    DevBuf d_ops_off, d_n_ops, d_out_off, d_out;
+    PM_TRY(d_ops_off.upload(ops_off.data(), (size_t)n * 8, nullptr));
+    PM_TRY(d_n_ops.upload(n_ops.data(), (size_t)n * 4, nullptr));
+    PM_TRY(d_out_off.upload(out_off.data(), (size_t)(n + 1) * 8, nullptr));
+    PM_TRY(emit_device(SA, SB, n, (const unsigned char *)batch->ops.p, ops_end, (const i64 *)d_ops_off.p, (const int *)d_n_ops.p,
+                       (const i64 *)d_out_off.p, out_off[(size_t)n], d_out, "pm_dp_align_maf"));
+    PM_HIP(hipMemcpy(merged.data(), d_out.p, (size_t)out_off[(size_t)n], hipMemcpyDeviceToHost));
+  }
+  batch.reset();
   lap("emit (device)");
   FILE *f = fopen(out_maf, "wb");
   if(!f) {

@@ -136,3 +136,16 @@ def test_align_maf_files_end_to_end(oracle_build, tmp_path):
     write(pb, B[:5], b"R")
     with pytest.raises(capi.PmError):
         dp.align_maf_files(pa, pb, params, po)
+    # two files without blocks: the header alone
+    write(pa, [], b"L")
+    write(pb, [], b"R")
+    dp.align_maf_files(pa, pb, params, po)
+    assert open(po, "rb").read() == b"##maf version=1 scoring=paramugsy_amd\n"
+    # a block without rows on one side (an `a` line followed by nothing) aligns as an empty profile
+    with open(pa, "wb") as f:
+        f.write(b"a score=0\n\na score=0\ns L.g0 0 4 + 100 ACGT\n\n")
+    with open(pb, "wb") as f:
+        f.write(b"a score=0\ns R.g0 0 3 + 100 ACG\n\na score=0\ns R.g0 5 4 + 100 ACGT\n\n")
+    dp.align_maf_files(pa, pb, params, po)
+    got = ora.parse_maf(po)
+    assert len(got) == 2 and got[0][1] == [b"ACG"] and got[1][1] == [b"ACGT", b"ACGT"]
