@@ -276,6 +276,15 @@ int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_ro
                    const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs, const uint8_t *ops,
                    const int64_t *ops_off, const int32_t *n_ops, uint8_t *out_text, int64_t *out_off, int device);
 int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, int device);
+/* The same for blocks that are already in memory (the flat description above): pack -> DP -> expansion in one call, the texts going
+ * to the device once and the packed columns and paths never leaving it.  scores[n_pairs]; merged_columns[n_pairs] = columns of
+ * merged block k (= length of its path); merged block k = rows(A_k) + rows(B_k) rows of merged_columns[k] bytes at
+ * out_text + out_off[k], A's rows first; out_off[n_pairs + 1] is always written.  out_capacity: bytes out_text holds -- a merged
+ * block has at most columns(A_k) + columns(B_k) columns, so (rows of A + rows of B) x (columns of A + columns of B) summed over the
+ * pairs always suffices; too small is PM_E_INVALID with out_off filled in (call again with out_off[n_pairs] bytes).  New surface. */
+int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a, const uint8_t *text_b,
+                       const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs, const pm_dp_params_t *params,
+                       int32_t *scores, int32_t *merged_columns, uint8_t *out_text, int64_t out_capacity, int64_t *out_off, int device);
 
 #ifdef __cplusplus
 }

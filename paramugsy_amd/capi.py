@@ -57,7 +57,7 @@ EXPORTS = [
     "pm_translate_files", "pm_sort_delta", "pm_maf_analyzer", "pm_profiles_make", "pm_stage_files", "pm_untranslate",
     "pm_dp_batch_create", "pm_dp_batch_run", "pm_dp_batch_run_profiled", "pm_dp_batch_fetch", "pm_dp_batch_info", "pm_dp_batch_chunks", "pm_dp_batch_variant", "pm_dp_batch_path_mode", "pm_dp_batch_destroy",
     "pm_dp_host_alloc", "pm_dp_host_free", "pm_dp_stream_create", "pm_dp_stream_align", "pm_dp_stream_destroy",
-    "pm_dp_pack_maf", "pm_dp_emit_maf", "pm_dp_align_maf",
+    "pm_dp_pack_maf", "pm_dp_emit_maf", "pm_dp_align_maf", "pm_dp_align_blocks",
 ]
 
 

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <new>
 #include <string>
@@ -396,6 +397,77 @@ int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_ro
 
 } // extern "C"
 
+// Blocks in, merged blocks out, through the device once: texts up, pack, DP, expansion along the paths, merged texts down.
+// scores / n_ops: n values each (n_ops[k] = columns of merged block k); out_off: n + 1 byte offsets into `merged`.
+static int align_blocks_core(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a, const uint8_t *text_b,
+                             const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n, const pm_dp_params_t *params,
+                             int device, std::vector<int32_t> &scores, std::vector<int32_t> &n_ops, std::vector<uint8_t> &merged,
+                             std::vector<int64_t> &out_off, const std::function<void(const char *)> &lap) {
+  PM_TRY(check_blocks(row_off_a, n_rows_a, block_row_a, n, "pm_dp_align (A)"));
+  PM_TRY(check_blocks(row_off_b, n_rows_b, block_row_b, n, "pm_dp_align (B)"));
+  // a block has as many columns as its first row has bytes
+  std::vector<int64_t> coa((size_t)n + 1, 0), cob((size_t)n + 1, 0);
+  for(int64_t k = 0; k < n; ++k) {
+    const int64_t ra = block_row_a[k], rb = block_row_b[k];
+    coa[(size_t)k + 1] = coa[(size_t)k] + (ra < block_row_a[k + 1] ? row_off_a[ra + 1] - row_off_a[ra] : 0);
+    cob[(size_t)k + 1] = cob[(size_t)k] + (rb < block_row_b[k + 1] ? row_off_b[rb + 1] - row_off_b[rb] : 0);
+  }
+  scores.assign((size_t)n, 0);
+  n_ops.assign((size_t)n, 0);
+  out_off.assign((size_t)n + 1, 0);
+  merged.clear();
+  if(n == 0) {
+    return PM_OK;
+  }
+  // the texts go to the device once; the packed columns, the paths and the merged texts never leave it before the last copy
+  MafSideDev SA, SB;
+  PM_TRY(SA.upload(text_a, row_off_a, n_rows_a, block_row_a, n, coa.data()));
+  PM_TRY(SB.upload(text_b, row_off_b, n_rows_b, block_row_b, n, cob.data()));
+  PM_TRY(SA.pack());
+  PM_TRY(SB.pack());
+  lap("upload + pack (device)");
+  PM_TRY(dp_batch_check_params(params));
+  std::unique_ptr<pm_dp_batch> batch(new(std::nothrow) pm_dp_batch());
+  if(!batch) {
+    return fail(PM_E_INVALID, "out of host memory");
+  }
+  PM_TRY(dp_batch_init(batch.get(), params, 0, device));
+  PM_TRY(dp_batch_load(batch.get(), (const uint8_t *)SA.cols.p, coa.data(), (const uint8_t *)SB.cols.p, cob.data(), n, nullptr));
+  PM_HIP(hipStreamSynchronize(nullptr));
+  PM_TRY(dp_batch_plan(batch.get(), nullptr));
+  PM_TRY(dp_run(batch.get(), nullptr, 1, nullptr, nullptr));
+  int perr = 0;
+  PM_HIP(hipMemcpy(scores.data(), batch->scores.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PM_HIP(hipMemcpy(n_ops.data(), batch->n_ops.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PM_HIP(hipMemcpy(&perr, batch->pipe_error.p, 4, hipMemcpyDeviceToHost));
+  if(perr) {
+    return fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
+  }
+  lap("DP (device)");
+  // pair k's path is the last n_ops[k] bytes of its slot; every row of its merged block is as long as the path
+  std::vector<int64_t> ops_off((size_t)n);
+  for(int64_t k = 0; k < n; ++k) {
+    ops_off[(size_t)k] = coa[(size_t)k + 1] + cob[(size_t)k + 1] - n_ops[(size_t)k];
+    out_off[(size_t)k + 1] = out_off[(size_t)k] + (block_row_a[k + 1] - block_row_a[k] + block_row_b[k + 1] - block_row_b[k]) * (int64_t)n_ops[(size_t)k];
+  }
+  const int64_t ops_end = coa[(size_t)n] + cob[(size_t)n];
+  if(ops_end >= ((int64_t)1 << 31)) {
+    return fail(PM_E_INVALID, "pm_dp_align: more than 2^31 columns in one call");
+  }
+  merged.resize((size_t)out_off[(size_t)n] + 1);
+  if(out_off[(size_t)n] > 0) {
+    DevBuf d_ops_off, d_n_ops, d_out_off, d_out;
+    PM_TRY(d_ops_off.upload(ops_off.data(), (size_t)n * 8, nullptr));
+    PM_TRY(d_n_ops.upload(n_ops.data(), (size_t)n * 4, nullptr));
+    PM_TRY(d_out_off.upload(out_off.data(), (size_t)(n + 1) * 8, nullptr));
+    PM_TRY(emit_device(SA, SB, n, (const unsigned char *)batch->ops.p, ops_end, (const i64 *)d_ops_off.p, (const int *)d_n_ops.p,
+                       (const i64 *)d_out_off.p, out_off[(size_t)n], d_out, "pm_dp_align"));
+    PM_HIP(hipMemcpy(merged.data(), d_out.p, (size_t)out_off[(size_t)n], hipMemcpyDeviceToHost));
+  }
+  lap("emit (device)");
+  return PM_OK;
+}
+
 extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, int device) {
   if(!maf_a || !maf_b || !params || !out_maf) {
     return fail(PM_E_INVALID, "pm_dp_align_maf: null argument");
@@ -436,73 +508,11 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
     return fail(PM_E_INVALID, "pm_dp_align_maf: the two MAF files must hold the same number of blocks (pair k = block k of each)");
   }
   lap("parse (two threads)");
-  // a block has as many columns as its first row has bytes
-  std::vector<int64_t> coa((size_t)n + 1, 0), cob((size_t)n + 1, 0);
-  for(int64_t k = 0; k < n; ++k) {
-    const int64_t ra = A.block_row[(size_t)k], rb = B.block_row[(size_t)k];
-    coa[(size_t)k + 1] = coa[(size_t)k] + (ra < A.block_row[(size_t)k + 1] ? A.row_off[(size_t)ra + 1] - A.row_off[(size_t)ra] : 0);
-    cob[(size_t)k + 1] = cob[(size_t)k] + (rb < B.block_row[(size_t)k + 1] ? B.row_off[(size_t)rb + 1] - B.row_off[(size_t)rb] : 0);
-  }
-  PM_TRY(check_blocks(A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(), n, "pm_dp_align_maf (A)"));
-  PM_TRY(check_blocks(B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, "pm_dp_align_maf (B)"));
-  if(n == 0) { // nothing to align: the header alone
-    FILE *f0 = fopen(out_maf, "wb");
-    if(!f0 || fputs("##maf version=1 scoring=paramugsy_amd\n", f0) < 0 || fclose(f0) != 0) {
-      return fail(PM_E_IO, std::string("cannot write ") + out_maf);
-    }
-    return PM_OK;
-  }
-  // the texts go to the device once; the packed columns, the paths and the merged texts never leave it before the last copy
-  MafSideDev SA, SB;
-  PM_TRY(SA.upload((const uint8_t *)A.text.data(), A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(), n, coa.data()));
-  PM_TRY(SB.upload((const uint8_t *)B.text.data(), B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, cob.data()));
-  PM_TRY(SA.pack());
-  PM_TRY(SB.pack());
-  lap("upload + pack (device)");
-  PM_TRY(dp_batch_check_params(params));
-  std::unique_ptr<pm_dp_batch> batch(new(std::nothrow) pm_dp_batch());
-  if(!batch) {
-    return fail(PM_E_INVALID, "out of host memory");
-  }
-  PM_TRY(dp_batch_init(batch.get(), params, 0, device));
-  PM_TRY(dp_batch_load(batch.get(), (const uint8_t *)SA.cols.p, coa.data(), (const uint8_t *)SB.cols.p, cob.data(), n, nullptr));
-  PM_HIP(hipStreamSynchronize(nullptr));
-  PM_TRY(dp_batch_plan(batch.get(), nullptr));
-  PM_TRY(dp_run(batch.get(), nullptr, 1, nullptr, nullptr));
-  std::vector<int32_t> scores((size_t)n), n_ops((size_t)n);
-  int perr = 0;
-  if(n > 0) {
-    PM_HIP(hipMemcpy(scores.data(), batch->scores.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    PM_HIP(hipMemcpy(n_ops.data(), batch->n_ops.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-  }
-  PM_HIP(hipMemcpy(&perr, batch->pipe_error.p, 4, hipMemcpyDeviceToHost));
-  if(perr) {
-    return fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
-  }
-  lap("DP (device)");
-  // pair k's path is the last n_ops[k] bytes of its slot; every row of its merged block is as long as the path
-  std::vector<int64_t> ops_off((size_t)n), out_off((size_t)n + 1, 0);
-  for(int64_t k = 0; k < n; ++k) {
-    ops_off[(size_t)k] = coa[(size_t)k + 1] + cob[(size_t)k + 1] - n_ops[(size_t)k];
-    out_off[(size_t)k + 1] = out_off[(size_t)k] + (A.block_row[(size_t)k + 1] - A.block_row[(size_t)k] + B.block_row[(size_t)k + 1] - B.block_row[(size_t)k]) *
-                                                       (int64_t)n_ops[(size_t)k];
-  }
-  const int64_t ops_end = coa[(size_t)n] + cob[(size_t)n];
-  if(ops_end >= ((int64_t)1 << 31)) {
-    return fail(PM_E_INVALID, "pm_dp_align_maf: more than 2^31 columns in one call");
-  }
-  std::vector<uint8_t> merged((size_t)out_off[(size_t)n] + 1);
-  if(out_off[(size_t)n] > 0) {
-    DevBuf d_ops_off, d_n_ops, d_out_off, d_out;
-    PM_TRY(d_ops_off.upload(ops_off.data(), (size_t)n * 8, nullptr));
-    PM_TRY(d_n_ops.upload(n_ops.data(), (size_t)n * 4, nullptr));
-    PM_TRY(d_out_off.upload(out_off.data(), (size_t)(n + 1) * 8, nullptr));
-    PM_TRY(emit_device(SA, SB, n, (const unsigned char *)batch->ops.p, ops_end, (const i64 *)d_ops_off.p, (const int *)d_n_ops.p,
-                       (const i64 *)d_out_off.p, out_off[(size_t)n], d_out, "pm_dp_align_maf"));
-    PM_HIP(hipMemcpy(merged.data(), d_out.p, (size_t)out_off[(size_t)n], hipMemcpyDeviceToHost));
-  }
-  batch.reset();
-  lap("emit (device)");
+  std::vector<int32_t> scores, n_ops;
+  std::vector<uint8_t> merged;
+  std::vector<int64_t> out_off;
+  PM_TRY(align_blocks_core((const uint8_t *)A.text.data(), A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(), (const uint8_t *)B.text.data(),
+                           B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, params, device, scores, n_ops, merged, out_off, lap));
   FILE *f = fopen(out_maf, "wb");
   if(!f) {
     return fail(PM_E_IO, std::string("cannot write ") + out_maf);
@@ -530,5 +540,34 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
     return fail(PM_E_IO, std::string("cannot write ") + out_maf);
   }
   lap("write");
+  return PM_OK;
+}
+
+extern "C" int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a, const uint8_t *text_b,
+                                  const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs,
+                                  const pm_dp_params_t *params, int32_t *scores, int32_t *merged_columns, uint8_t *out_text, int64_t out_capacity,
+                                  int64_t *out_off, int device) {
+  if(!row_off_a || !row_off_b || !block_row_a || !block_row_b || !params || !scores || !merged_columns || !out_off || n_pairs < 0 ||
+     (!out_text && out_capacity > 0)) {
+    return fail(PM_E_INVALID, "pm_dp_align_blocks: null argument");
+  }
+  PM_TRY(use_device(device));
+  std::vector<int32_t> s, n_ops;
+  std::vector<uint8_t> merged;
+  std::vector<int64_t> off;
+  PM_TRY(align_blocks_core(text_a, row_off_a, n_rows_a, block_row_a, text_b, row_off_b, n_rows_b, block_row_b, n_pairs, params, device, s, n_ops, merged,
+                           off, [](const char *) {}));
+  memcpy(out_off, off.data(), (size_t)(n_pairs + 1) * 8);
+  if(n_pairs > 0) {
+    memcpy(scores, s.data(), (size_t)n_pairs * 4);
+    memcpy(merged_columns, n_ops.data(), (size_t)n_pairs * 4);
+  }
+  if(off[(size_t)n_pairs] > out_capacity) {
+    return fail(PM_E_INVALID, "pm_dp_align_blocks: out_text holds " + std::to_string(out_capacity) + " bytes, the merged blocks need " +
+                                  std::to_string(off[(size_t)n_pairs]) + " (at most (rows of A + rows of B) x (columns of A + columns of B) per pair)");
+  }
+  if(off[(size_t)n_pairs] > 0) {
+    memcpy(out_text, merged.data(), (size_t)off[(size_t)n_pairs]);
+  }
   return PM_OK;
 }

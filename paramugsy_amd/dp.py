@@ -81,6 +81,8 @@ def _lib():
         l.pm_dp_emit_maf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         l.pm_dp_align_maf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PmDpParams), C.c_char_p, C.c_int]
+        l.pm_dp_align_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.POINTER(PmDpParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         l.pm_dp_batch_destroy.argtypes = [C.c_void_p]
         l.pm_dp_batch_destroy.restype = None
         l.pm_dp_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64]
@@ -305,6 +307,30 @@ def emit_maf(blocks_a: Sequence[Sequence[bytes]], blocks_b: Sequence[Sequence[by
         base = int(out_off[k])
         merged.append([out[base + r * ln: base + (r + 1) * ln].tobytes() for r in range(rows)])
     return merged
+
+
+def align_blocks(blocks_a: Sequence[Sequence[bytes]], blocks_b: Sequence[Sequence[bytes]], params: PmDpParams,
+                 device: int = 0) -> Tuple[np.ndarray, List[List[bytes]]]:
+    """Pair k = block k of each side -> (scores, merged blocks), pack + DP + expansion in one call (pm_dp_align_blocks): the
+    texts go to the device once, the packed columns and the paths stay there."""
+    ta, roa, bra = flatten_blocks(blocks_a)
+    tb, rob, brb = flatten_blocks(blocks_b)
+    n = len(blocks_a)
+    if len(blocks_b) != n:
+        raise ValueError("pair k is block k of each side: %d and %d blocks" % (n, len(blocks_b)))
+    cap = sum((len(a) + len(b)) * ((len(a[0]) if a else 0) + (len(b[0]) if b else 0)) for a, b in zip(blocks_a, blocks_b))
+    scores = np.zeros(max(1, n), dtype=np.int32)
+    cols = np.zeros(max(1, n), dtype=np.int32)
+    out = np.zeros(max(1, cap), dtype=np.uint8)
+    out_off = np.zeros(n + 1, dtype=np.int64)
+    capi.check(_lib().pm_dp_align_blocks(ta.ctypes.data, roa.ctypes.data, len(roa) - 1, bra.ctypes.data, tb.ctypes.data, rob.ctypes.data,
+                                         len(rob) - 1, brb.ctypes.data, n, C.byref(params), scores.ctypes.data, cols.ctypes.data,
+                                         out.ctypes.data, cap, out_off.ctypes.data, device))
+    merged = []
+    for k in range(n):
+        rows, ln, base = len(blocks_a[k]) + len(blocks_b[k]), int(cols[k]), int(out_off[k])
+        merged.append([out[base + r * ln: base + (r + 1) * ln].tobytes() for r in range(rows)])
+    return scores[:n], merged
 
 
 def align_maf_files(maf_a: str, maf_b: str, params: PmDpParams, out_maf: str, device: int = 0) -> None:

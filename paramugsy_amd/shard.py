@@ -211,7 +211,7 @@ def align_sharded(inputs, params, rank: int, world: int, dist=None, device: int 
 
 def align_blocks_sharded(blocks_a, blocks_b, params, rank: int, world: int, dist=None, device: int = 0, block_fn=None):
     """MAF blocks in, merged MAF blocks out, over a static pair partition: pair k = block k of each side.  Rank r packs, aligns
-    and expands its contiguous slice on its GPU (pm_dp_pack_maf -> pm_dp_batch_* -> pm_dp_emit_maf); rank 0 receives every
+    and expands its contiguous slice on its GPU (pm_dp_align_blocks: pack -> DP -> expansion without leaving the device); rank 0 receives every
     shard's scores and merged blocks in pair order: the "host-side gather of MAF blocks".  Three flat arrays travel per rank
     (scores, rows and columns per merged block, all row texts back to back).
     block_fn(sub_a, sub_b, params) -> (scores, merged blocks) replaces the HIP path in the CPU tests (the oracle)."""
@@ -224,16 +224,7 @@ def align_blocks_sharded(blocks_a, blocks_b, params, rank: int, world: int, dist
             scores, merged = block_fn(sub_a, sub_b, params)
         else:
             from . import dp
-            ca, oa = dp.pack_maf(sub_a, device=device)
-            cb, ob = dp.pack_maf(sub_b, device=device)
-            batch = dp.DpBatch(dp.DpInputs(ca, oa, cb, ob), params, device=device)
-            try:
-                batch.run(traceback=True)
-                scores, ops, n_ops = batch.fetch()
-                paths = batch.paths(ops, n_ops)
-            finally:
-                batch.close()
-            merged = dp.emit_maf(sub_a, sub_b, paths, device=device)
+            scores, merged = dp.align_blocks(sub_a, sub_b, params, device=device)
     except Exception as e:  # noqa: BLE001 -- reported to every rank below
         err = e
     if world == 1 or dist is None:

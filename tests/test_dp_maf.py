@@ -86,6 +86,41 @@ def test_blocks_through_the_dp_and_back(oracle_build):
 
 
 @pytest.mark.gpu
+def test_align_blocks_in_one_call_equals_the_three_stages(oracle_build):
+    """pm_dp_align_blocks (texts to the device once, columns and paths staying there) against pack -> DpBatch -> emit through host
+    memory, on random block pairs including empty blocks and one-row blocks; and its refusal of a buffer that is too small."""
+    from paramugsy_amd import capi
+    rng = np.random.default_rng(14)
+    A = random_blocks(rng, 30, max_rows=5, max_cols=260) + [[b"ACGT"], [b"-"], [b"AC-T", b"ACGT"]]
+    B = random_blocks(rng, 30, max_rows=3, max_cols=260) + [[b"A"], [b"ACG"], [b"T"]]
+    params = dp.make_params(3, 3)
+    scores, merged = dp.align_blocks(A, B, params)
+    ca, oa = dp.pack_maf(A)
+    cb, ob = dp.pack_maf(B)
+    batch = dp.DpBatch(dp.DpInputs(ca, oa, cb, ob), params)
+    batch.run(traceback=True)
+    s2, ops, n_ops = batch.fetch()
+    paths = batch.paths(ops, n_ops)
+    batch.close()
+    assert np.array_equal(scores, s2)
+    assert merged == dp.emit_maf(A, B, paths)
+    for k in range(len(A)):
+        assert merged[k] == ora.emit_block(A[k], B[k], paths[k].tolist())
+    s0, m0 = dp.align_blocks([], [], params)
+    assert len(s0) == 0 and m0 == []
+    # a buffer that is too small: refused, with the needed size in out_off
+    import ctypes as C
+    ta, roa, bra = dp.flatten_blocks(A)
+    tb, rob, brb = dp.flatten_blocks(B)
+    n = len(A)
+    sc, cols, out, off = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(16, np.uint8), np.zeros(n + 1, np.int64)
+    rc = dp._lib().pm_dp_align_blocks(ta.ctypes.data, roa.ctypes.data, len(roa) - 1, bra.ctypes.data, tb.ctypes.data, rob.ctypes.data,
+                                       len(rob) - 1, brb.ctypes.data, n, C.byref(params), sc.ctypes.data, cols.ctypes.data, out.ctypes.data, 16,
+                                       off.ctypes.data, 0)
+    assert rc != 0 and off[-1] == sum(len(m) * len(m[0]) for m in merged) and np.array_equal(sc, scores)
+
+
+@pytest.mark.gpu
 def test_emit_refuses_a_path_that_does_not_span_the_pair():
     from paramugsy_amd import capi
     with pytest.raises(capi.PmError) as e:
