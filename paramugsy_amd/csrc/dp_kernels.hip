@@ -145,7 +145,11 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     }
     int diag_in = (j0 == 0 ? 0 : -gop) - gop; // H~[0][j0] - gop
     int e = DP_NEG_INF; // the running E of this lane's row; between steps: what the lane hands to its right neighbour
-    int bin_ho = 0, bin_e = DP_NEG_INF;
+    // what the column left of the stripe hands to lane 0, 64 rows at a time (lane r & 63 holds row r's): the seam of the stripe to
+    // the left, or for the first stripe the DP's own column 0, H~[t+1][0] - gop = -2 gop with no E -- constants kept in the same
+    // registers, so that with several waves per pair (few pairs: a wave's own branches are what its steps wait for) the step reads
+    // them the same way whatever the stripe; one wave per pair keeps the branch, which saves the first stripe two v_readlane a step
+    int bin_ho = -2 * gop, bin_e = DP_NEG_INF;
     if(s > 0) {
       // lane 63's stores of the previous stripe must be visible to every lane's loads
       if(ng == 1) { // (several workgroups: the seam is read with agent-scope atomic loads instead)
@@ -224,7 +228,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       for(int t = t0; t < t1; ++t, ii16 += 16) {
       // what the column left of the stripe hands to lane 0 for row t
       int b_ho, b_e;
-      if(s == 0) {
+      if(NW == 1 && s == 0) {
         b_ho = -2 * gop; // H~[t+1][0] - gop
         b_e = DP_NEG_INF;
       }
