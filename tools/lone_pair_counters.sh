@@ -1,3 +1,4 @@
+# GPU box: instruction and wait counters of the fill kernel for ONE pair of 32 x 10 kbp (a lone wave per SIMD): two rocprofv3 --pmc passes.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/lonepmc
 rm -rf $O; mkdir -p $O
