@@ -2,8 +2,8 @@
 """bench.py -- throughput of the hot path on N GPUs of one node (one process per GPU, no collective on the
 data path: the work units are independent).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config ns|c1|c2|deep] [--scaling weak|strong]
-                    [--path dp|translate|both]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config ns|c1|c2|deep] [--scaling strong|weak]
+                    [--path dp|translate|both] [--no-ride-alongs]
 
 With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts N ranks of itself
 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), never touches the GPU, relays rank 0's JSON
@@ -11,19 +11,21 @@ line and exits non-zero if any rank did.  Under `python -m torch.distributed.run
 it is one of the ranks.  A line is printed only when the number of ranks that ran equals --gpus.
 
 Prints ONE JSON line on rank 0.  `metric`/`value` are BASELINE.json's metric (profile-DP GCUPS, see paramugsy_amd/dp.py)
-on --config (default `ns`, the north-star shape at one GPU's share: 12 500 pairs of 8 rows x 4 096 columns, so that
---gpus 8 under weak scaling is exactly the north-star's 100 k pairs); BASELINE.json configs[1] (`c1`) and the measured
-numbers of the translate path -- the path the reference actually ships -- ride along in the same line under
-"c1" and "translate".  Each carries
-  roofline      achieved = algorithmic bytes per launch / average device time of the dominant kernel (HIP events
-                on the launch stream), against the 8 TB/s HBM peak
+on --config, default `ns`: the batch the north-star target is quoted on, 100 000 pairs of 8 rows x 4 096 columns, the WHOLE
+batch on one GPU at N = 1 and statically pair-partitioned over the ranks at N > 1 (--scaling strong, the default: BASELINE.json
+configs[3]/[4] semantics, cf. the chunked pair lists of lib/base/pm_job.ml:43-57).  The other BASELINE configurations ride
+along in the same line, each with its own roofline and an oracle-checked sample: "c1" (configs[1], N = 1 only), "c2" (the stated
+stand-in for configs[2]; the same batch partitioned at N > 1 is configs[3]), "deep" (configs[4]: 4 096 pairs of 32 rows x
+10 kbp in the whole job, 512 per GPU at N = 8) -- and "translate", the measured numbers of the path the reference actually
+ships.  Each carries
+  roofline      achieved = algorithmic bytes per launch / average device time of a launch of the dominant kernel (HIP
+                events on the launch stream), against the 8 TB/s HBM peak
   cpu_baseline  rank 0, N=1 only: the CPU side timed on this box's host cores on a bounded sample of the same
                 workload, single-threaded and as one process per core (translate: the upstream reference binary
                 oracle/_ref/m_translate when it travelled with the snapshot, kind "reference"; DP: the oracle, kind "port")
-Inputs are synthetic (seeded) and resident in HBM when the timed region starts.
---scaling weak: every rank gets the configuration's per-GPU batch; strong: ONE batch of the configuration's size (times
---strong-factor) is partitioned over the ranks with paramugsy_amd.shard.partition (BASELINE.json configs[3]/[4] semantics,
-cf. lib/base/pm_job.ml:43-57).
+Inputs are synthetic (seeded; the big DP batches are drawn on the GPU, paramugsy_amd/synth_device.py) and resident in HBM when
+the timed region starts.
+--scaling weak: every rank gets one GPU's eighth of the configuration (c1: the configuration itself).
 """
 import argparse
 import json
@@ -38,16 +40,19 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
-# per-GPU DP workloads (BASELINE.json configs); lengths in columns
+# DP workloads (BASELINE.json configs); `pairs` is the whole job (what one GPU runs at N = 1 and what N ranks partition under
+# strong scaling), `weak_pairs` one rank's batch under --scaling weak; lengths in columns
 DP_CONFIGS = {
-    "c1": {"pairs": 10000, "rows": 2, "len": 1000, "what": "BASELINE.json configs[1]: 10 k synthetic 2-row x 1 kbp profile pairs"},
-    "ns": {"pairs": 12500, "rows": 8, "len": 4096,
-           "what": "north-star shape, one GPU's eighth of 100 k synthetic 8-row x 4 kbp profile pairs"},
-    "c2": {"pairs": 100000, "rows": 4, "len": 0,
-           "what": "stand-in for BASELINE.json configs[2] (nucmer is not in the image): 100 k ragged segment pairs, 4-row profiles, "
+    "c1": {"pairs": 10000, "weak_pairs": 10000, "rows": 2, "len": 1000,
+           "what": "BASELINE.json configs[1]: 10 k synthetic 2-row x 1 kbp profile pairs"},
+    "ns": {"pairs": 100000, "weak_pairs": 12500, "rows": 8, "len": 4096,
+           "what": "the batch the north-star target is quoted on: 100 k synthetic 8-row x 4 kbp profile pairs"},
+    "c2": {"pairs": 100000, "weak_pairs": 12500, "rows": 4, "len": 0,
+           "what": "stand-in for BASELINE.json configs[2]/[3] (nucmer is not in the image): 100 k ragged segment pairs, 4-row profiles, "
                    "lengths log-normal (median 1 500, sigma 0.6, clipped to [200, 8 000]), seed 20261003"},
-    "deep": {"pairs": 512, "rows": 32, "len": 10000,
-             "what": "BASELINE.json configs[4] per GPU: 512 deep 32-row x 10 kbp profile pairs (int16 column weights)"},
+    "deep": {"pairs": 4096, "weak_pairs": 512, "rows": 32, "len": 10000,
+             "what": "BASELINE.json configs[4]: deep 32-row x 10 kbp profile pairs (int16 column weights), 4 096 in the whole job "
+                     "(512 per GPU on 8)"},
 }
 
 
@@ -58,9 +63,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--path", choices=["dp", "translate", "both"], default="both")
     ap.add_argument("--config", choices=sorted(DP_CONFIGS), default="ns")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--strong-factor", type=int, default=1, help="strong scaling: the fixed batch is this many per-GPU batches")
-    ap.add_argument("--no-c1", action="store_true", help="skip the configs[1] ride-along")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
+    ap.add_argument("--no-ride-alongs", "--no-c1", dest="no_ride", action="store_true", help="skip the c1 / c2 / deep ride-alongs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the transfer-inclusive pass (pm_dp_stream_align)")
     ap.add_argument("--dry-launch", action="store_true", help="ranks report their environment and exit (no GPU work)")
@@ -74,7 +78,7 @@ def parse_args():
     ap.add_argument("--dp-pairs", type=int, default=0)
     ap.add_argument("--dp-rows", type=int, default=0)
     ap.add_argument("--dp-len", type=int, default=0)
-    ap.add_argument("--dp-budget-gib", type=float, default=0.0, help="path workspace budget (0: the library's default, 32 GiB)")
+    ap.add_argument("--dp-budget-gib", type=float, default=0.0, help="path workspace budget (0: the library's default, 96 GiB or 40 %% of the device's memory)")
     return ap.parse_args()
 
 
@@ -189,12 +193,12 @@ def sum_over_ranks(torch, dist, value):
     return float(t.item())
 
 
-def measured_traffic(kernel_substr, config_key):
+def measured_traffic(kernel_substr, config_key, launches=1):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/pmc_traffic.json), if the bench
     configuration is the profiled one.  rocprofv3 cannot run inside bench.py; the file is written by
     tools/summarize_prof.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same script.
     FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes: MI355X_MICROARCH.md, HBM); both
-    counters are in KB."""
+    counters are in KB; the table holds the mean per dispatch of the kernel, i.e. per launch."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
@@ -317,31 +321,33 @@ def bench_translate(args, rank, world, local, torch, dist):
 
 # ------------------------------------------------------------------ profile DP
 
-def dp_inputs_for(cfg_name, cfg, rank, world, scaling, strong_factor):
-    """This rank's pairs of the configuration.  weak: the per-GPU batch, seeded by rank.  strong: the contiguous slice
-    shard.partition gives this rank of ONE batch of strong_factor per-GPU batches (every rank generates the same seeded
-    batch description and keeps its slice)."""
+def dp_inputs_for(cfg_name, cfg, rank, world, scaling, device):
+    """This rank's pairs of the configuration, and the number of pairs in the whole job.  strong: the contiguous slice
+    shard.partition gives this rank of ONE batch of cfg["pairs"] pairs (every rank knows the whole batch's seeded lengths and
+    draws only its slice).  weak: one GPU's eighth (cfg["weak_pairs"]), seeded by rank."""
     import numpy as np
     from paramugsy_amd import dp as dpm
     from paramugsy_amd.shard import partition
-    n, rows, L = cfg["pairs"], cfg["rows"], cfg["len"]
+    from paramugsy_amd.synth_device import synth_batch_device
+    rows, L = cfg["rows"], cfg["len"]
     seed = 20261003
     if scaling == "strong":
-        n_total = n * strong_factor
+        n_total = cfg["pairs"]
         lo, hi = partition(n_total, world, rank)
     else:
-        n_total = n
-        lo, hi = 0, n
+        n_total = cfg["weak_pairs"]
+        lo, hi = 0, n_total
         seed += rank
-    if cfg_name == "c1" and scaling == "weak":
-        return dpm.synth_pairs_fast(seed, n, rows, L), n_total  # the generator round 1's numbers were measured with
+    if cfg_name == "c1" and hi - lo == 10000 and rows == 2 and L == 1000:
+        return dpm.synth_pairs_fast(seed, 10000, rows, L), (n_total if scaling == "strong" else n_total * world)
     if L > 0:
         la = np.full(n_total, L, dtype=np.int64)
         lb = la
     else:
         la, lb = dpm.ragged_lengths(seed, n_total)
-    # a slice of a seeded batch: seed the slice by its position so that no rank has to generate the whole batch
-    return dpm.synth_batch(seed * 1000003 + lo, la[lo:hi], lb[lo:hi], rows, rows), n_total
+    # a slice of a seeded batch: seed the slice by its position so that no rank has to draw the whole batch
+    inputs = synth_batch_device(seed * 1000003 + lo, la[lo:hi], lb[lo:hi], rows, rows, device=device)
+    return inputs, (n_total if scaling == "strong" else n_total * world)
 
 
 def _oracle_leg(payload):
@@ -359,18 +365,36 @@ def _oracle_leg(payload):
     return time.perf_counter() - t0
 
 
-def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, with_cpu):
-    """One step = one pass (fill + path) over this rank's profile pairs, inputs resident in HBM."""
+def _tuned_leg(payload):
+    """One worker of cpu_baseline.tuned: oracle/dp_tuned.c (two-row recurrence over pre-folded weights, scores only)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from paramugsy_amd import dp as dpm
+    ca, oa, cb, ob, sub, go, ge = payload
+    p = dpm.PmDpParams()
+    for k in range(25):
+        p.sub[k] = sub[k]
+    p.gap_open, p.gap_extend = go, ge
+    t0 = time.perf_counter()
+    sc = pyoracle.dp_scores_tuned(dpm.DpInputs(ca, oa, cb, ob), p)
+    return time.perf_counter() - t0, sc
+
+
+def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, with_cpu, with_e2e):
+    """One step = one pass (fill + path kernels of every workspace chunk) over this rank's profile pairs, inputs resident in HBM."""
     import numpy as np
     from paramugsy_amd import dp as dpm
     from paramugsy_amd.shard import slice_pairs
     cfg = dict(DP_CONFIGS[cfg_name])
     if cfg_name == args.config:
-        cfg["pairs"] = args.dp_pairs or cfg["pairs"]
+        if args.dp_pairs:
+            cfg["pairs"] = cfg["weak_pairs"] = args.dp_pairs
         cfg["rows"] = args.dp_rows or cfg["rows"]
         cfg["len"] = args.dp_len or cfg["len"]
     rows = cfg["rows"]
-    inputs, n_total = dp_inputs_for(cfg_name, cfg, rank, world, args.scaling, args.strong_factor)
+    t_synth = time.perf_counter()
+    inputs, n_total = dp_inputs_for(cfg_name, cfg, rank, world, args.scaling, "cuda:%d" % local)
+    t_synth = time.perf_counter() - t_synth
     n = inputs.n_pairs
     params = dpm.make_params(rows, rows)
     batch = dpm.DpBatch(inputs, params, device=local, tb_budget_bytes=int(args.dp_budget_gib * (1 << 30)))
@@ -393,6 +417,7 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
     ops_per_cell = variant["valu_ops_per_cell"]
     shape = "%d-row x %d-column" % (rows, cfg["len"]) if cfg["len"] else "%d-row, ragged (%d..%d columns)" % (
         rows, int(np.diff(inputs.off_a).min()) if n else 0, int(np.diff(inputs.off_a).max()) if n else 0)
+    launches = max(1, info["chunks"])
     out = {
         "metric": "profile-DP GCUPS (global affine-gap profile x profile alignment, scores + traceback)",
         "value": cells_all * steps / dt / 1e9,
@@ -400,27 +425,111 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
         "ms_per_step": dt / steps * 1e3,
         "dtype": "int32",
         "config": {"workload": "%s: %d synthetic %s profile pairs on this rank (%s scaling, %d in the whole job), int32 affine-gap scores, "
-                               "scores + full traceback" % (cfg["what"], n, shape, args.scaling, n_total if args.scaling == "strong" else n * world),
-                   "name": cfg_name, "pairs_per_rank": n, "rows": rows, "columns": cfg["len"], "cells_per_step_per_rank": cells,
-                   "chunks": info["chunks"], "kernel_variant": variant,
+                               "scores + full traceback" % (cfg["what"], n, shape, args.scaling, n_total),
+                   "name": cfg_name, "pairs_in_job": n_total, "pairs_per_rank": n, "rows": rows, "columns": cfg["len"],
+                   "cells_per_step_per_rank": cells, "chunks": info["chunks"], "kernel_variant": variant,
                    "reference_counterpart": "none: the reference has no DP (SURVEY.md 0); specification and oracle are this repo's own"},
         "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_walk_kernel" if variant.get("checkpoints") else "dp_traceback_kernel": ms_tb,
                       "note": "device time summed over the step's launches (one fill and one path launch per workspace chunk; with several "
                               "chunks the path kernel of chunk c runs beside the fill kernel of chunk c + 1, so the two sums overlap)"},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": measured_traffic("dp_fill_kernel", "dp:%s:%d:%d:%d" % (cfg_name, n, rows, cfg["len"])),
+                     "traffic": measured_traffic("dp_fill_kernel", "dp:%s:%d:%d:%d" % (cfg_name, n, rows, cfg["len"]), launches),
                      "kernel": "dp_fill_kernel",
-                     "launches_per_step": info["chunks"],
-                     "avg_launch_ms": ms_fill / max(1, info["chunks"]),
-                     "algorithmic_bytes_per_launch": alg_bytes // max(1, info["chunks"]),
+                     "launches_per_step": launches,
+                     "avg_launch_ms": ms_fill / launches,
+                     "algorithmic_bytes_per_launch": alg_bytes // launches,
                      "valu": {"ops_per_cell": ops_per_cell, "achieved_Tops": cells * ops_per_cell / (ms_fill * 1e-3) / 1e12,
                               "peak_Tops": valu_peak / 1e12, "frac": cells * ops_per_cell / (ms_fill * 1e-3) / valu_peak,
-                              "note": "useful cell instructions only (per-step overhead, wavefront fill/drain and column padding "
-                                      "excluded) against the half-rate VALU issue limit; the issue-slot utilisation is higher"},
+                              "definition": "useful cell instructions only (per-step overhead, wavefront fill/drain and column padding excluded), "
+                                            "EVERY one of them priced at the half-rate issue limit of 4 cycles per wave64 instruction per SIMD "
+                                            "(4 of the 6 cell instructions are half-rate, 2 full-rate: against the mixed nominal bound of 20 cycles "
+                                            "per 64 cells, 7.86 T cells/s, the fraction is cells/s / 7.86e12; against the measured bare-cell loop, "
+                                            "6.2 T cells/s, profiles/r02_cell_rate.txt, cells/s / 6.2e12)",
+                              "cells_per_s": cells / (ms_fill * 1e-3),
+                              "frac_of_mixed_issue_bound": cells / (ms_fill * 1e-3) / 7.86e12,
+                              "frac_of_measured_cell_loop": cells / (ms_fill * 1e-3) / 6.2e12},
                      "note": "max-plus recurrence: the fill kernel is bound by int32 VALU issue, not by HBM; the HBM fraction is reported as measured"},
+        "setup_s": {"synthesis": t_synth},
     }
-    if rank == 0 and world == 1 and not args.no_end_to_end:
+    # every configuration: a sample of the batch under the oracle (scores and paths, op for op)
+    scores, ops, n_ops = batch.fetch()
+    la = np.diff(inputs.off_a)
+    lb = np.diff(inputs.off_b)
+    cum = np.cumsum(la * lb)
+    want_cells = 2.0e9 if with_cpu else 2.5e8
+    k = int(max(1, min(n, np.searchsorted(cum, want_cells) + 1)))  # 2e9 cells: 10-15 s on one core
+    if rank == 0 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle
+        sample = slice_pairs(inputs, 0, k)
+        t0 = time.perf_counter()
+        o_scores, o_paths = pyoracle.dp_align(sample, params)
+        cpu_dt = time.perf_counter() - t0
+        same = bool(np.array_equal(scores[:k], o_scores)) and all(
+            np.array_equal(p, q) for p, q in zip(batch.paths(ops, n_ops)[:k], o_paths))
+        sample_cells = int(cum[k - 1])
+        out["oracle_check"] = {"pairs": k, "cells": sample_cells, "scores_and_paths_identical": same,
+                               "oracle": "oracle/dp_oracle.c (this repo's own specification: parity unpinned, SURVEY.md 0)"}
+        if not same:
+            raise SystemExit("bench.py: %s: the GPU's scores or paths differ from the oracle on the first %d pairs" % (cfg_name, k))
+        if with_cpu and world == 1:
+            out["cpu_baseline"] = {"value": sample_cells / cpu_dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
+                                   "sample": "first %d pairs of the same batch through oracle/dp_oracle.c (scalar C, full matrix, scores + paths), "
+                                             "%.1f s; GPU results identical on the sample: %s" % (k, cpu_dt, same)}
+            nproc = host_cores()
+            import multiprocessing as mp
+            from paramugsy_amd.shard import partition
+            kk = int(max(nproc, min(n, np.searchsorted(cum, 1.0e9 * nproc) + 1)))  # about 1e9 cells per core
+
+            def payloads_for(n_pairs_sample):
+                pl = []
+                for w_ in range(nproc):
+                    lo, hi = partition(n_pairs_sample, nproc, w_)
+                    sl = slice_pairs(inputs, lo, hi)
+                    pl.append((np.ascontiguousarray(sl.cols_a), sl.off_a, np.ascontiguousarray(sl.cols_b), sl.off_b,
+                               list(params.sub), params.gap_open, params.gap_extend))
+                return pl
+            with mp.get_context("spawn").Pool(nproc) as pool:
+                if nproc > 1:
+                    t0 = time.perf_counter()
+                    pool.map(_oracle_leg, payloads_for(kk))
+                    par_dt = time.perf_counter() - t0
+                    out["cpu_baseline"]["all_cores"] = {"value": int(cum[kk - 1]) / par_dt / 1e9, "unit": "GCUPS", "cores": nproc, "nproc": nproc,
+                                                        "sample": "first %d pairs as %d processes (one per host core), %.1f s wall incl. process start"
+                                                        % (kk, nproc, par_dt)}
+                # an honest CPU figure beside the port: two-row recurrence over pre-folded column weights, scores only,
+                # -O3 -march=native, one process per core (oracle/dp_tuned.c; its scores must equal the GPU's)
+                if hasattr(pyoracle, "dp_scores_tuned"):
+                    kt = int(max(nproc, min(n, np.searchsorted(cum, 6.0e9 * nproc) + 1)))
+                    t0 = time.perf_counter()
+                    res = pool.map(_tuned_leg, payloads_for(kt))
+                    tuned_dt = time.perf_counter() - t0
+                    t_scores = np.concatenate([r[1] for r in res])
+                    out["cpu_baseline"]["tuned"] = {
+                        "value": int(cum[kt - 1]) / tuned_dt / 1e9, "unit": "GCUPS", "cores": nproc, "kind": "port",
+                        "per_core_GCUPS": int(cum[kt - 1]) / sum(r[0] for r in res) / 1e9,
+                        "sample": "first %d pairs, scores only, oracle/dp_tuned.c (pre-folded weights, two-row recurrence, gcc -O3 -march=native), "
+                                  "%d processes, %.1f s wall; scores equal the GPU's: %s"
+                                  % (kt, nproc, tuned_dt, bool(np.array_equal(t_scores, scores[:kt])))}
+    # host-side gather (never in `value`): every rank's scores and paths fetched from its GPU and moved to rank 0 in pair order
+    t0 = time.perf_counter()
+    g_scores, g_ops, g_nops = batch.fetch()
+    if dist is not None:
+        from paramugsy_amd.shard import gather_bytes
+        for buf in (g_scores, g_nops, g_ops):
+            gather_bytes(buf.tobytes(), rank, world, dist)
+    g_dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([g_dt], dtype=torch.float64, device=comm_device(dist))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g_dt = float(t.item())
+    out["gather_ms"] = g_dt * 1e3
+    out["gather_what"] = "scores + path lengths + all ops (%.0f MB on this rank) fetched from the GPU%s; not part of `value`" % (
+        (g_scores.nbytes + g_nops.nbytes + g_ops.nbytes) / 1e6, " and moved to rank 0 in pair order (point to point)" if dist is not None else "")
+    r_scores, r_nops = g_scores, g_nops
+    batch.close()
+    if rank == 0 and world == 1 and with_e2e and not args.no_end_to_end:
         # transfer-inclusive rate (never `value`): the same batch from pinned host buffers through pm_dp_stream_align
         # (segmented upload behind which the fill kernel runs, results back into pinned host arrays)
         pa, pb = dpm.PinnedArray(inputs.cols_a.shape, np.uint8), dpm.PinnedArray(inputs.cols_b.shape, np.uint8)
@@ -436,7 +545,6 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
             t0 = time.perf_counter()
             st.align(pin, ps.a, po.a, pn.a)
             best = min(best, time.perf_counter() - t0)
-        r_scores, _, r_nops = batch.fetch()
         out["end_to_end"] = {"value": cells / best / 1e9, "unit": "GCUPS", "ms": best * 1e3,
                              "what": "pm_dp_stream_align: pinned host columns in (%.0f MB), scores + paths out (%.0f MB), 4 upload segments; "
                                      "best of 3; results equal the resident batch's: %s"
@@ -445,44 +553,6 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
         st.close()
         for x in (pa, pb, ps, pn, po):
             x.close()
-    if with_cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # cpu_baseline leg: the oracle's scalar full-matrix aligner on a bounded sample of the same batch
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import pyoracle
-        la = np.diff(inputs.off_a)
-        lb = np.diff(inputs.off_b)
-        cum = np.cumsum(la * lb)
-        k = int(max(1, min(n, np.searchsorted(cum, 2.0e9) + 1)))  # about 2e9 cells: 10-15 s on one core
-        sample = slice_pairs(inputs, 0, k)
-        t0 = time.perf_counter()
-        o_scores, o_paths = pyoracle.dp_align(sample, params)
-        cpu_dt = time.perf_counter() - t0
-        scores, ops, n_ops = batch.fetch()
-        same = bool(np.array_equal(scores[:k], o_scores)) and all(
-            np.array_equal(p, q) for p, q in zip(batch.paths(ops, n_ops)[:k], o_paths))
-        sample_cells = int(cum[k - 1])
-        out["cpu_baseline"] = {"value": sample_cells / cpu_dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
-                               "sample": "first %d pairs of the same batch through oracle/dp_oracle.c (scalar C, scores + paths), %.1f s; "
-                                         "GPU results identical on the sample: %s" % (k, cpu_dt, same)}
-        nproc = host_cores()
-        if nproc > 1:
-            import multiprocessing as mp
-            from paramugsy_amd.shard import partition
-            kk = int(max(nproc, min(n, np.searchsorted(cum, 1.0e9 * nproc) + 1)))  # about 1e9 cells per core
-            payloads = []
-            for w_ in range(nproc):
-                lo, hi = partition(kk, nproc, w_)
-                sl = slice_pairs(inputs, lo, hi)
-                payloads.append((np.ascontiguousarray(sl.cols_a), sl.off_a, np.ascontiguousarray(sl.cols_b), sl.off_b,
-                                 list(params.sub), params.gap_open, params.gap_extend))
-            with mp.get_context("spawn").Pool(nproc) as pool:
-                t0 = time.perf_counter()
-                pool.map(_oracle_leg, payloads)
-                par_dt = time.perf_counter() - t0
-            out["cpu_baseline"]["all_cores"] = {"value": int(cum[kk - 1]) / par_dt / 1e9, "unit": "GCUPS", "cores": nproc, "nproc": nproc,
-                                                "sample": "first %d pairs as %d processes (one per host core), %.1f s wall incl. process start"
-                                                % (kk, nproc, par_dt)}
-    batch.close()
     return out
 
 
@@ -499,19 +569,24 @@ def main():
     if args.path in ("translate", "both"):
         tr = bench_translate(args, rank, world, local, torch, dist)
     dp = None
-    c1 = None
+    rides = {}
     if args.path in ("dp", "both"):
-        dp = bench_dp(args, args.config, rank, world, local, torch, dist, args.steps, args.warmup, True)
-        if args.config != "c1" and not args.no_c1 and args.scaling == "weak":
-            c1 = bench_dp(args, "c1", rank, world, local, torch, dist, max(args.steps, 20), args.warmup, False)
+        dp = bench_dp(args, args.config, rank, world, local, torch, dist, args.steps, args.warmup, True, True)
+        if not args.no_ride:
+            # the other BASELINE configurations, each with its own roofline and oracle-checked sample.  c1 is a one-GPU
+            # configuration: it rides along at N = 1 only (with its own cpu_baseline and transfer-inclusive rate)
+            for name in ("c1", "c2", "deep"):
+                if name == args.config or (name == "c1" and world > 1):
+                    continue
+                rides[name] = bench_dp(args, name, rank, world, local, torch, dist, max(args.steps, 20) if name == "c1" else args.steps,
+                                       args.warmup, name == "c1", name == "c1")
     main_part = dp if dp is not None else tr
     result.update(main_part)
     if os.environ.get("PM_BENCH_REHEARSAL") == "1":
         result["rehearsal"] = "every rank on device 0, gloo instead of RCCL: the numbers of this line mean nothing"
     result.update({"n_gpus": ran, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": args.scaling,
                    "vs_baseline": None, "data": "synthetic"})
-    if c1 is not None:
-        result["c1"] = c1
+    result.update(rides)
     if dp is not None and tr is not None:
         result["translate"] = tr
     if rank == 0:

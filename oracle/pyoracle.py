@@ -162,3 +162,38 @@ def dp_score_of_path(inputs, params, k, path):
     s = C.c_int32()
     rc = o.dp_oracle_score_of_path(a.ctypes.data, len(a), b.ctypes.data, len(b), C.byref(params), p.ctypes.data, len(p), C.byref(s))
     return rc, s.value
+
+
+# ---------------------------------------------------------------- tuned CPU scorer (oracle/dp_tuned.c): bench.py's cpu_baseline.tuned
+# Compiled on the machine it runs on (gcc -O3 -march=native), into a temporary directory: a -march=native object built in one
+# container must not travel to another CPU.
+
+_dp_tuned = None
+
+
+def dp_tuned_lib() -> C.CDLL:
+    global _dp_tuned
+    if _dp_tuned is None:
+        import subprocess
+        import tempfile
+        from paramugsy_amd.dp import PmDpParams
+        out = os.path.join(tempfile.mkdtemp(prefix="pm_dp_tuned_"), "libdp_tuned.so")
+        subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-o", out, os.path.join(_HERE, "dp_tuned.c")],
+                       check=True, capture_output=True)
+        o = C.CDLL(out)
+        o.dp_tuned_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(PmDpParams), C.c_void_p]
+        _dp_tuned = o
+    return _dp_tuned
+
+
+def dp_scores_tuned(inputs, params):
+    o = dp_tuned_lib()
+    scores = np.zeros(inputs.n_pairs, dtype=np.int32)
+    ca = np.ascontiguousarray(inputs.cols_a)
+    cb = np.ascontiguousarray(inputs.cols_b)
+    oa = np.ascontiguousarray(inputs.off_a, dtype=np.int64)
+    ob = np.ascontiguousarray(inputs.off_b, dtype=np.int64)
+    rc = o.dp_tuned_score_batch(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, inputs.n_pairs, C.byref(params),
+                                scores.ctypes.data)
+    assert rc == 0
+    return scores

@@ -78,9 +78,13 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 // read as agent-scope atomics (sc1: past the XCD's L2), ordered by the wave's own s_waitcnt vmcnt(0) -- agent-scope release /
 // acquire FENCES write back and invalidate the whole L2 of the XCD every time and made 128 pairs of 32 x 10 kbp 3.5x slower.
 // The host asks for this only while every workgroup can have a CU of its own (n * NG <= CUs).  No workgroup can wait for ever on
-// one that has not started: workgroups start in blockIdx order, a pair's are consecutive, earlier pairs never wait on later
-// ones and so finish and free their CUs, and the chip holds any one pair's (at most 16) workgroups at once; the bounded waits
-// above stay as the last line of defence.
+// one that has not started, by construction: a workgroup does not take its (pair, team slot) from blockIdx -- HIP promises no
+// dispatch order -- but from a ticket it draws at entry (the word after the progress words, zeroed with them).  The tickets
+// drawn so far are 0 .. T-1 and their workgroups have all started; a pair whose NG tickets are all below T has every one of its
+// waves running and depends on nothing else, so it finishes whatever the rest of the device is doing; the one pair that straddles
+// T holds fewer than NG <= 16 workgroups, which cannot fill the chip, so the dispatcher goes on starting workgroups and T
+// grows.  The bounded waits stay as the last line of defence, and a wave that finds *pipe_error set (by any wave of the grid)
+// stops waiting at once, so a failed launch drains in milliseconds instead of paying the time-out at every block.
 template <int C, int MODE, bool DOT4, int NW, bool UNI>
 __global__ void __launch_bounds__(64 * NW)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
@@ -98,10 +102,19 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const int lane = threadIdx.x & 63;
   int4 *ring = ring_all[wv];
   unsigned(*tbstage)[TBS] = tbstage_all[wv];
-  const int pos = ng > 1 ? (int)(blockIdx.x / (unsigned)ng) : (int)blockIdx.x;
-  const int team = NW * ng;                                              // waves of this pair
-  const int tw = ng > 1 ? wv * ng + (int)(blockIdx.x % (unsigned)ng) : wv; // this wave's place among them: consecutive stripes go to
-                                                                          // different workgroups
+  unsigned bid = blockIdx.x;
+  if(NW > 1 && ng > 1) { // the ticket (see above): the order in which workgroups START, whatever their blockIdx
+    __shared__ unsigned ticket;
+    if(threadIdx.x == 0) {
+      ticket = (unsigned)__hip_atomic_fetch_add(gprog + (i64)gridDim.x * NW, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    bid = ticket;
+  }
+  const int pos = ng > 1 ? (int)(bid / (unsigned)ng) : (int)bid;
+  const int team = NW * ng;                                     // waves of this pair
+  const int tw = ng > 1 ? wv * ng + (int)(bid % (unsigned)ng) : wv; // this wave's place among them: consecutive stripes go to
+                                                                 // different workgroups
   int *gp = ng > 1 ? gprog + (i64)pos * team : nullptr;
   const i64 pair = order[pos]; // the launch's pairs in processing order (dp_batch_plan)
   const i64 a0 = off_a[pair], b0 = off_b[pair];
@@ -172,6 +185,9 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           if(ng > 1) {
             int *word = gp + (s - 1) % team;
             while(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+              if((spins & 1023) == 0 && __hip_atomic_load(pipe_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                break; // the launch has already failed somewhere: do not wait, let the grid drain
+              }
               __builtin_amdgcn_s_sleep(4);
               if(++spins > (1 << 22)) {
                 if(lane == 0) {
@@ -185,6 +201,9 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           else {
             volatile int *word = &progress[(s - 1) % NW];
             while(*word < need) {
+              if((spins & 1023) == 0 && __hip_atomic_load(pipe_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                break;
+              }
               __builtin_amdgcn_s_sleep(2);
               if(++spins > (1 << 22)) {
                 if(lane == 0) {
@@ -1107,8 +1126,9 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
     }
   }
   if(ng > 1) {
-    PM_TRY(grow(h->gprog, (size_t)(n * ng * nw) * sizeof(int)));
-    PM_HIP(hipMemsetAsync(h->gprog.p, 0, (size_t)(n * ng * nw) * sizeof(int), stream));
+    // one progress word per wave of the launch, then the ticket counter the workgroups draw their places from
+    PM_TRY(grow(h->gprog, (size_t)(n * ng * nw + 1) * sizeof(int)));
+    PM_HIP(hipMemsetAsync(h->gprog.p, 0, (size_t)(n * ng * nw + 1) * sizeof(int), stream));
   }
 #define DP_LAUNCH_FILL(CC, TR, D4, NWV, UN)                                                                                                  \
   dp_fill_kernel<CC, TR, D4, NWV, UN><<<(unsigned)(n * ng), 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,    \
@@ -1347,6 +1367,7 @@ int pm_dp_batch_fetch(pm_dp_batch_t *h, int32_t *scores, uint8_t *ops, int32_t *
     int perr = 0;
     PM_HIP(hipMemcpy(&perr, h->pipe_error.p, 4, hipMemcpyDeviceToHost));
     if(perr) {
+      (void)hipMemset(h->pipe_error.p, 0, 4); // reported: the batch can be run again
       return fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
     }
   }

@@ -194,7 +194,8 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
     if(le > p && text[le - 1] == '\r') {
       --le;
     }
-    if(le > p + 1 && text[p] == 'a' && (text[p + 1] == ' ' || text[p + 1] == '\t')) {
+    // a block starts at an `a` line; the score after it is optional in MAF, so a line that is just `a` opens a block too
+    if((le == p + 1 && text[p] == 'a') || (le > p + 1 && text[p] == 'a' && (text[p + 1] == ' ' || text[p + 1] == '\t'))) {
       out.block_row.push_back((int64_t)out.rows.size());
       open = true;
     }

@@ -184,6 +184,8 @@ int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *
   }
   drain();
   if(!rc && s->host_words[8]) {
+    (void)hipMemset(b->pipe_error.p, 0, 4); // reported: the stream's batch is reused by the next call
+    s->host_words[8] = 0;
     rc = fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
   }
   return rc;

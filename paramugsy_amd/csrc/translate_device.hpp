@@ -395,6 +395,9 @@ struct Sink {
   int disorder;  // COUNT: a gap arrived out of the writer's merge order
   i64 *fix;      // FIX pass: the open segment's gaps in arrival order, two words each {start << 1 | row, end}; else nullptr
   I fix_n;
+  I fix_cap;     // FIX pass: gaps the scratch list holds (the unit's offset count + 1).  A gap owns at least one offset of
+                 // its segment, so a segment that commits never holds more; one that is later dropped may, and the
+                 // gaps past the cap are then simply not recorded (nothing ever reads them)
 
   PM_HD __forceinline__ void put(I v) {
     if(EMIT && !fix) {
@@ -409,7 +412,7 @@ struct Sink {
     if(!EMIT && pend > 0 && (g.s < last_start || (g.s == last_start && last_row == 0 && row == 1))) {
       disorder = 1;
     }
-    if(EMIT && fix) {
+    if(EMIT && fix && fix_n < fix_cap) {
       fix[2 * (i64)fix_n] = (i64)g.s * 2 + row;
       fix[2 * (i64)fix_n + 1] = (i64)g.e;
       ++fix_n;
@@ -461,7 +464,8 @@ struct Sink {
       const i64 gs = fix[2 * (i64)k] >> 1, ge = fix[2 * (i64)k + 1];
       const I sign = take_ref ? -1 : 1;
       fix_write(at, (I)(sign * (gs - column)));
-      for(i64 n = ge - gs; n > 0; --n) {
+      // the gap's remaining columns: length - 1 = |e - s|, as the COUNT and EMIT passes count them (M_range::length)
+      for(i64 n = gs <= ge ? ge - gs : gs - ge; n > 0; --n) {
         fix_write(at, sign);
       }
       column = ge;

@@ -242,10 +242,16 @@ static bool read_side_soa(const std::string &dir, Side &side) {
   if(n < 0 || g < 0 || nb < 0 || head[3] != (long long)st_txt.st_size) {
     return false;
   }
+  // counts the file cannot hold would wrap `need` below: bound them by the file's size first
+  const long long words = (long long)(blob.size() / 8);
+  if(n > words || g > words || nb > (long long)blob.size()) {
+    return false;
+  }
   const size_t need = 40 + (size_t)(3 * n + (n + 1) + 2 * g) * 8 + (size_t)nb;
   if(blob.size() != need) {
     return false;
   }
+  try {
   Side s;
   const char *p = blob.data() + 40;
   auto get = [&](std::vector<long long> &v, long long count) {
@@ -261,6 +267,11 @@ static bool read_side_soa(const std::string &dir, Side &side) {
   get(s.gap_end, g);
   if(s.gap_off[0] != 0 || s.gap_off[(size_t)n] != g) {
     return false;
+  }
+  for(long long r = 0; r < n; ++r) { // the offsets index the gap arrays on the device: a damaged file must not get that far
+    if(s.gap_off[(size_t)r] > s.gap_off[(size_t)r + 1]) {
+      return false;
+    }
   }
   const char *e = blob.data() + blob.size();
   s.major.reserve((size_t)n);
@@ -281,6 +292,10 @@ static bool read_side_soa(const std::string &dir, Side &side) {
   }
   side = std::move(s);
   return true;
+  }
+  catch(const std::exception &) { // out of memory while copying: the text file is still there
+    return false;
+  }
 }
 
 int load_side(const std::string &dir, Side &side) {

@@ -249,12 +249,14 @@ translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, cons
   sink.disorder = 0;
   sink.fix = fix;
   sink.fix_n = 0;
+  sink.fix_cap = 0;
   if(EMIT) {
     sink.ent = entries + ent_off[u];
     sink.ent_cap = (I)(ent_off[u + 1] - ent_off[u]);
     sink.off = offsets;
     sink.off_base = off_off[u];
     sink.off_cap = (I)(off_off[u + 1] - off_off[u]);
+    sink.fix_cap = sink.off_cap + 1; // the scratch list is 2 * (offsets of the unit) + 2 words (pm_job_create)
   }
   const int d = u_delta[u], l = u_left[u], r = u_right[u];
   if constexpr(EMIT) {

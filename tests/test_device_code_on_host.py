@@ -158,3 +158,23 @@ def test_int_path_near_its_entry_limit(harness, oracle_build, tmp_path):
     for narrow in (False, True):
         st = check_against_oracle(harness, t, narrow)
         assert st is not None and (st == 0).all()
+
+
+@pytest.mark.parametrize("narrow", [False, True])
+def test_dropped_segment_with_more_gaps_than_the_unit_has_offsets(narrow, harness, oracle_build):
+    """The FIX pass's scratch list holds (offsets of the unit + 1) gaps: enough for every segment that commits, because a gap
+    owns at least one of its segment's offsets.  A segment that is dropped (b_finish does not commit) can hold more: twenty
+    adjacent one-column gaps in the entry's reference row right where the left row has its own gap, and a column gapped in
+    both rows further on that sends the unit to the FIX pass.  The recording stops at the cap (under ASAN, PM_HARNESS_SANITIZE=1,
+    an unbounded list wrote past the scratch here) and the unit's output equals the oracle's."""
+    from paramugsy_amd.translate import Tables
+    i64 = lambda *v: np.array(v, dtype=np.int64)
+    left = {"start": i64(1), "end": i64(199), "length": i64(200), "gap_off": i64(0, 1), "gap_start": i64(41), "gap_end": i64(41)}
+    right = {"start": i64(1), "end": i64(199), "length": i64(200), "gap_off": i64(0, 1), "gap_start": i64(61), "gap_end": i64(61)}
+    ref_gaps = list(range(41, 61)) + [90]
+    deltas = {"ref_start": i64(1), "ref_end": i64(150), "qry_start": i64(1), "qry_end": i64(170),
+              "ref_gap_off": i64(0, len(ref_gaps)), "ref_gap_start": i64(*ref_gaps), "ref_gap_end": i64(*ref_gaps),
+              "qry_gap_off": i64(0, 1), "qry_gap_start": i64(90), "qry_gap_end": i64(90)}
+    z = np.zeros(1, dtype=np.int32)
+    t = Tables(left, right, deltas, {"delta": z, "left": z, "right": z})
+    check_against_oracle(harness, t, narrow)

@@ -184,3 +184,18 @@ def test_align_maf_files_end_to_end(oracle_build, tmp_path):
     dp.align_maf_files(pa, pb, params, po)
     got = ora.parse_maf(po)
     assert len(got) == 2 and got[0][1] == [b"ACG"] and got[1][1] == [b"ACGT", b"ACGT"]
+
+
+@pytest.mark.gpu
+def test_score_less_a_lines_open_blocks(oracle_build, tmp_path):
+    """The score after `a` is optional in MAF: a line that is just `a` (also with a trailing CR) starts a block, so the rows
+    that follow are not appended to the block before it and block k of A still meets block k of B."""
+    pa, pb, po = str(tmp_path / "a.maf"), str(tmp_path / "b.maf"), str(tmp_path / "out.maf")
+    with open(pa, "wb") as f:
+        f.write(b"##maf version=1\na\ns L.g0 0 4 + 100 ACGT\n\na\r\ns L.g0 9 3 + 100 TTG\r\n\n")
+    with open(pb, "wb") as f:
+        f.write(b"a score=1\ns R.g0 0 4 + 100 ACGT\n\na\ns R.g0 7 3 + 100 TTG\n\n")
+    dp.align_maf_files(pa, pb, dp.make_params(1, 1), po)
+    got = ora.parse_maf(po)
+    assert len(got) == 2
+    assert got[0][1] == [b"ACGT", b"ACGT"] and got[1][1] == [b"TTG", b"TTG"]

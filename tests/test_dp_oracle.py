@@ -86,3 +86,22 @@ def test_pack_profile_counts():
     import pytest
     with pytest.raises(ValueError):
         dp.pack_profile([b"A"] * 256)
+
+
+def test_tuned_cpu_scorer_equals_the_oracle(oracle_build):
+    """oracle/dp_tuned.c (bench.py's cpu_baseline.tuned: skewed two-row recurrence, 16 pairs of one shape per SIMD vector) gives
+    the oracle's scores: groups of equal shape (the vector path), ragged pairs, empty profiles, a tail shorter than a vector."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    import pyoracle
+    for inputs, rows in ((dp.synth_batch(11, np.full(37, 300), np.full(37, 280), 5, 5), (5, 5)),
+                         (dp.synth_pairs(12, 20, 2, 150, vary_length=True), (2, 2))):
+        p = dp.make_params(*rows)
+        assert np.array_equal(pyoracle.dp_scores_tuned(inputs, p), pyoracle.dp_scores(inputs, p))
+    la, lb = dp.ragged_lengths(13, 30, median=200, lo=1, hi=900)
+    la[3] = 0
+    lb[9] = 0
+    inputs = dp.synth_batch(14, la, lb, 3, 6)
+    p = dp.make_params(3, 6, open_per_pair=11, extend_per_pair=1)
+    assert np.array_equal(pyoracle.dp_scores_tuned(inputs, p), pyoracle.dp_scores(inputs, p))

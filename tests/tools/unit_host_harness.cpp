@@ -189,6 +189,7 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
       fx.off_base = oo[u];
       fx.off_cap = (I)(oo[u + 1] - oo[u]);
       fx.fix = scratch.data();
+      fx.fix_cap = fx.off_cap + 1;
       st = run_unit<true>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], fx);
       if(st != status[u]) {
         return 2;
