@@ -177,9 +177,12 @@ def dp_tuned_lib() -> C.CDLL:
         import subprocess
         import tempfile
         from paramugsy_amd.dp import PmDpParams
-        out = os.path.join(tempfile.mkdtemp(prefix="pm_dp_tuned_"), "libdp_tuned.so")
-        subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-o", out, os.path.join(_HERE, "dp_tuned.c")],
-                       check=True, capture_output=True)
+        out = os.environ.get("PM_DP_TUNED_SO", "")  # built by a parent process on this machine (bench.py's worker pool)
+        if not (out and os.path.exists(out)):
+            out = os.path.join(tempfile.mkdtemp(prefix="pm_dp_tuned_"), "libdp_tuned.so")
+            subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-o", out, os.path.join(_HERE, "dp_tuned.c")],
+                           check=True, capture_output=True)
+            os.environ["PM_DP_TUNED_SO"] = out
         o = C.CDLL(out)
         o.dp_tuned_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(PmDpParams), C.c_void_p]
         _dp_tuned = o

@@ -24,6 +24,7 @@
 #include <thread>
 #include <vector>
 
+#include "multi.hpp"
 #include "pm_internal.hpp"
 #include "translate_host.hpp"
 
@@ -603,7 +604,7 @@ static void format_units(size_t u0, size_t u1, const Side &left, const Side &rig
 // header rule, which only needs the names of the last entry printed before a unit: the units are cut into slices of
 // about equal output, every slice is formatted by its own thread from the header names in force at its start, and
 // the slices are written in order.
-int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
+int write_results(OutSink sink, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
                   const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string &last_left,
                   std::string &last_right) {
   const size_t U = units.delta.size();
@@ -660,7 +661,7 @@ int write_results(FILE *f, const Side &left, const Side &right, const UnitList &
     }
   }
   for(size_t s = 0; s < n_slices; ++s) {
-    if(!text[s].empty() && fwrite(text[s].data(), 1, text[s].size(), f) != text[s].size()) {
+    if(!text[s].empty() && !sink.write(text[s].data(), text[s].size())) {
       return fail(PM_E_IO, "write failed");
     }
   }
@@ -807,6 +808,11 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
 
 // The device part of a translate job and the text of its output: upload + prepare + sizing, one pass, fetch, format + write.
 int run_workload(Workload &w, FILE *out, int device) {
+  return run_tables(w.left, w.right, w.table, w.units, w.parse_rc, w.parse_msg, OutSink(out), device);
+}
+
+int run_tables(const Side &left, const Side &right, const DeltaTable &table, const UnitList &units, int parse_rc, const std::string &parse_msg,
+               OutSink out, int device) {
   const bool timing = getenv("PM_TIMING") != nullptr;
   auto now = []() {
     timespec ts;
@@ -815,11 +821,14 @@ int run_workload(Workload &w, FILE *out, int device) {
   };
   double t1 = now();
   std::string last_left, last_right;
-  if(!w.units.delta.empty()) {
-    pm_rows_t lv, rv;
-    pm_deltas_t dv;
+  if(!units.delta.empty()) {
+    pm_rows_t lv = rows_view(left), rv = rows_view(right);
+    pm_deltas_t dv = deltas_view(table);
     pm_units_t uv;
-    workload_views(w, &lv, &rv, &dv, &uv);
+    uv.n = (int64_t)units.delta.size();
+    uv.delta = units.delta.data();
+    uv.left = units.left.data();
+    uv.right = units.right.data();
     pm_job_t *job = nullptr;
     PM_TRY(pm_job_create(&lv, &rv, &dv, &uv, device, &job));
     double t2 = now();
@@ -852,17 +861,138 @@ int run_workload(Workload &w, FILE *out, int device) {
       return rc;
     }
     double t4 = now();
-    PM_TRY(write_results(out, w.left, w.right, w.units, status.data(), ent_off.data(), entries.data(), offsets.data(), last_left,
-                         last_right));
+    PM_TRY(write_results(out, left, right, units, status.data(), ent_off.data(), entries.data(), offsets.data(), last_left, last_right));
     if(timing) {
       fprintf(stderr, "[pm] device init + upload + prepare + sizing: %.3f s; run: %.4f s; fetch: %.3f s; format + write: %.3f s\n", t2 - t1,
               t3 - t2, t4 - t3, now() - t4);
     }
   }
-  if(w.parse_rc) {
-    return fail(w.parse_rc, w.parse_msg);
+  if(parse_rc) {
+    return fail(parse_rc, parse_msg);
   }
   return PM_OK;
+}
+
+// ------------------------------------------------------------------ several devices (multi.hpp)
+
+// The header names (first two tokens after '>') of a delta header line [b, e).
+static void header_names(const char *b, const char *e, std::string &l, std::string &r) {
+  const char *p = b + 1, *tb, *te;
+  l.clear();
+  r.clear();
+  if(next_token(p, e, tb, te)) {
+    l.assign(tb, te);
+    if(next_token(p, e, tb, te)) {
+      r.assign(tb, te);
+    }
+  }
+}
+
+// Shard texts, each printed by a writer that started with no header in force (m_delta_stream_writer.hh:55-60), joined into what
+// ONE writer prints over the shards' entries in order: a shard's leading `>` line is dropped when the names in force at the end
+// of what precedes it are the same (the writer prints a header only when the name pair changes, m_delta_stream_writer.hh:62-67,
+// and keeps that state from one delta file to the next).
+int merge_shard_texts(const std::vector<std::string> &parts, size_t n_parts, OutSink out) {
+  std::string in_l, in_r; // names in force; the writer starts with ("", "")
+  bool have = false;
+  for(size_t k = 0; k < n_parts; ++k) {
+    const std::string &t = parts[k];
+    if(t.empty()) {
+      continue;
+    }
+    size_t from = 0;
+    if(t[0] == '>') {
+      const char *e = (const char *)memchr(t.data(), '\n', t.size());
+      const size_t line = e ? (size_t)(e - t.data()) + 1 : t.size();
+      std::string l, r;
+      header_names(t.data(), t.data() + line - (e ? 1 : 0), l, r);
+      if(have && l == in_l && r == in_r) {
+        from = line;
+      }
+    }
+    if(!out.write(t.data() + from, t.size() - from)) {
+      return fail(PM_E_IO, "write failed");
+    }
+    // the last header line of this shard is in force for the next
+    size_t at = std::string::npos;
+    for(size_t q = t.size(); q-- > 0;) {
+      if(t[q] == '>' && (q == 0 || t[q - 1] == '\n')) {
+        at = q;
+        break;
+      }
+    }
+    if(at != std::string::npos) {
+      const char *e = (const char *)memchr(t.data() + at, '\n', t.size() - at);
+      header_names(t.data() + at, e ? e : t.data() + t.size(), in_l, in_r);
+      have = true;
+    }
+  }
+  return PM_OK;
+}
+
+// Para_mugsy::translate over several devices: the delta-file list is cut into n_devices contiguous slices, every worker parses
+// and translates its slice on its device against the two sides (loaded once, shared read-only) and formats its text in memory;
+// the texts are joined in list order.  The reference dies at the first failure with everything before it on the stream: the
+// join stops after the first failing shard (its partial output included) and the call returns that shard's error.
+int translate_to_file_multi(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
+                            const int *devices, int n_devices) {
+  Side left, right;
+  {
+    // the two sides side by side; the devices' runtimes come up meanwhile
+    int rc_r = PM_OK;
+    std::string msg_r;
+    std::thread other([&]() {
+      rc_r = load_side(right_dir, right);
+      if(rc_r) {
+        msg_r = pm_last_error();
+      }
+      else {
+        build_side_index(right);
+      }
+    });
+    std::thread warm([&]() {
+      for(int k = 0; k < n_devices; ++k) {
+        (void)use_device(devices[k]);
+        (void)hipFree(nullptr);
+      }
+    });
+    int rc_l = load_side(left_dir, left);
+    if(!rc_l) {
+      build_side_index(left);
+    }
+    std::string msg_l = rc_l ? pm_last_error() : "";
+    other.join();
+    warm.join();
+    if(rc_l) {
+      return fail(rc_l, msg_l);
+    }
+    if(rc_r) {
+      return fail(rc_r, msg_r);
+    }
+  }
+  std::vector<std::string> text((size_t)n_devices);
+  std::vector<int> rcs;
+  int rc = run_on_devices(
+      devices, n_devices,
+      [&](int w, int device) {
+        int64_t lo, hi;
+        partition((int64_t)delta_paths.size(), n_devices, w, lo, hi);
+        Workload mine; // its sides stay empty: the shared ones are used
+        parse_deltas(std::vector<std::string>(delta_paths.begin() + lo, delta_paths.begin() + hi), mine);
+        enumerate_units(left, right, mine.table, 0, mine.units);
+        return run_tables(left, right, mine.table, mine.units, mine.parse_rc, mine.parse_msg, OutSink(&text[(size_t)w]), device);
+      },
+      &rcs);
+  std::string msg = rc ? pm_last_error() : "";
+  size_t upto = (size_t)n_devices;
+  for(size_t w = 0; w < rcs.size(); ++w) {
+    if(rcs[w]) {
+      upto = w + 1; // the failing shard's partial output is what the reference had written when it died
+      break;
+    }
+  }
+  PM_TRY(merge_shard_texts(text, upto, OutSink(out)));
+  return rc ? fail(rc, msg) : PM_OK;
 }
 
 } // namespace pm
@@ -891,6 +1021,39 @@ extern "C" int pm_translate_files(const char *left_dir, const char *right_dir, c
     rc = pm::fail(PM_E_IO, "close failed");
   }
   return rc;
+}
+
+extern "C" int pm_translate_files_multi(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
+                                        const char *out_path, const int *devices, int n_devices) {
+  if(!left_dir || !right_dir || !out_path || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
+    return pm::fail(PM_E_INVALID, "pm_translate_files_multi: null argument");
+  }
+  PM_TRY(pm::check_devices(devices, n_devices, "pm_translate_files_multi"));
+  std::vector<std::string> paths;
+  for(int k = 0; k < n_paths; ++k) {
+    if(!delta_paths[k]) {
+      return pm::fail(PM_E_INVALID, "pm_translate_files_multi: null path");
+    }
+    paths.push_back(delta_paths[k]);
+  }
+  FILE *f = fopen(out_path, "wb");
+  if(!f) {
+    return pm::fail(PM_E_IO, std::string("cannot open ") + out_path);
+  }
+  fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_dir, right_dir); // m_translate_main.cc:35-39
+  int rc = pm::translate_to_file_multi(left_dir, right_dir, paths, f, devices, n_devices);
+  if(fclose(f) != 0 && !rc) {
+    rc = pm::fail(PM_E_IO, "close failed");
+  }
+  return rc;
+}
+
+extern "C" int pm_partition(int64_t n_items, int n_parts, int part, int64_t *lo, int64_t *hi) {
+  if(n_items < 0 || n_parts < 1 || part < 0 || part >= n_parts || !lo || !hi) {
+    return pm::fail(PM_E_INVALID, "pm_partition: bad argument");
+  }
+  pm::partition(n_items, n_parts, part, *lo, *hi);
+  return PM_OK;
 }
 
 struct pm_workload {

@@ -48,7 +48,21 @@ int parse_delta_file(const std::string &path, DeltaTable &table);
 int parse_delta_text(const std::string &text, const std::string &label, DeltaTable &table);
 bool read_stream(FILE *f, std::string &out);
 void enumerate_units(const Side &left, const Side &right, const DeltaTable &table, size_t first_entry, UnitList &units);
-int write_results(FILE *f, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
+// Where a job's delta text goes: a stream, or a string in memory (a shard of a multi-device job, gathered by the caller).
+struct OutSink {
+  FILE *f = nullptr;
+  std::string *mem = nullptr;
+  OutSink(FILE *f_) : f(f_) {}
+  OutSink(std::string *m) : mem(m) {}
+  bool write(const char *p, size_t n) {
+    if(mem) {
+      mem->append(p, n);
+      return true;
+    }
+    return fwrite(p, 1, n, f) == n;
+  }
+};
+int write_results(OutSink out, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
                   const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string &last_left,
                   std::string &last_right);
 // <dir>/profiles.soa when it matches <dir>/profiles, else the text file (parse_profiles)
@@ -58,8 +72,17 @@ int load_deltas(const std::vector<std::string> &delta_paths, Workload &w);
 void parse_deltas(const std::vector<std::string> &delta_paths, Workload &w);
 void index_and_enumerate(Workload &w);
 int run_workload(Workload &w, FILE *out, int device);
+// The device part of a translate job over tables that are in place (the two sides may be shared, read-only, by several callers):
+// upload + prepare + sizing, one pass, fetch, format.  parse_rc / parse_msg: a delta-file parse failure to report after the
+// output of the entries read before it.
+int run_tables(const Side &left, const Side &right, const DeltaTable &table, const UnitList &units, int parse_rc, const std::string &parse_msg,
+               OutSink out, int device);
 int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w);
 void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units);
+// multi.hpp: the job's delta-file list over several devices, texts joined in list order (header rule re-applied at the seams)
+int merge_shard_texts(const std::vector<std::string> &parts, size_t n_parts, OutSink out);
+int translate_to_file_multi(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
+                            const int *devices, int n_devices);
 int translate_to_file(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
                       int device);
 

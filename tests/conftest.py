@@ -4,6 +4,15 @@ import sys
 
 import pytest
 
+# torch first: its wheel carries its own HIP runtime under the same soname as /opt/rocm's (libamdhip64.so.7), and the process
+# uses whichever is loaded first.  With libparamugsy_amd.so loaded first, torch's kernels meet a runtime they were not built
+# for ("no ROCm-capable device"); the other way round both work -- the order bench.py has.  (The executables under bin/ run on
+# /opt/rocm's runtime, so the suite exercises both.)
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover -- the CPU-side tests do not need it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
