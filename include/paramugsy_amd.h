@@ -286,6 +286,40 @@ int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_a, int64_t 
                        const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs, const pm_dp_params_t *params,
                        int32_t *scores, int32_t *merged_columns, uint8_t *out_text, int64_t out_capacity, int64_t *out_off, int device);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Several devices of one node behind one call (csrc/multi.hpp).  The host north_star names (OCaml behind a C ABI, or the CLI)
+ * cannot run one torch.distributed process per GPU; these entries take a device list instead: the job's independent items --
+ * pairs, blocks, delta files -- are cut into n_devices contiguous slices (pm_partition: the first n % parts slices hold one item
+ * more), one host thread and one HIP context per device run the single-device path on their slice, there is NO collective, and
+ * the outputs are gathered on the host in input order.  What this replaces in the reference: the chunked pair lists of
+ * lib/base/pm_job.ml:43-57,83-91 run as `run_size` concurrent OS processes (lib/base/queued_task_server.ml:57-66), whose outputs
+ * the order-sensitive writer concatenates (lib/profiles_lib/m_delta_stream_writer.hh:62-67).  The same device may be named more
+ * than once (its workers share it).  Results are byte for byte those of the single-device call.  If a worker fails the call
+ * fails with the error of the first failing slice (pm_last_error names the device).  New surface. */
+int pm_partition(int64_t n_items, int n_parts, int part, int64_t *lo, int64_t *hi);
+/* pm_translate_files over a device list: every worker parses and translates its slice of the delta-file list against the two
+ * sides (loaded once); the texts are joined in list order with the writer's header rule re-applied at the seams (a `>` line is
+ * printed only when the name pair changes).  On a failure the output holds what the reference had written when it died: the
+ * slices before the failing one and the failing slice's partial output. */
+int pm_translate_files_multi(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
+                             const char *out_path, const int *devices, int n_devices);
+/* Host only (no device): complete m_translate outputs over consecutive slices of one delta-file list (two header lines each) ->
+ * the file one run over the whole list prints; the join pm_translate_files_multi does in memory, for callers that shard across
+ * processes or nodes themselves (the reference's SGE driver, lib/base/sge_interface.ml:55-74). */
+int pm_delta_join_files(const char *const *part_paths, int n_parts, const char *out_path);
+/* pm_dp_stream_align over a device list: host columns in, scores / ops / n_ops out in pm_dp_batch_fetch's layout (every slice
+ * writes its results at its own place of the caller's arrays; ops == n_ops == NULL: scores only). */
+int pm_dp_align_multi(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
+                      const pm_dp_params_t *params, const int *devices, int n_devices, int32_t *scores, uint8_t *ops, int32_t *n_ops);
+/* pm_dp_align_blocks / pm_dp_align_maf over a device list: MAF blocks in, merged MAF blocks out in pair order -- north_star's
+ * "host-side gather of MAF blocks". */
+int pm_dp_align_blocks_multi(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a,
+                             const uint8_t *text_b, const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs,
+                             const pm_dp_params_t *params, const int *devices, int n_devices, int32_t *scores, int32_t *merged_columns,
+                             uint8_t *out_text, int64_t out_capacity, int64_t *out_off);
+int pm_dp_align_maf_multi(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, const int *devices,
+                          int n_devices);
+
 #ifdef __cplusplus
 }
 #endif

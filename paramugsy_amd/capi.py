@@ -58,6 +58,7 @@ EXPORTS = [
     "pm_dp_batch_create", "pm_dp_batch_run", "pm_dp_batch_run_profiled", "pm_dp_batch_fetch", "pm_dp_batch_info", "pm_dp_batch_chunks", "pm_dp_batch_variant", "pm_dp_batch_path_mode", "pm_dp_batch_destroy",
     "pm_dp_host_alloc", "pm_dp_host_free", "pm_dp_stream_create", "pm_dp_stream_align", "pm_dp_stream_destroy",
     "pm_dp_pack_maf", "pm_dp_emit_maf", "pm_dp_align_maf", "pm_dp_align_blocks",
+    "pm_partition", "pm_delta_join_files", "pm_translate_files_multi", "pm_dp_align_multi", "pm_dp_align_blocks_multi", "pm_dp_align_maf_multi",
 ]
 
 
@@ -103,6 +104,9 @@ def lib() -> C.CDLL:
         l.pm_maf_analyzer.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         l.pm_profiles_make.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         l.pm_untranslate.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+        l.pm_delta_join_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p]
+        l.pm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, _i64p, _i64p]
+        l.pm_translate_files_multi.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, _i32p, C.c_int]
         _lib = l
     return _lib
 

@@ -28,6 +28,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "dp_batch.hpp"
+#include "multi.hpp"
 #include "dp_internal.hpp"
 #include "pm_internal.hpp"
 
@@ -398,6 +399,65 @@ int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_ro
 
 } // extern "C"
 
+// The MAF file of the merged blocks: `a score=<DP score>`, then A's rows and B's rows, every `s` line keeping its leading fields;
+// merged_of(k) = the text of merged block k (rows x n_ops[k] bytes, A's rows first).
+static int write_merged_maf(const char *out_maf, const MafDpBlocks &A, const MafDpBlocks &B, int64_t n, const std::vector<int32_t> &scores,
+                            const std::vector<int32_t> &n_ops, const std::function<const uint8_t *(int64_t)> &merged_of) {
+  FILE *f = fopen(out_maf, "wb");
+  if(!f) {
+    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
+  }
+  bool ok = true;
+  std::string o = "##maf version=1 scoring=paramugsy_amd\n";
+  for(int64_t k = 0; k < n; ++k) {
+    o += "a score=" + std::to_string(scores[(size_t)k]) + "\n";
+    const int64_t ra = A.block_row[k + 1] - A.block_row[k], rb = B.block_row[k + 1] - B.block_row[k];
+    const int64_t len = n_ops[(size_t)k];
+    const uint8_t *text = merged_of(k);
+    for(int64_t r = 0; r < ra + rb; ++r) {
+      const MafDpRow &row = r < ra ? A.rows[(size_t)(A.block_row[k] + r)] : B.rows[(size_t)(B.block_row[k] + r - ra)];
+      o += row.head;
+      o += ' ';
+      o.append((const char *)text + r * len, (size_t)len);
+      o += '\n';
+    }
+    o += '\n';
+    if(o.size() > (1u << 22)) {
+      ok = ok && fwrite(o.data(), 1, o.size(), f) == o.size();
+      o.clear();
+    }
+  }
+  ok = ok && fwrite(o.data(), 1, o.size(), f) == o.size();
+  if(fclose(f) != 0 || !ok) {
+    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
+  }
+  return PM_OK;
+}
+
+// Both files parsed side by side; each parser reports through its own return value (pm_last_error is per thread).
+static int parse_two_mafs(const char *maf_a, const char *maf_b, MafDpBlocks &A, MafDpBlocks &B, const char *who) {
+  int rc_b = PM_OK;
+  std::string err_b;
+  std::thread other([&]() {
+    rc_b = parse_maf_blocks(maf_b, B);
+    if(rc_b) {
+      err_b = pm_last_error();
+    }
+  });
+  const int rc_a = parse_maf_blocks(maf_a, A);
+  other.join();
+  if(rc_a) {
+    return rc_a;
+  }
+  if(rc_b) {
+    return fail(rc_b, err_b);
+  }
+  if(A.block_row.size() != B.block_row.size()) {
+    return fail(PM_E_INVALID, std::string(who) + ": the two MAF files must hold the same number of blocks (pair k = block k of each)");
+  }
+  return PM_OK;
+}
+
 // Blocks in, merged blocks out, through the device once: texts up, pack, DP, expansion along the paths, merged texts down.
 // scores / n_ops: n values each (n_ops[k] = columns of merged block k); out_off: n + 1 byte offsets into `merged`.
 static int align_blocks_core(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a, const uint8_t *text_b,
@@ -485,61 +545,15 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
     }
   };
   MafDpBlocks A, B;
-  {
-    // the two files are parsed side by side; each parser reports through its own return value (pm_last_error is per thread)
-    int rc_b = PM_OK;
-    std::string err_b;
-    std::thread other([&]() {
-      rc_b = parse_maf_blocks(maf_b, B);
-      if(rc_b) {
-        err_b = pm_last_error();
-      }
-    });
-    const int rc_a = parse_maf_blocks(maf_a, A);
-    other.join();
-    if(rc_a) {
-      return rc_a;
-    }
-    if(rc_b) {
-      return fail(rc_b, err_b);
-    }
-  }
+  PM_TRY(parse_two_mafs(maf_a, maf_b, A, B, "pm_dp_align_maf"));
   const int64_t n = (int64_t)A.block_row.size() - 1;
-  if(n != (int64_t)B.block_row.size() - 1) {
-    return fail(PM_E_INVALID, "pm_dp_align_maf: the two MAF files must hold the same number of blocks (pair k = block k of each)");
-  }
   lap("parse (two threads)");
   std::vector<int32_t> scores, n_ops;
   std::vector<uint8_t> merged;
   std::vector<int64_t> out_off;
   PM_TRY(align_blocks_core((const uint8_t *)A.text.data(), A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(), (const uint8_t *)B.text.data(),
                            B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, params, device, scores, n_ops, merged, out_off, lap));
-  FILE *f = fopen(out_maf, "wb");
-  if(!f) {
-    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
-  }
-  std::string o = "##maf version=1 scoring=paramugsy_amd\n";
-  for(int64_t k = 0; k < n; ++k) {
-    o += "a score=" + std::to_string(scores[(size_t)k]) + "\n";
-    const int64_t ra = A.block_row[k + 1] - A.block_row[k], rb = B.block_row[k + 1] - B.block_row[k];
-    const int64_t len = n_ops[(size_t)k];
-    for(int64_t r = 0; r < ra + rb; ++r) {
-      const MafDpRow &row = r < ra ? A.rows[(size_t)(A.block_row[k] + r)] : B.rows[(size_t)(B.block_row[k] + r - ra)];
-      o += row.head;
-      o += ' ';
-      o.append((const char *)merged.data() + out_off[(size_t)k] + r * len, (size_t)len);
-      o += '\n';
-    }
-    o += '\n';
-    if(o.size() > (1u << 22)) {
-      fwrite(o.data(), 1, o.size(), f);
-      o.clear();
-    }
-  }
-  fwrite(o.data(), 1, o.size(), f);
-  if(fclose(f) != 0) {
-    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
-  }
+  PM_TRY(write_merged_maf(out_maf, A, B, n, scores, n_ops, [&](int64_t k) { return merged.data() + out_off[(size_t)k]; }));
   lap("write");
   return PM_OK;
 }
@@ -571,4 +585,129 @@ extern "C" int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_
     memcpy(out_text, merged.data(), (size_t)off[(size_t)n_pairs]);
   }
   return PM_OK;
+}
+
+// ------------------------------------------------------------------ several devices (multi.hpp)
+
+// Pairs [lo, hi) of a flat block description as a description of their own (tables rebased to 0; the text is not copied).
+struct BlockSlice {
+  const uint8_t *text;
+  std::vector<int64_t> row_off, block_row;
+  int64_t n_rows;
+  BlockSlice(const uint8_t *t, const int64_t *ro, const int64_t *br, int64_t lo, int64_t hi) {
+    const int64_t r0 = br[lo], r1 = br[hi];
+    n_rows = r1 - r0;
+    text = t ? t + ro[r0] : nullptr;
+    row_off.resize((size_t)n_rows + 1);
+    for(int64_t r = r0; r <= r1; ++r) {
+      row_off[(size_t)(r - r0)] = ro[r] - ro[r0];
+    }
+    block_row.resize((size_t)(hi - lo) + 1);
+    for(int64_t k = lo; k <= hi; ++k) {
+      block_row[(size_t)(k - lo)] = br[k] - r0;
+    }
+  }
+};
+
+// pack -> DP -> expansion of the pairs' contiguous slices on their devices; worker w's merged texts stay in merged[w], its scores
+// and merged widths go to their places in the whole job's arrays, part_off[w] = the slice's own text offsets (n_w + 1 values).
+static int align_blocks_multi_core(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a,
+                                   const uint8_t *text_b, const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n,
+                                   const pm_dp_params_t *params, const int *devices, int n_devices, std::vector<int32_t> &scores,
+                                   std::vector<int32_t> &n_ops, std::vector<std::vector<uint8_t> > &merged,
+                                   std::vector<std::vector<int64_t> > &part_off) {
+  PM_TRY(check_blocks(row_off_a, n_rows_a, block_row_a, n, "pm_dp_align (A)"));
+  PM_TRY(check_blocks(row_off_b, n_rows_b, block_row_b, n, "pm_dp_align (B)"));
+  scores.assign((size_t)n, 0);
+  n_ops.assign((size_t)n, 0);
+  merged.assign((size_t)n_devices, std::vector<uint8_t>());
+  part_off.assign((size_t)n_devices, std::vector<int64_t>(1, 0));
+  return run_on_devices(devices, n_devices, [&](int w, int device) {
+    int64_t lo, hi;
+    partition(n, n_devices, w, lo, hi);
+    if(hi <= lo) {
+      return (int)PM_OK;
+    }
+    BlockSlice sa(text_a, row_off_a, block_row_a, lo, hi), sb(text_b, row_off_b, block_row_b, lo, hi);
+    std::vector<int32_t> s, m;
+    PM_TRY(align_blocks_core(sa.text, sa.row_off.data(), sa.n_rows, sa.block_row.data(), sb.text, sb.row_off.data(), sb.n_rows, sb.block_row.data(),
+                             hi - lo, params, device, s, m, merged[(size_t)w], part_off[(size_t)w], [](const char *) {}));
+    memcpy(scores.data() + lo, s.data(), (size_t)(hi - lo) * 4);
+    memcpy(n_ops.data() + lo, m.data(), (size_t)(hi - lo) * 4);
+    return (int)PM_OK;
+  });
+}
+
+extern "C" int pm_dp_align_blocks_multi(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a,
+                                        const uint8_t *text_b, const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b,
+                                        int64_t n_pairs, const pm_dp_params_t *params, const int *devices, int n_devices, int32_t *scores,
+                                        int32_t *merged_columns, uint8_t *out_text, int64_t out_capacity, int64_t *out_off) {
+  if(!row_off_a || !row_off_b || !block_row_a || !block_row_b || !params || !scores || !merged_columns || !out_off || n_pairs < 0 ||
+     (!out_text && out_capacity > 0)) {
+    return fail(PM_E_INVALID, "pm_dp_align_blocks_multi: null argument");
+  }
+  PM_TRY(check_devices(devices, n_devices, "pm_dp_align_blocks_multi"));
+  std::vector<int32_t> s, m;
+  std::vector<std::vector<uint8_t> > merged;
+  std::vector<std::vector<int64_t> > part_off;
+  PM_TRY(align_blocks_multi_core(text_a, row_off_a, n_rows_a, block_row_a, text_b, row_off_b, n_rows_b, block_row_b, n_pairs, params, devices,
+                                 n_devices, s, m, merged, part_off));
+  // the host-side gather: the slices' texts back to back, in pair order
+  out_off[0] = 0;
+  for(int w = 0; w < n_devices; ++w) {
+    int64_t lo, hi;
+    partition(n_pairs, n_devices, w, lo, hi);
+    for(int64_t k = lo; k < hi; ++k) {
+      out_off[k + 1] = out_off[lo] + part_off[(size_t)w][(size_t)(k - lo) + 1];
+    }
+  }
+  if(n_pairs > 0) {
+    memcpy(scores, s.data(), (size_t)n_pairs * 4);
+    memcpy(merged_columns, m.data(), (size_t)n_pairs * 4);
+  }
+  if(out_off[n_pairs] > out_capacity) {
+    return fail(PM_E_INVALID, "pm_dp_align_blocks_multi: out_text holds " + std::to_string(out_capacity) + " bytes, the merged blocks need " +
+                                  std::to_string(out_off[n_pairs]));
+  }
+  for(int w = 0; w < n_devices; ++w) {
+    int64_t lo, hi;
+    partition(n_pairs, n_devices, w, lo, hi);
+    const int64_t bytes = out_off[hi] - out_off[lo];
+    if(bytes > 0) {
+      memcpy(out_text + out_off[lo], merged[(size_t)w].data(), (size_t)bytes);
+    }
+  }
+  return PM_OK;
+}
+
+extern "C" int pm_dp_align_maf_multi(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, const int *devices,
+                                     int n_devices) {
+  if(!maf_a || !maf_b || !params || !out_maf) {
+    return fail(PM_E_INVALID, "pm_dp_align_maf_multi: null argument");
+  }
+  PM_TRY(check_devices(devices, n_devices, "pm_dp_align_maf_multi"));
+  MafDpBlocks A, B;
+  PM_TRY(parse_two_mafs(maf_a, maf_b, A, B, "pm_dp_align_maf_multi"));
+  const int64_t n = (int64_t)A.block_row.size() - 1;
+  std::vector<int32_t> scores, n_ops;
+  std::vector<std::vector<uint8_t> > merged;
+  std::vector<std::vector<int64_t> > part_off;
+  PM_TRY(align_blocks_multi_core((const uint8_t *)A.text.data(), A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(),
+                                 (const uint8_t *)B.text.data(), B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, params, devices,
+                                 n_devices, scores, n_ops, merged, part_off));
+  // merged block k lives in the buffer of the worker whose slice holds pair k
+  std::vector<int> owner((size_t)n);
+  std::vector<int64_t> first((size_t)n_devices + 1, n);
+  for(int w = 0; w < n_devices; ++w) {
+    int64_t lo, hi;
+    partition(n, n_devices, w, lo, hi);
+    first[(size_t)w] = lo;
+    for(int64_t k = lo; k < hi; ++k) {
+      owner[(size_t)k] = w;
+    }
+  }
+  return write_merged_maf(out_maf, A, B, n, scores, n_ops, [&](int64_t k) {
+    const int w = owner[(size_t)k];
+    return (const uint8_t *)merged[(size_t)w].data() + part_off[(size_t)w][(size_t)(k - first[(size_t)w])];
+  });
 }

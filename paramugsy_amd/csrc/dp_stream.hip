@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "dp_batch.hpp"
+#include "multi.hpp"
 
 using namespace pm;
 
@@ -197,6 +198,54 @@ void pm_dp_stream_destroy(pm_dp_stream_t *s) {
   }
   (void)hipSetDevice(s->device);
   delete s;
+}
+
+// The same over several devices of one node (multi.hpp): the pairs are cut into n_devices contiguous slices, every worker feeds its
+// slice to its device through a pm_dp_stream of its own and writes its results straight into the caller's arrays at the slice's
+// place -- pair k's scores[k], n_ops[k] and ops slot are where pm_dp_stream_align / pm_dp_batch_fetch put them, so the "gather"
+// is the layout itself.  Workers that share a device (the same index named twice) share its workspace budget.
+int pm_dp_align_multi(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
+                      const pm_dp_params_t *params, const int *devices, int n_devices, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
+  if(n_pairs < 0 || !off_a || !off_b || !params || !scores || (n_pairs > 0 && (!cols_a || !cols_b))) {
+    return fail(PM_E_INVALID, "pm_dp_align_multi: null argument");
+  }
+  if((ops == nullptr) != (n_ops == nullptr)) {
+    return fail(PM_E_INVALID, "pm_dp_align_multi: ops and n_ops go together");
+  }
+  if(off_a[0] != 0 || off_b[0] != 0) {
+    return fail(PM_E_INVALID, "pm_dp_align_multi: offsets must start at 0");
+  }
+  PM_TRY(check_devices(devices, n_devices, "pm_dp_align_multi"));
+  PM_TRY(dp_batch_check_params(params));
+  return run_on_devices(devices, n_devices, [&](int w, int device) {
+    int64_t lo, hi;
+    partition(n_pairs, n_devices, w, lo, hi);
+    if(hi <= lo) {
+      return (int)PM_OK;
+    }
+    int sharing = 0;
+    for(int k = 0; k < n_devices; ++k) {
+      sharing += devices[k] == device;
+    }
+    int64_t workspace = 0; // the library's default: 96 GiB, at most 40 % of the device's memory
+    if(sharing > 1) {
+      size_t free_b = 0, total_b = 0;
+      PM_HIP(hipMemGetInfo(&free_b, &total_b));
+      workspace = std::min<int64_t>((int64_t)96 << 30, (int64_t)(total_b / 10 * 4)) / sharing;
+    }
+    std::vector<int64_t> oa((size_t)(hi - lo) + 1), ob((size_t)(hi - lo) + 1);
+    for(int64_t k = lo; k <= hi; ++k) {
+      oa[(size_t)(k - lo)] = off_a[k] - off_a[lo];
+      ob[(size_t)(k - lo)] = off_b[k] - off_b[lo];
+    }
+    pm_dp_stream_t *st = nullptr;
+    PM_TRY(pm_dp_stream_create(params, 4, workspace, device, &st));
+    int rc = pm_dp_stream_align(st, cols_a + off_a[lo] * 8, oa.data(), cols_b + off_b[lo] * 8, ob.data(), hi - lo, scores + lo,
+                                ops ? ops + off_a[lo] + off_b[lo] : nullptr, n_ops ? n_ops + lo : nullptr);
+    std::string msg = rc ? pm_last_error() : "";
+    pm_dp_stream_destroy(st);
+    return rc ? fail(rc, msg) : (int)PM_OK;
+  });
 }
 
 } // extern "C"

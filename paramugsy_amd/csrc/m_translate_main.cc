@@ -1,6 +1,7 @@
 // m_translate_main.cc -- the drop-in executable.  Same argv, same exit behaviour and same output bytes as
 // the reference's lib/m_translate/m_translate_main.cc:19-46; the work runs on the GPU through the C ABI.
-// Optional: PARAMUGSY_DEVICE=<n> selects the HIP device (default 0).
+// Optional: PARAMUGSY_DEVICE=<n> selects the HIP device (default 0); PARAMUGSY_DEVICES=0,1,... spreads the delta-file list over
+// several devices of the node (pm_translate_files_multi; the argv stays the reference's).
 #include <cstdio>
 #include <unistd.h>
 #include <cstdlib>
@@ -29,7 +30,20 @@ int main(int argc, char **argv) {
   }
   const char *dev_env = getenv("PARAMUGSY_DEVICE");
   int device = dev_env ? atoi(dev_env) : 0;
-  int rc = pm_translate_files(argv[1], argv[2], cpaths.data(), (int)cpaths.size(), argv[4], device);
+  std::vector<int> devs;
+  if(const char *list = getenv("PARAMUGSY_DEVICES")) {
+    for(const char *p = list; *p;) {
+      char *end = nullptr;
+      long v = strtol(p, &end, 10);
+      if(end == p) {
+        break;
+      }
+      devs.push_back((int)v);
+      p = *end == ',' ? end + 1 : end;
+    }
+  }
+  int rc = devs.size() > 1 ? pm_translate_files_multi(argv[1], argv[2], cpaths.data(), (int)cpaths.size(), argv[4], devs.data(), (int)devs.size())
+                           : pm_translate_files(argv[1], argv[2], cpaths.data(), (int)cpaths.size(), argv[4], devs.size() == 1 ? devs[0] : device);
   if(rc != PM_OK) {
     fprintf(stderr, "m_translate: error %d: %s\n", rc, pm_last_error());
     // the reference ends in SIGABRT (uncaught exception / assert) on every failure past argument checking

@@ -44,6 +44,25 @@ static std::vector<std::string> read_list(const std::string &path) {
   return out;
 }
 
+// "0,1,2" -> {0, 1, 2}; empty when the text is empty or malformed
+static std::vector<int> parse_devices(const std::string &text) {
+  std::vector<int> out;
+  size_t at = 0;
+  while(at < text.size()) {
+    size_t e = text.find(',', at);
+    if(e == std::string::npos) {
+      e = text.size();
+    }
+    const std::string tok = text.substr(at, e - at);
+    if(tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) {
+      return std::vector<int>();
+    }
+    out.push_back(atoi(tok.c_str()));
+    at = e + 1;
+  }
+  return out;
+}
+
 // One command; returns the process exit code it stands for (0 ok, 2 = uncaught OCaml exception / bad flags).
 static int run_command(const std::string &cmd, std::map<std::string, std::string> &flag, int device) {
   int rc;
@@ -65,8 +84,53 @@ static int run_command(const std::string &cmd, std::map<std::string, std::string
     for(size_t k = 0; k < paths.size(); ++k) {
       cpaths.push_back(paths[k].c_str());
     }
-    rc = pm_translate_files(flag["-profiles_left"].c_str(), flag["-profiles_right"].c_str(), cpaths.data(), (int)cpaths.size(),
-                            flag["-out_delta"].c_str(), device);
+    // new in this build: -devices 0,1,... (or PARAMUGSY_DEVICES) spreads the delta-file list over several GPUs of the node, one
+    // host thread per device, output identical to the one-device run (pm_translate_files_multi)
+    const char *devs_env = getenv("PARAMUGSY_DEVICES");
+    const std::string devs_text = !flag["-devices"].empty() ? flag["-devices"] : (devs_env ? devs_env : "");
+    std::vector<int> devs = parse_devices(devs_text);
+    if(!devs_text.empty() && devs.empty()) {
+      fprintf(stderr, "-devices takes a comma-separated list of device indices\n");
+      return 2;
+    }
+    if(!devs.empty()) {
+      rc = pm_translate_files_multi(flag["-profiles_left"].c_str(), flag["-profiles_right"].c_str(), cpaths.data(), (int)cpaths.size(),
+                                    flag["-out_delta"].c_str(), devs.data(), (int)devs.size());
+    }
+    else {
+      rc = pm_translate_files(flag["-profiles_left"].c_str(), flag["-profiles_right"].c_str(), cpaths.data(), (int)cpaths.size(),
+                              flag["-out_delta"].c_str(), device);
+    }
+  }
+  else if(cmd == "align") {
+    // new in this build (the DP has no reference counterpart): two MAF files with the same number of blocks -> a MAF
+    // file of merged blocks; -devices 0,1,... spreads the pairs over several GPUs (pm_dp_align_maf_multi)
+    if(flag["-left_maf"].empty() || flag["-right_maf"].empty() || flag["-out_maf"].empty()) {
+      fprintf(stderr, "Must provide -left_maf, -right_maf and -out_maf\n");
+      return 2;
+    }
+    pm_dp_params_t prm;
+    const int rows = flag["-rows"].empty() ? 1 : atoi(flag["-rows"].c_str()); // penalties scale with the row pairs of a column pair
+    for(int a = 0; a < 5; ++a) {
+      for(int b = 0; b < 5; ++b) {
+        prm.sub[a * 5 + b] = (a == 4 && b == 4) ? 0 : (a == 4 || b == 4) ? -3 : (a == b ? 5 : -4);
+      }
+    }
+    prm.gap_open = (flag["-gap_open"].empty() ? 8 : atoi(flag["-gap_open"].c_str())) * rows * rows;
+    prm.gap_extend = (flag["-gap_extend"].empty() ? 2 : atoi(flag["-gap_extend"].c_str())) * rows * rows;
+    const char *devs_env = getenv("PARAMUGSY_DEVICES");
+    const std::string devs_text = !flag["-devices"].empty() ? flag["-devices"] : (devs_env ? devs_env : "");
+    std::vector<int> devs = parse_devices(devs_text);
+    if(!devs_text.empty() && devs.empty()) {
+      fprintf(stderr, "-devices takes a comma-separated list of device indices\n");
+      return 2;
+    }
+    if(!devs.empty()) {
+      rc = pm_dp_align_maf_multi(flag["-left_maf"].c_str(), flag["-right_maf"].c_str(), &prm, flag["-out_maf"].c_str(), devs.data(), (int)devs.size());
+    }
+    else {
+      rc = pm_dp_align_maf(flag["-left_maf"].c_str(), flag["-right_maf"].c_str(), &prm, flag["-out_maf"].c_str(), device);
+    }
   }
   else if(cmd == "stage") {
     // new in this build: the make + make + translate prefix of lib/base/mugsy_profiles_task.ml:40-58 in one process
@@ -113,7 +177,7 @@ static int run_command(const std::string &cmd, std::map<std::string, std::string
 
 int main(int argc, char **argv) {
   if(argc < 2) {
-    fprintf(stderr, "usage: mugsy_profiles {make|translate|untranslate|stage|serve} <flags>\n");
+    fprintf(stderr, "usage: mugsy_profiles {make|translate|untranslate|stage|align|serve} <flags>\n");
     return 1;
   }
   std::string cmd = argv[1];

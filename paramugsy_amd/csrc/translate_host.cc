@@ -1048,6 +1048,46 @@ extern "C" int pm_translate_files_multi(const char *left_dir, const char *right_
   return rc;
 }
 
+// Host only: the outputs of m_translate runs over consecutive slices of one delta-file list (each a complete file: the two header
+// lines of m_translate_main.cc:35-39, then the entries) joined into what one run over the whole list prints.
+extern "C" int pm_delta_join_files(const char *const *part_paths, int n_parts, const char *out_path) {
+  if(n_parts < 0 || (n_parts > 0 && !part_paths) || !out_path) {
+    return pm::fail(PM_E_INVALID, "pm_delta_join_files: null argument");
+  }
+  std::vector<std::string> body((size_t)n_parts);
+  std::string head;
+  for(int k = 0; k < n_parts; ++k) {
+    std::string text;
+    if(!part_paths[k] || !pm::read_whole_file(part_paths[k], text)) {
+      return pm::fail(PM_E_IO, std::string("cannot read ") + (part_paths[k] ? part_paths[k] : "(null)"));
+    }
+    size_t a = text.find('\n');
+    size_t b = a == std::string::npos ? a : text.find('\n', a + 1);
+    if(b == std::string::npos) {
+      return pm::fail(PM_E_PARSE, std::string(part_paths[k]) + ": not an m_translate output (two header lines expected)");
+    }
+    if(k == 0) {
+      head = text.substr(0, b + 1);
+    }
+    body[(size_t)k] = text.substr(b + 1);
+  }
+  FILE *f = fopen(out_path, "wb");
+  if(!f) {
+    return pm::fail(PM_E_IO, std::string("cannot open ") + out_path);
+  }
+  int rc = PM_OK;
+  if(!head.empty() && fwrite(head.data(), 1, head.size(), f) != head.size()) {
+    rc = pm::fail(PM_E_IO, "write failed");
+  }
+  if(!rc) {
+    rc = pm::merge_shard_texts(body, body.size(), pm::OutSink(f));
+  }
+  if(fclose(f) != 0 && !rc) {
+    rc = pm::fail(PM_E_IO, "close failed");
+  }
+  return rc;
+}
+
 extern "C" int pm_partition(int64_t n_items, int n_parts, int part, int64_t *lo, int64_t *hi) {
   if(n_items < 0 || n_parts < 1 || part < 0 || part >= n_parts || !lo || !hi) {
     return pm::fail(PM_E_INVALID, "pm_partition: bad argument");

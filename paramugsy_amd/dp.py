@@ -83,6 +83,11 @@ def _lib():
         l.pm_dp_align_maf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PmDpParams), C.c_char_p, C.c_int]
         l.pm_dp_align_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                          C.POINTER(PmDpParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        l.pm_dp_align_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(PmDpParams), C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        l.pm_dp_align_blocks_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                               C.POINTER(PmDpParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        l.pm_dp_align_maf_multi.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(PmDpParams), C.c_char_p, C.c_void_p, C.c_int]
         l.pm_dp_batch_destroy.argtypes = [C.c_void_p]
         l.pm_dp_batch_destroy.restype = None
         l.pm_dp_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_int64]
@@ -333,8 +338,54 @@ def align_blocks(blocks_a: Sequence[Sequence[bytes]], blocks_b: Sequence[Sequenc
     return scores[:n], merged
 
 
-def align_maf_files(maf_a: str, maf_b: str, params: PmDpParams, out_maf: str, device: int = 0) -> None:
+def align_maf_files(maf_a: str, maf_b: str, params: PmDpParams, out_maf: str, device: int = 0, devices: Sequence[int] = None) -> None:
+    """devices: a device list -> pm_dp_align_maf_multi (the blocks cut into contiguous slices, one host thread per device)."""
+    if devices is not None:
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        capi.check(_lib().pm_dp_align_maf_multi(maf_a.encode(), maf_b.encode(), C.byref(params), out_maf.encode(), dev.ctypes.data, len(dev)))
+        return
     capi.check(_lib().pm_dp_align_maf(maf_a.encode(), maf_b.encode(), C.byref(params), out_maf.encode(), device))
+
+
+def align_multi(inputs: DpInputs, params: PmDpParams, devices: Sequence[int], with_paths: bool = True):
+    """pm_dp_align_multi: host columns in, (scores, ops, n_ops) out in pm_dp_batch_fetch's layout, the pairs cut into contiguous
+    slices over `devices` (one host thread and one HIP context each; no torch.distributed anywhere)."""
+    n = inputs.n_pairs
+    oa = np.ascontiguousarray(inputs.off_a, dtype=np.int64)
+    ob = np.ascontiguousarray(inputs.off_b, dtype=np.int64)
+    ca = np.ascontiguousarray(inputs.cols_a, dtype=np.uint8)
+    cb = np.ascontiguousarray(inputs.cols_b, dtype=np.uint8)
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    scores = np.zeros(max(1, n), dtype=np.int32)
+    ops = np.zeros(max(1, int(oa[-1] + ob[-1])), dtype=np.uint8) if with_paths else None
+    n_ops = np.zeros(max(1, n), dtype=np.int32) if with_paths else None
+    capi.check(_lib().pm_dp_align_multi(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, n, C.byref(params), dev.ctypes.data, len(dev),
+                                        scores.ctypes.data, ops.ctypes.data if with_paths else None, n_ops.ctypes.data if with_paths else None))
+    return scores[:n], ops, (n_ops[:n] if with_paths else None)
+
+
+def align_blocks_multi(blocks_a: Sequence[Sequence[bytes]], blocks_b: Sequence[Sequence[bytes]], params: PmDpParams,
+                       devices: Sequence[int]) -> Tuple[np.ndarray, List[List[bytes]]]:
+    """pm_dp_align_blocks_multi: align_blocks over a device list; merged blocks gathered on the host in pair order."""
+    ta, roa, bra = flatten_blocks(blocks_a)
+    tb, rob, brb = flatten_blocks(blocks_b)
+    n = len(blocks_a)
+    if len(blocks_b) != n:
+        raise ValueError("pair k is block k of each side: %d and %d blocks" % (n, len(blocks_b)))
+    cap = sum((len(a) + len(b)) * ((len(a[0]) if a else 0) + (len(b[0]) if b else 0)) for a, b in zip(blocks_a, blocks_b))
+    scores = np.zeros(max(1, n), dtype=np.int32)
+    cols = np.zeros(max(1, n), dtype=np.int32)
+    out = np.zeros(max(1, cap), dtype=np.uint8)
+    out_off = np.zeros(n + 1, dtype=np.int64)
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    capi.check(_lib().pm_dp_align_blocks_multi(ta.ctypes.data, roa.ctypes.data, len(roa) - 1, bra.ctypes.data, tb.ctypes.data, rob.ctypes.data,
+                                               len(rob) - 1, brb.ctypes.data, n, C.byref(params), dev.ctypes.data, len(dev), scores.ctypes.data,
+                                               cols.ctypes.data, out.ctypes.data, cap, out_off.ctypes.data))
+    merged = []
+    for k in range(n):
+        rows, ln, base = len(blocks_a[k]) + len(blocks_b[k]), int(cols[k]), int(out_off[k])
+        merged.append([out[base + r * ln: base + (r + 1) * ln].tobytes() for r in range(rows)])
+    return scores[:n], merged
 
 
 # ---------------------------------------------------------------- synthetic workloads

@@ -189,6 +189,16 @@ def translate(left_dir: str, right_dir: str, nucmer_list: Sequence[str], out_pat
     capi.check(capi.lib().pm_translate_files(left_dir.encode(), right_dir.encode(), arr, len(nucmer_list), out_path.encode(), device))
 
 
+def translate_multi(left_dir: str, right_dir: str, nucmer_list: Sequence[str], out_path: str, devices: Sequence[int]) -> None:
+    """The same over a device list (pm_translate_files_multi): one host thread and one HIP context per device, the delta-file
+    list cut into contiguous slices, texts joined in list order with the writer's header rule re-applied at the seams."""
+    import numpy as np
+    arr = (C.c_char_p * len(nucmer_list))(*[p.encode() for p in nucmer_list])
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    capi.check(capi.lib().pm_translate_files_multi(left_dir.encode(), right_dir.encode(), arr, len(nucmer_list), out_path.encode(),
+                                                   dev.ctypes.data_as(C.POINTER(C.c_int32)), len(dev)))
+
+
 def m_translate_main(argv: List[str]) -> int:
     """argv[0] = program name, as in m_translate_main.cc:19-46."""
     if len(argv) < 5:
