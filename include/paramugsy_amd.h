@@ -124,6 +124,15 @@ int pm_job_sizes(pm_job_t *job, int64_t *n_entries, int64_t *n_offsets);
  * entries [unit_entry_off[u], unit_entry_off[u+1]).  Any pointer may be NULL to skip that array.
  * Returns PM_OK, or PM_E_UNIT when some unit_status is non-zero (arrays are still filled). */
 int pm_job_fetch(pm_job_t *job, int32_t *unit_status, int64_t *unit_entry_off, pm_entry_t *entries, int64_t *offsets);
+/* The text M_delta_stream_writer::write prints for the last run's results (lib/profiles_lib/m_delta_stream_writer.hh:55-82),
+ * formatted ON THE DEVICE: a `>left right lenL lenR` line whenever the pair of major names changes, `rs re qs qe 1 2 3`, then one
+ * signed offset per line.  left_major / right_major: p_major_name of every row of the two sides (NUL-terminated).  The text ends
+ * with the first failing unit's partial output, as the reference's stream does when it dies there: *failed_unit = that unit's
+ * index or -1, *failed_status its PM_ST_* (either pointer may be NULL).  pm_job_text sizes and formats (the bytes stay in HBM);
+ * pm_job_text_fetch copies *n_bytes bytes to `out`. */
+int pm_job_text(pm_job_t *job, const char *const *left_major, const char *const *right_major, int64_t *n_bytes, int64_t *failed_unit,
+                int32_t *failed_status);
+int pm_job_text_fetch(pm_job_t *job, char *out);
 /* Algorithmic bytes one pm_job_run moves (inputs read + outputs written), for roofline accounting. */
 int pm_job_algorithmic_bytes(pm_job_t *job, int64_t *bytes);
 /* Algorithmic bytes of the two heavy kernels separately (count pass, emit pass) and the number of live units (those

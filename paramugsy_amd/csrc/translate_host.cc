@@ -5,7 +5,7 @@
 //   _split_gaps                  lib/profiles_lib/m_delta.cc:14-68        -> split_offsets
 //   _profile_map_of_dir          lib/m_translate/m_translate.cc:188-207   -> build_side_index
 //   _translate_delta (loops)     lib/m_translate/m_translate.cc:650-709   -> enumerate_units
-//   M_delta_stream_writer::write lib/profiles_lib/m_delta_stream_writer.hh:55-82 -> TextSink
+//   M_delta_stream_writer::write lib/profiles_lib/m_delta_stream_writer.hh:55-82 -> on the device (pm_job_text, translate_job.hip)
 //   translate + main's 2 lines   lib/m_translate/m_translate.cc:713-730, m_translate_main.cc:35-39 -> pm_translate_files
 // The arithmetic of every work unit runs on the GPU (translate_job.hip); nothing here computes a translation.
 //
@@ -480,38 +480,6 @@ void enumerate_units(const Side &left, const Side &right, const DeltaTable &t, s
 
 // ------------------------------------------------------------------ text out
 
-struct TextSink {
-  FILE *f;
-  std::string buf;
-  std::string last_left, last_right; // M_delta_stream_writer::header_names starts as ("", "")
-  explicit TextSink(FILE *f_) : f(f_) { buf.reserve(1 << 20); }
-  void put_i64(long long v) {
-    char tmp[24];
-    int n = 0;
-    unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
-    do {
-      tmp[n++] = (char)('0' + u % 10);
-      u /= 10;
-    } while(u);
-    if(v < 0) {
-      tmp[n++] = '-';
-    }
-    while(n) {
-      buf.push_back(tmp[--n]);
-    }
-  }
-  bool flush() {
-    if(!buf.empty()) {
-      if(fwrite(buf.data(), 1, buf.size(), f) != buf.size()) {
-        return false;
-      }
-      buf.clear();
-    }
-    return true;
-  }
-  bool maybe_flush() { return buf.size() < (1 << 20) - 4096 ? true : flush(); }
-};
-
 // A host array whose elements are left uninitialised (plain malloc), for buffers a copy is about to fill.
 template <typename T>
 struct HostArray {
@@ -555,130 +523,6 @@ static void touch_pages(const std::vector<std::pair<char *, size_t> > &bufs) {
   for(size_t k = 0; k < th.size(); ++k) {
     th[k].join();
   }
-}
-
-// Text of the units [u0, u1): what M_delta_stream_writer::write prints for their entries, starting from the header
-// names (last_left, last_right) that the writer holds when it reaches u0.
-static void format_units(size_t u0, size_t u1, const Side &left, const Side &right, const UnitList &units,
-                         const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string last_left,
-                         std::string last_right, std::string &text) {
-  TextSink out(nullptr);
-  out.buf.swap(text);
-  out.last_left.swap(last_left);
-  out.last_right.swap(last_right);
-  for(size_t u = u0; u < u1; ++u) {
-    int l = units.left[u], r = units.right[u];
-    for(int64_t k = unit_entry_off[u]; k < unit_entry_off[u + 1]; ++k) {
-      const pm_entry_t &en = entries[(size_t)k];
-      if(left.major[l] != out.last_left || right.major[r] != out.last_right) { // m_delta_stream_writer.hh:62-67
-        out.buf.push_back('>');
-        out.buf += left.major[l];
-        out.buf.push_back(' ');
-        out.buf += right.major[r];
-        out.buf.push_back(' ');
-        out.put_i64(left.length[l]);
-        out.buf.push_back(' ');
-        out.put_i64(right.length[r]);
-        out.buf.push_back('\n');
-        out.last_left = left.major[l];
-        out.last_right = right.major[r];
-      }
-      out.put_i64(en.ref_start);
-      out.buf.push_back(' ');
-      out.put_i64(en.ref_end);
-      out.buf.push_back(' ');
-      out.put_i64(en.qry_start);
-      out.buf.push_back(' ');
-      out.put_i64(en.qry_end);
-      out.buf += " 1 2 3\n"; // m_delta_stream_writer.hh:71
-      for(int64_t o = 0; o < en.n_offsets; ++o) {
-        out.put_i64(offsets[(size_t)(en.offset_begin + o)]);
-        out.buf.push_back('\n');
-      }
-    }
-  }
-  text.swap(out.buf);
-}
-
-// Formatting is the longest host phase of a job (tens of MB of decimal text), and units are independent but for the
-// header rule, which only needs the names of the last entry printed before a unit: the units are cut into slices of
-// about equal output, every slice is formatted by its own thread from the header names in force at its start, and
-// the slices are written in order.
-int write_results(OutSink sink, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
-                  const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string &last_left,
-                  std::string &last_right) {
-  const size_t U = units.delta.size();
-  // the reference dies inside the first failing unit: what it had emitted so far is on the stream, nothing after it
-  size_t end = U, failed = U;
-  for(size_t u = 0; u < U; ++u) {
-    if(status[u] != PM_ST_OK) {
-      failed = u;
-      end = u + 1;
-      break;
-    }
-  }
-  const int64_t total_entries = end > 0 ? unit_entry_off[end] : 0;
-  size_t n_slices = 1;
-  {
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t want = hw == 0 ? 1 : (hw > 16 ? 16 : hw);
-    // a slice is worth a thread from a few thousand entries up
-    n_slices = (size_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)want, total_entries / 4096));
-  }
-  std::vector<size_t> cut(n_slices + 1, end);
-  cut[0] = 0;
-  for(size_t s = 1; s < n_slices; ++s) { // first unit whose entries start at or after the s-th share of the entries
-    int64_t target = total_entries * (int64_t)s / (int64_t)n_slices;
-    cut[s] = (size_t)(std::lower_bound(unit_entry_off, unit_entry_off + end, target) - unit_entry_off);
-    if(cut[s] < cut[s - 1]) {
-      cut[s] = cut[s - 1];
-    }
-  }
-  // header names in force at the start of each slice: those of the last unit before it that printed an entry
-  std::vector<std::string> ll(n_slices), rr(n_slices);
-  ll[0] = last_left;
-  rr[0] = last_right;
-  for(size_t s = 1; s < n_slices; ++s) {
-    ll[s] = ll[s - 1];
-    rr[s] = rr[s - 1];
-    for(size_t u = cut[s]; u-- > cut[s - 1];) {
-      if(unit_entry_off[u + 1] > unit_entry_off[u]) {
-        ll[s] = left.major[units.left[u]];
-        rr[s] = right.major[units.right[u]];
-        break;
-      }
-    }
-  }
-  std::vector<std::string> text(n_slices);
-  {
-    std::vector<std::thread> workers;
-    for(size_t s = 1; s < n_slices; ++s) {
-      workers.emplace_back([&, s]() { format_units(cut[s], cut[s + 1], left, right, units, unit_entry_off, entries, offsets, ll[s], rr[s], text[s]); });
-    }
-    format_units(cut[0], cut[1], left, right, units, unit_entry_off, entries, offsets, ll[0], rr[0], text[0]);
-    for(size_t k = 0; k < workers.size(); ++k) {
-      workers[k].join();
-    }
-  }
-  for(size_t s = 0; s < n_slices; ++s) {
-    if(!text[s].empty() && !sink.write(text[s].data(), text[s].size())) {
-      return fail(PM_E_IO, "write failed");
-    }
-  }
-  for(size_t u = end; u-- > 0;) { // the names the writer holds afterwards
-    if(unit_entry_off[u + 1] > unit_entry_off[u]) {
-      last_left = left.major[units.left[u]];
-      last_right = right.major[units.right[u]];
-      break;
-    }
-  }
-  if(failed < U) {
-    char msg[160];
-    snprintf(msg, sizeof msg, "work unit %zu (delta entry %d, left row %d, right row %d) failed with status %d", failed, units.delta[failed],
-             units.left[failed], units.right[failed], (int)status[failed]);
-    return fail(status[failed] == PM_ST_MALFORMED_INPUT ? PM_E_MALFORMED : PM_E_UNIT, msg);
-  }
-  return PM_OK;
 }
 
 static pm_rows_t rows_view(const Side &s) {
@@ -820,7 +664,6 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
     return ts.tv_sec + ts.tv_nsec * 1e-9;
   };
   double t1 = now();
-  std::string last_left, last_right;
   if(!units.delta.empty()) {
     pm_rows_t lv = rows_view(left), rv = rows_view(right);
     pm_deltas_t dv = deltas_view(table);
@@ -838,33 +681,46 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
       rc = pm_job_sizes(job, &ne, &no);
     }
     double t3 = now();
-    // result buffers: not value-initialised (144 MB for a million units); their pages are touched by a few threads at
-    // once before the device-to-host copies land in them
-    HostArray<int32_t> status((size_t)uv.n);
-    HostArray<int64_t> ent_off((size_t)uv.n + 1);
-    HostArray<pm_entry_t> entries((size_t)ne);
-    HostArray<int64_t> offsets((size_t)no);
-    if(!status.ok() || !ent_off.ok() || !entries.ok() || !offsets.ok()) {
-      pm_job_destroy(job);
-      return fail(PM_E_INVALID, "out of host memory");
+    // the writer's text is formatted on the device (pm_job_text): what comes back is the bytes of the output, not the
+    // entries and offsets they are printed from (half the bytes, and no host formatting)
+    std::vector<const char *> ln(left.major.size()), rn(right.major.size());
+    for(size_t r = 0; r < ln.size(); ++r) {
+      ln[r] = left.major[r].c_str();
     }
-    touch_pages({{status.bytes(), status.size_bytes()}, {ent_off.bytes(), ent_off.size_bytes()}, {entries.bytes(), entries.size_bytes()},
-                 {offsets.bytes(), offsets.size_bytes()}});
+    for(size_t r = 0; r < rn.size(); ++r) {
+      rn[r] = right.major[r].c_str();
+    }
+    int64_t n_bytes = 0, failed = -1;
+    int32_t failed_status = 0;
     if(!rc) {
-      rc = pm_job_fetch(job, status.data(), ent_off.data(), entries.data(), offsets.data());
-      if(rc == PM_E_UNIT) {
-        rc = PM_OK; // write_results reports the first failing unit after the output that precedes it
+      rc = pm_job_text(job, ln.data(), rn.data(), &n_bytes, &failed, &failed_status);
+    }
+    double t4 = now();
+    if(!rc && n_bytes > 0) {
+      HostArray<char> text((size_t)n_bytes); // not value-initialised; its pages are touched by a few threads before the copy lands
+      if(!text.ok()) {
+        pm_job_destroy(job);
+        return fail(PM_E_INVALID, "out of host memory");
+      }
+      touch_pages({{text.bytes(), text.size_bytes()}});
+      rc = pm_job_text_fetch(job, text.data());
+      if(!rc && !out.write(text.data(), (size_t)n_bytes)) {
+        rc = fail(PM_E_IO, "write failed");
       }
     }
     pm_job_destroy(job);
     if(rc) {
       return rc;
     }
-    double t4 = now();
-    PM_TRY(write_results(out, left, right, units, status.data(), ent_off.data(), entries.data(), offsets.data(), last_left, last_right));
     if(timing) {
-      fprintf(stderr, "[pm] device init + upload + prepare + sizing: %.3f s; run: %.4f s; fetch: %.3f s; format + write: %.3f s\n", t2 - t1,
-              t3 - t2, t4 - t3, now() - t4);
+      fprintf(stderr, "[pm] device init + upload + prepare + sizing: %.3f s; run: %.4f s; text on the device: %.4f s; fetch + write: %.3f s (%lld bytes)\n",
+              t2 - t1, t3 - t2, t4 - t3, now() - t4, (long long)n_bytes);
+    }
+    if(failed >= 0) { // the reference died inside this unit: what it had printed is on the stream
+      char msg[160];
+      snprintf(msg, sizeof msg, "work unit %lld (delta entry %d, left row %d, right row %d) failed with status %d", (long long)failed,
+               units.delta[(size_t)failed], units.left[(size_t)failed], units.right[(size_t)failed], (int)failed_status);
+      return fail(failed_status == PM_ST_MALFORMED_INPUT ? PM_E_MALFORMED : PM_E_UNIT, msg);
     }
   }
   if(parse_rc) {

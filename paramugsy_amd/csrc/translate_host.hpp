@@ -62,9 +62,6 @@ struct OutSink {
     return fwrite(p, 1, n, f) == n;
   }
 };
-int write_results(OutSink out, const Side &left, const Side &right, const UnitList &units, const int32_t *status,
-                  const int64_t *unit_entry_off, const pm_entry_t *entries, const int64_t *offsets, std::string &last_left,
-                  std::string &last_right);
 // <dir>/profiles.soa when it matches <dir>/profiles, else the text file (parse_profiles)
 int load_side(const std::string &dir, Side &side);
 int write_side_soa(const std::string &dir, const Side &side, long long profiles_text_bytes);

@@ -20,6 +20,7 @@
 
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pm_internal.hpp"
@@ -335,6 +336,170 @@ __global__ void s2p_batch_kernel(RowsD rows, i64 n, const int *row, const i64 *p
   out[q] = v;
 }
 
+// ------------------------------------------------------------------ the writer's text, on the device
+// M_delta_stream_writer::write (m_delta_stream_writer.hh:55-82) for every entry of a job's result, in unit order: a `>` header
+// line when the (left major name, right major name) pair differs from the pair of the last entry printed, the entry line
+// `rs re qs qe 1 2 3`, one signed offset per line, the terminating 0 among them (deltas_of_gaps' output is what the emit
+// pass left in `offsets`).  Three kernels around two scans:
+//   text_units_kernel    per unit: "has entries" (for the header rule: which unit printed last before me) and the first
+//                        failing unit (the reference dies inside it: what it had printed stays, nothing after it)
+//   text_measure_kernel  per entry: its unit (upper bound in ent_off), whether it carries a header, its bytes
+//   text_write_kernel    per entry: the bytes, at the exclusive scan of the measures
+// One lane per entry: an entry is ~25-40 bytes of decimal text, its offset list 1-2 numbers on average.
+
+__device__ __forceinline__ int udec_len(unsigned long long u) {
+  int n = 1;
+  if(u < 4294967296ull) { // 32-bit divisions for the usual case
+    unsigned w = (unsigned)u;
+    while(w >= 10u) {
+      w /= 10u;
+      ++n;
+    }
+    return n;
+  }
+  while(u >= 10ull) {
+    u /= 10ull;
+    ++n;
+  }
+  return n;
+}
+
+__device__ __forceinline__ int dec_len(i64 v) {
+  return v < 0 ? 1 + udec_len(0ull - (unsigned long long)v) : udec_len((unsigned long long)v);
+}
+
+__device__ __forceinline__ char *put_dec(char *p, i64 v) {
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  if(v < 0) {
+    *p++ = '-';
+  }
+  const int n = udec_len(u);
+  if(u < 4294967296ull) {
+    unsigned w = (unsigned)u;
+    for(int k = n - 1; k >= 0; --k) {
+      p[k] = (char)('0' + w % 10u);
+      w /= 10u;
+    }
+  }
+  else {
+    for(int k = n - 1; k >= 0; --k) {
+      p[k] = (char)('0' + (unsigned)(u % 10ull));
+      u /= 10ull;
+    }
+  }
+  return p + n;
+}
+
+__global__ void text_units_kernel(i64 U, const int *status, const i64 *ent_off, int *last_ne, int *first_fail) {
+  const i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(u >= U) {
+    return;
+  }
+  last_ne[u] = ent_off[u + 1] > ent_off[u] ? (int)u : -1;
+  if(status[u] != PM_ST_OK) {
+    atomicMin(first_fail, (int)u);
+  }
+}
+
+struct TextNames {
+  const char *bytes[2];   // the rows' major names back to back, left side / right side
+  const i64 *off[2];      // [rows + 1]
+  const int *id[2];       // equal names <-> equal ids
+  const i64 *length[2];   // p_length of the rows (the header's two numbers)
+};
+
+template <bool WRITE>
+__global__ void text_entries_kernel(i64 E, i64 U, const i64 *ent_off, const int *u_left, const int *u_right, const int *last_ne,
+                                    const int *first_fail, const pm_entry_t *entries, const i64 *offsets, TextNames names, int *e_unit,
+                                    i64 *len, const i64 *pos, char *text) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= E) {
+    return;
+  }
+  int u;
+  if(!WRITE) {
+    // the unit that owns entry k: the last u with ent_off[u] <= k (units without entries repeat their neighbour's offset)
+    i64 lo = 0, hi = U; // invariant: ent_off[lo] <= k < ent_off[hi]
+    while(hi - lo > 1) {
+      const i64 mid = (lo + hi) >> 1;
+      if(ent_off[mid] <= k) {
+        lo = mid;
+      }
+      else {
+        hi = mid;
+      }
+    }
+    u = (int)lo;
+  }
+  else {
+    u = e_unit[k];
+    if(u < 0) {
+      return; // behind the first failing unit: the reference never got there
+    }
+  }
+  const int l = u_left[u], r = u_right[u];
+  bool header = false;
+  if(k == ent_off[u]) { // the unit's first entry: does the writer hold another name pair?
+    const int p = u > 0 ? last_ne[u - 1] : -1; // the last unit before u that printed (inclusive max-scan of text_units_kernel's marks)
+    // (the writer starts with the pair ("", ""), m_delta_stream_writer.hh:55-60)
+    header = p < 0 ? (names.off[0][l + 1] > names.off[0][l] || names.off[1][r + 1] > names.off[1][r])
+                   : (names.id[0][u_left[p]] != names.id[0][l] || names.id[1][u_right[p]] != names.id[1][r]);
+  }
+  const pm_entry_t en = entries[k];
+  if(!WRITE) {
+    if(u > *first_fail) {
+      e_unit[k] = -1;
+      len[k] = 0;
+      return;
+    }
+    i64 n = dec_len(en.ref_start) + dec_len(en.ref_end) + dec_len(en.qry_start) + dec_len(en.qry_end) + 3 + 7;
+    if(header) {
+      n += 1 + (names.off[0][l + 1] - names.off[0][l]) + 1 + (names.off[1][r + 1] - names.off[1][r]) + 1 + dec_len(names.length[0][l]) + 1 +
+           dec_len(names.length[1][r]) + 1;
+    }
+    for(i64 o = 0; o < en.n_offsets; ++o) {
+      n += dec_len(offsets[en.offset_begin + o]) + 1;
+    }
+    e_unit[k] = u;
+    len[k] = n;
+    return;
+  }
+  char *p = text + pos[k];
+  if(header) {
+    *p++ = '>';
+    for(i64 c = names.off[0][l]; c < names.off[0][l + 1]; ++c) {
+      *p++ = names.bytes[0][c];
+    }
+    *p++ = ' ';
+    for(i64 c = names.off[1][r]; c < names.off[1][r + 1]; ++c) {
+      *p++ = names.bytes[1][c];
+    }
+    *p++ = ' ';
+    p = put_dec(p, names.length[0][l]);
+    *p++ = ' ';
+    p = put_dec(p, names.length[1][r]);
+    *p++ = '\n';
+  }
+  p = put_dec(p, en.ref_start);
+  *p++ = ' ';
+  p = put_dec(p, en.ref_end);
+  *p++ = ' ';
+  p = put_dec(p, en.qry_start);
+  *p++ = ' ';
+  p = put_dec(p, en.qry_end);
+  *p++ = ' ';
+  *p++ = '1';
+  *p++ = ' ';
+  *p++ = '2';
+  *p++ = ' ';
+  *p++ = '3'; // the three error fields, m_delta_stream_writer.hh:71
+  *p++ = '\n';
+  for(i64 o = 0; o < en.n_offsets; ++o) {
+    p = put_dec(p, offsets[en.offset_begin + o]);
+    *p++ = '\n';
+  }
+}
+
 // ------------------------------------------------------------------ device-resident tables
 
 static int check_csr(const int64_t *off, int64_t n, const char *what) {
@@ -537,6 +702,9 @@ struct pm_job {
   i64 input_bytes = 0;
   hipStream_t last_stream = nullptr;
   bool ran = false;
+  // the delta text of the last run, formatted on the device (pm_job_text)
+  DevBuf t_names[2], t_name_off[2], t_name_id[2], t_marks, t_last_ne, t_eunit, t_len, t_pos, t_text, t_scan_tmp, t_word;
+  i64 text_bytes = -1;
 };
 
 // The four phases of one pass; `ev` (5 events) brackets them when the pass is being timed.
@@ -959,6 +1127,119 @@ int pm_job_fetch(pm_job_t *j, int32_t *unit_status, int64_t *unit_entry_off, pm_
       snprintf(msg, sizeof msg, "unit %lld ended with status %d", (long long)u, (int)st[u]);
       return fail(PM_E_UNIT, msg);
     }
+  }
+  return PM_OK;
+}
+
+// One side's major names as the text kernels take them: bytes back to back, offsets, and an id per row (equal names, equal ids).
+static int upload_names(pm_job *j, int side, const char *const *names, i64 n) {
+  std::vector<i64> off((size_t)n + 1, 0);
+  std::vector<int> id((size_t)n, 0);
+  std::string blob;
+  std::unordered_map<std::string, int> seen;
+  for(i64 r = 0; r < n; ++r) {
+    if(!names[r]) {
+      return fail(PM_E_INVALID, "pm_job_text: null name");
+    }
+    const std::string name(names[r]);
+    blob += name;
+    off[(size_t)r + 1] = (i64)blob.size();
+    id[(size_t)r] = seen.emplace(name, (int)seen.size()).first->second;
+  }
+  PM_TRY(j->t_names[side].upload(blob.data(), blob.size(), nullptr));
+  PM_TRY(j->t_name_off[side].upload(off.data(), off.size() * 8, nullptr));
+  PM_TRY(j->t_name_id[side].upload(id.data(), id.size() * 4, nullptr));
+  return PM_OK;
+}
+
+int pm_job_text(pm_job_t *j, const char *const *left_major, const char *const *right_major, int64_t *n_bytes, int64_t *failed_unit,
+                int32_t *failed_status) {
+  if(!j || !n_bytes || (j->left.n > 0 && !left_major) || (j->right.n > 0 && !right_major)) {
+    return fail(PM_E_INVALID, "pm_job_text: null argument");
+  }
+  PM_TRY(use_device(j->device));
+  int64_t E = 0, O = 0;
+  PM_TRY(pm_job_sizes(j, &E, &O)); // waits for the run; refuses a job that has not run
+  const i64 U = j->n_units;
+  hipStream_t stream = j->last_stream;
+  PM_TRY(upload_names(j, 0, left_major, j->left.n));
+  PM_TRY(upload_names(j, 1, right_major, j->right.n));
+  PM_TRY(j->t_word.alloc(8));
+  const int no_fail = 0x7fffffff;
+  PM_HIP(hipMemcpyAsync(j->t_word.p, &no_fail, 4, hipMemcpyHostToDevice, stream));
+  PM_TRY(j->t_marks.alloc((size_t)(U + 1) * 4));
+  PM_TRY(j->t_last_ne.alloc((size_t)(U + 1) * 4));
+  PM_TRY(j->t_eunit.alloc((size_t)(E + 1) * 4));
+  PM_TRY(j->t_len.alloc((size_t)(E + 1) * 8));
+  PM_TRY(j->t_pos.alloc((size_t)(E + 1) * 8));
+  j->text_bytes = 0;
+  if(U > 0) {
+    text_units_kernel<<<(unsigned)((U + 255) / 256), 256, 0, stream>>>(U, (const int *)j->status.p, (const i64 *)j->ent_off.p, (int *)j->t_marks.p,
+                                                                        (int *)j->t_word.p);
+    PM_HIP(hipGetLastError());
+    size_t tmp = 0;
+    PM_HIP(rocprim::inclusive_scan(nullptr, tmp, (int *)j->t_marks.p, (int *)j->t_last_ne.p, (size_t)U, rocprim::maximum<int>(), stream));
+    size_t tmp2 = 0;
+    PM_HIP(rocprim::exclusive_scan(nullptr, tmp2, (i64 *)j->t_len.p, (i64 *)j->t_pos.p, (i64)0, (size_t)(E + 1), rocprim::plus<i64>(), stream));
+    PM_TRY(j->t_scan_tmp.alloc(std::max(tmp, tmp2) + 16));
+    tmp = j->t_scan_tmp.bytes;
+    PM_HIP(rocprim::inclusive_scan(j->t_scan_tmp.p, tmp, (int *)j->t_marks.p, (int *)j->t_last_ne.p, (size_t)U, rocprim::maximum<int>(), stream));
+  }
+  TextNames names;
+  for(int sd = 0; sd < 2; ++sd) {
+    names.bytes[sd] = (const char *)j->t_names[sd].p;
+    names.off[sd] = (const i64 *)j->t_name_off[sd].p;
+    names.id[sd] = (const int *)j->t_name_id[sd].p;
+  }
+  names.length[0] = (const i64 *)j->left.length.p;
+  names.length[1] = (const i64 *)j->right.length.p;
+  PM_HIP(hipMemsetAsync((i64 *)j->t_len.p + E, 0, 8, stream));
+  if(E > 0) {
+    text_entries_kernel<false><<<(unsigned)((E + 255) / 256), 256, 0, stream>>>(
+        E, U, (const i64 *)j->ent_off.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->t_last_ne.p, (const int *)j->t_word.p,
+        (const pm_entry_t *)j->entries.p, (const i64 *)j->offsets.p, names, (int *)j->t_eunit.p, (i64 *)j->t_len.p, nullptr, nullptr);
+    PM_HIP(hipGetLastError());
+    size_t tmp = j->t_scan_tmp.bytes;
+    PM_HIP(rocprim::exclusive_scan(j->t_scan_tmp.p, tmp, (i64 *)j->t_len.p, (i64 *)j->t_pos.p, (i64)0, (size_t)(E + 1), rocprim::plus<i64>(), stream));
+    i64 total = 0;
+    PM_HIP(hipMemcpyAsync(&total, (i64 *)j->t_pos.p + E, 8, hipMemcpyDeviceToHost, stream));
+    PM_HIP(hipStreamSynchronize(stream));
+    if(total < 0 || total > ((i64)1 << 40)) {
+      return fail(PM_E_INVALID, "pm_job_text: implausible text size");
+    }
+    if((i64)j->t_text.bytes < total) {
+      PM_TRY(j->t_text.alloc((size_t)total));
+    }
+    text_entries_kernel<true><<<(unsigned)((E + 255) / 256), 256, 0, stream>>>(
+        E, U, (const i64 *)j->ent_off.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->t_last_ne.p, (const int *)j->t_word.p,
+        (const pm_entry_t *)j->entries.p, (const i64 *)j->offsets.p, names, (int *)j->t_eunit.p, nullptr, (const i64 *)j->t_pos.p,
+        (char *)j->t_text.p);
+    PM_HIP(hipGetLastError());
+    j->text_bytes = total;
+  }
+  int ff = no_fail;
+  PM_HIP(hipMemcpyAsync(&ff, j->t_word.p, 4, hipMemcpyDeviceToHost, stream));
+  PM_HIP(hipStreamSynchronize(stream));
+  *n_bytes = j->text_bytes;
+  if(failed_unit) {
+    *failed_unit = ff == no_fail ? -1 : ff;
+  }
+  if(failed_status) {
+    *failed_status = 0;
+    if(ff != no_fail) {
+      PM_HIP(hipMemcpy(failed_status, (int *)j->status.p + ff, 4, hipMemcpyDeviceToHost));
+    }
+  }
+  return PM_OK;
+}
+
+int pm_job_text_fetch(pm_job_t *j, char *out) {
+  if(!j || j->text_bytes < 0 || (j->text_bytes > 0 && !out)) {
+    return fail(PM_E_INVALID, "pm_job_text_fetch: pm_job_text has not been called");
+  }
+  PM_TRY(use_device(j->device));
+  if(j->text_bytes > 0) {
+    PM_HIP(hipMemcpy(out, j->t_text.p, (size_t)j->text_bytes, hipMemcpyDeviceToHost));
   }
   return PM_OK;
 }
