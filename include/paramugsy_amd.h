@@ -133,6 +133,8 @@ int pm_job_fetch(pm_job_t *job, int32_t *unit_status, int64_t *unit_entry_off, p
 int pm_job_text(pm_job_t *job, const char *const *left_major, const char *const *right_major, int64_t *n_bytes, int64_t *failed_unit,
                 int32_t *failed_status);
 int pm_job_text_fetch(pm_job_t *job, char *out);
+/* bytes [first, first + n) of the text (a caller that writes the text out while the rest is still on its way) */
+int pm_job_text_fetch_range(pm_job_t *job, char *out, int64_t first, int64_t n);
 /* Algorithmic bytes one pm_job_run moves (inputs read + outputs written), for roofline accounting. */
 int pm_job_algorithmic_bytes(pm_job_t *job, int64_t *bytes);
 /* Algorithmic bytes of the two heavy kernels separately (count pass, emit pass) and the number of live units (those

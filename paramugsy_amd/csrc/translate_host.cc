@@ -13,6 +13,9 @@
 // integer is a PM_E_PARSE error here (the reference would read its numeric prefix).  The producers of these
 // files (lib/profiles/m_profile.ml:122-135 printf "%d"; MUMmer) never emit such tokens.
 #include <algorithm>
+#include <atomic>
+#include <functional>
+#include <iterator>
 #include <cerrno>
 #include <climits>
 #include <cstdio>
@@ -28,7 +31,12 @@
 #include "pm_internal.hpp"
 #include "translate_host.hpp"
 
+namespace pm {
+int warm_translate_kernels(); // translate_job.hip
+}
+
 #include <sys/stat.h>
+#include <unistd.h>
 
 namespace pm {
 
@@ -457,25 +465,92 @@ static inline bool ranges_overlap(long long as, long long ae, long long bs, long
   return e - s >= 0;
 }
 
-// m_translate.cc:666-707, for entries [first, t.size())
+// The rows an entry's loops visit (m_translate.cc:682-706): lefts [l0, l0 + nl) of `lr`, rights [r0, r0 + nr) of `rr`, every pair
+// of them a unit.  false when one of the entry's sequences has no rows.
+struct EntrySpan {
+  const std::vector<int> *lr, *rr;
+  size_t l0, nl, r0, nr;
+};
+static bool entry_span(const Side &left, const Side &right, const DeltaTable &t, size_t d, EntrySpan &sp) {
+  std::map<std::string, std::vector<int> >::const_iterator li = left.by_seq.find(t.ref_name[d]);
+  std::map<std::string, std::vector<int> >::const_iterator ri = right.by_seq.find(t.qry_name[d]);
+  if(li == left.by_seq.end() || ri == right.by_seq.end()) {
+    return false;
+  }
+  sp.lr = &li->second;
+  sp.rr = &ri->second;
+  sp.l0 = first_candidate(left, *sp.lr, t.ref_start[d], t.ref_end[d]);
+  sp.r0 = first_candidate(right, *sp.rr, t.qry_start[d], t.qry_end[d]);
+  sp.nl = sp.nr = 0;
+  for(size_t l = sp.l0; l < sp.lr->size() && ranges_overlap(left.start[(*sp.lr)[l]], left.end[(*sp.lr)[l]], t.ref_start[d], t.ref_end[d]); ++l) {
+    ++sp.nl;
+  }
+  for(size_t r = sp.r0; r < sp.rr->size() && ranges_overlap(right.start[(*sp.rr)[r]], right.end[(*sp.rr)[r]], t.qry_start[d], t.qry_end[d]); ++r) {
+    ++sp.nr;
+  }
+  return true;
+}
+
+// m_translate.cc:666-707, for entries [first, t.size()): the units in entry order, left rows outer, right rows inner.  The entries
+// are cut into slices, one per thread: a counting pass gives every slice its place in the list, a second pass fills it.
 void enumerate_units(const Side &left, const Side &right, const DeltaTable &t, size_t first, UnitList &units) {
-  for(size_t d = first; d < t.ref_start.size(); ++d) {
-    std::map<std::string, std::vector<int> >::const_iterator li = left.by_seq.find(t.ref_name[d]);
-    std::map<std::string, std::vector<int> >::const_iterator ri = right.by_seq.find(t.qry_name[d]);
-    if(li == left.by_seq.end() || ri == right.by_seq.end()) {
-      continue;
+  const size_t n = t.ref_start.size() > first ? t.ref_start.size() - first : 0;
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t n_threads = hw == 0 ? 1 : (hw > 8 ? 8 : hw);
+  if(n < 4096) {
+    n_threads = 1;
+  }
+  std::vector<size_t> count(n_threads + 1, 0);
+  auto slice = [&](size_t k, size_t &lo, size_t &hi) {
+    lo = first + n * k / n_threads;
+    hi = first + n * (k + 1) / n_threads;
+  };
+  auto run = [&](const std::function<void(size_t)> &fn) {
+    std::vector<std::thread> th;
+    for(size_t k = 1; k < n_threads; ++k) {
+      th.emplace_back(fn, k);
     }
-    const std::vector<int> &lr = li->second, &rr = ri->second;
-    size_t l0 = first_candidate(left, lr, t.ref_start[d], t.ref_end[d]);
-    size_t r0 = first_candidate(right, rr, t.qry_start[d], t.qry_end[d]);
-    for(size_t l = l0; l < lr.size() && ranges_overlap(left.start[lr[l]], left.end[lr[l]], t.ref_start[d], t.ref_end[d]); ++l) {
-      for(size_t r = r0; r < rr.size() && ranges_overlap(right.start[rr[r]], right.end[rr[r]], t.qry_start[d], t.qry_end[d]); ++r) {
-        units.delta.push_back((int)d);
-        units.left.push_back(lr[l]);
-        units.right.push_back(rr[r]);
+    fn(0);
+    for(size_t k = 0; k < th.size(); ++k) {
+      th[k].join();
+    }
+  };
+  run([&](size_t k) {
+    size_t lo, hi, c = 0;
+    slice(k, lo, hi);
+    EntrySpan sp;
+    for(size_t d = lo; d < hi; ++d) {
+      if(entry_span(left, right, t, d, sp)) {
+        c += sp.nl * sp.nr;
       }
     }
+    count[k + 1] = c;
+  });
+  for(size_t k = 0; k < n_threads; ++k) {
+    count[k + 1] += count[k];
   }
+  const size_t base = units.delta.size();
+  units.delta.resize(base + count[n_threads]);
+  units.left.resize(base + count[n_threads]);
+  units.right.resize(base + count[n_threads]);
+  run([&](size_t k) {
+    size_t lo, hi, at = base + count[k];
+    slice(k, lo, hi);
+    EntrySpan sp;
+    for(size_t d = lo; d < hi; ++d) {
+      if(!entry_span(left, right, t, d, sp)) {
+        continue;
+      }
+      for(size_t l = sp.l0; l < sp.l0 + sp.nl; ++l) {
+        for(size_t r = sp.r0; r < sp.r0 + sp.nr; ++r) {
+          units.delta[at] = (int)d;
+          units.left[at] = (*sp.lr)[l];
+          units.right[at] = (*sp.rr)[r];
+          ++at;
+        }
+      }
+    }
+  });
 }
 
 // ------------------------------------------------------------------ text out
@@ -556,10 +631,25 @@ static pm_deltas_t deltas_view(const DeltaTable &t) {
 // Parse both sides and every delta file of a job and list its work units (host only, no device needed).
 // `parse_rc`/`parse_msg` keep a delta-file parse failure: the entries read before it are still in the table,
 // as the reference would have translated them before throwing (m_translate.cc:722-728).
+static double wall_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
 int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w) {
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  const double t0 = wall_now();
   PM_TRY(load_side(left_dir, w.left));
   PM_TRY(load_side(right_dir, w.right));
-  return load_deltas(delta_paths, w);
+  const double t1 = wall_now();
+  parse_deltas(delta_paths, w);
+  const double t2 = wall_now();
+  index_and_enumerate(w);
+  if(timing) {
+    fprintf(stderr, "[pm]   sides: %.4f s; delta files: %.4f s; index + enumerate: %.4f s\n", t1 - t0, t2 - t1, wall_now() - t2);
+  }
+  return PM_OK;
 }
 
 // The delta files and the unit list of a workload whose two sides are already in place (read from disk, or handed over in
@@ -578,13 +668,93 @@ void parse_deltas(const std::vector<std::string> &delta_paths, Workload &w) {
   w.table.qry_gap_off.push_back(0);
   w.parse_rc = PM_OK;
   w.parse_msg.clear();
-  for(size_t k = 0; k < delta_paths.size(); ++k) {
-    int rc = parse_delta_file(delta_paths[k], w.table);
-    if(rc) {
-      w.parse_rc = rc;
-      w.parse_msg = pm_last_error();
+  const size_t n = delta_paths.size();
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t n_threads = std::min<size_t>(n, hw == 0 ? 1 : (hw > 8 ? 8 : hw));
+  if(n_threads <= 1) {
+    for(size_t k = 0; k < n; ++k) {
+      int rc = parse_delta_file(delta_paths[k], w.table);
+      if(rc) {
+        w.parse_rc = rc;
+        w.parse_msg = pm_last_error();
+        break;
+      }
+    }
+    return;
+  }
+  // every file into a table of its own, a few files at a time; the tables are then joined in list order, up to and including
+  // the first file that failed (what it held before the failure stays)
+  std::vector<DeltaTable> part(n);
+  std::vector<int> rc(n, PM_OK);
+  std::vector<std::string> msg(n);
+  std::atomic<size_t> next(0);
+  auto work = [&]() {
+    for(size_t k = next.fetch_add(1); k < n; k = next.fetch_add(1)) {
+      part[k].ref_gap_off.push_back(0);
+      part[k].qry_gap_off.push_back(0);
+      rc[k] = parse_delta_file(delta_paths[k], part[k]);
+      if(rc[k]) {
+        msg[k] = pm_last_error(); // the error slot is per thread
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for(size_t k = 1; k < n_threads; ++k) {
+    th.emplace_back(work);
+  }
+  work();
+  for(size_t k = 0; k < th.size(); ++k) {
+    th[k].join();
+  }
+  size_t upto = n;
+  for(size_t k = 0; k < n; ++k) {
+    if(rc[k]) {
+      w.parse_rc = rc[k];
+      w.parse_msg = msg[k];
+      upto = k + 1;
       break;
     }
+  }
+  DeltaTable &t = w.table;
+  size_t entries = 0, gr = 0, gq = 0;
+  for(size_t k = 0; k < upto; ++k) {
+    entries += part[k].ref_start.size();
+    gr += part[k].ref_gap_start.size();
+    gq += part[k].qry_gap_start.size();
+  }
+  for(std::vector<std::string> *v : {&t.ref_name, &t.qry_name}) {
+    v->reserve(entries);
+  }
+  for(std::vector<long long> *v : {&t.ref_len, &t.qry_len, &t.ref_start, &t.ref_end, &t.qry_start, &t.qry_end}) {
+    v->reserve(entries);
+  }
+  t.ref_gap_off.reserve(entries + 1);
+  t.qry_gap_off.reserve(entries + 1);
+  t.ref_gap_start.reserve(gr);
+  t.ref_gap_end.reserve(gr);
+  t.qry_gap_start.reserve(gq);
+  t.qry_gap_end.reserve(gq);
+  for(size_t k = 0; k < upto; ++k) {
+    DeltaTable &p = part[k];
+    auto cat = [](std::vector<long long> &dst, const std::vector<long long> &src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    std::move(p.ref_name.begin(), p.ref_name.end(), std::back_inserter(t.ref_name));
+    std::move(p.qry_name.begin(), p.qry_name.end(), std::back_inserter(t.qry_name));
+    cat(t.ref_len, p.ref_len);
+    cat(t.qry_len, p.qry_len);
+    cat(t.ref_start, p.ref_start);
+    cat(t.ref_end, p.ref_end);
+    cat(t.qry_start, p.qry_start);
+    cat(t.qry_end, p.qry_end);
+    const long long r0 = (long long)t.ref_gap_start.size(), q0 = (long long)t.qry_gap_start.size();
+    for(size_t e = 1; e < p.ref_gap_off.size(); ++e) {
+      t.ref_gap_off.push_back(r0 + p.ref_gap_off[e]);
+      t.qry_gap_off.push_back(q0 + p.qry_gap_off[e]);
+    }
+    cat(t.ref_gap_start, p.ref_gap_start);
+    cat(t.ref_gap_end, p.ref_gap_end);
+    cat(t.qry_gap_start, p.qry_gap_start);
+    cat(t.qry_gap_end, p.qry_gap_end);
+    p = DeltaTable();
   }
 }
 
@@ -627,11 +797,17 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   // the HIP runtime takes ~0.25 s to come up in a fresh process: let it do so while the host parses
   int init_rc = PM_OK;
   std::string init_msg;
+  double init_s = 0;
   std::thread init([&]() {
+    const double i0 = wall_now();
     init_rc = use_device(device);
     if(init_rc) {
       init_msg = pm_last_error(); // the error slot is per thread
     }
+    else {
+      (void)warm_translate_kernels(); // the context and the kernels' code object, not just the device index
+    }
+    init_s = wall_now() - i0;
   });
   Workload w;
   int load_rc = load_workload(left_dir, right_dir, delta_paths, w);
@@ -645,9 +821,125 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   }
   double t1 = now();
   if(timing) {
-    fprintf(stderr, "[pm] parse + enumerate: %.3f s (%zu units)\n", t1 - t0, w.units.delta.size());
+    fprintf(stderr, "[pm] parse + enumerate: %.3f s (%zu units); HIP runtime start-up beside it: %.3f s\n", t1 - t0, w.units.delta.size(), init_s);
   }
   return run_workload(w, out, device);
+}
+
+// The job's text from HBM to the sink, in pieces: while piece k is written (a stream: by a second thread, straight to the file
+// descriptor at the piece's place), piece k + 1 is on its way.  The host buffer is this thread's own and is kept: a resident
+// worker's second call finds its pages mapped, and from then on the buffer is pinned (copies at the link's speed).
+struct TextBuffer {
+  char *p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  int uses = 0;
+  ~TextBuffer() { release(); }
+  void release() {
+    if(p) {
+      if(pinned) {
+        (void)hipHostFree(p);
+      }
+      else {
+        free(p);
+      }
+    }
+    p = nullptr;
+    cap = 0;
+  }
+  bool reserve(size_t n) {
+    ++uses;
+    const bool want_pinned = uses > 1; // a process that comes back is a resident one
+    if(p && cap >= n && (pinned || !want_pinned)) {
+      return true;
+    }
+    release();
+    const size_t room = n + n / 8 + 4096;
+    if(want_pinned && hipHostMalloc((void **)&p, room, hipHostMallocDefault) == hipSuccess) {
+      pinned = true;
+      cap = room;
+      return true;
+    }
+    (void)hipGetLastError();
+    pinned = false;
+    p = (char *)malloc(room);
+    cap = p ? room : 0;
+    return p != nullptr;
+  }
+};
+
+static int fetch_text(pm_job_t *job, int64_t n_bytes, OutSink out, bool timing, const std::function<void()> &copied) {
+  static thread_local TextBuffer buf;
+  const double t0 = wall_now();
+  if(!buf.reserve((size_t)n_bytes)) {
+    return fail(PM_E_INVALID, "out of host memory");
+  }
+  const int64_t piece = (int64_t)8 << 20;
+  const int64_t n_pieces = (n_bytes + piece - 1) / piece;
+  // a stream sink: flush what the caller printed so far, then write the pieces at their places through the descriptor
+  long long base = -1;
+  int fd = -1;
+  if(out.f) {
+    if(fflush(out.f) == 0) {
+      base = (long long)ftello(out.f);
+      fd = fileno(out.f);
+    }
+    if(base < 0 || fd < 0) {
+      base = -1; // not seekable (a pipe): plain fwrite below
+    }
+  }
+  std::atomic<int64_t> ready(0);
+  std::atomic<int> write_failed(0);
+  std::thread writer;
+  if(base >= 0) {
+    writer = std::thread([&]() {
+      for(int64_t k = 0; k < n_pieces; ++k) {
+        while(ready.load(std::memory_order_acquire) <= k) {
+          if(ready.load(std::memory_order_acquire) < 0) {
+            return;
+          }
+          std::this_thread::yield();
+        }
+        const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
+        int64_t done = 0;
+        while(done < n) {
+          const ssize_t w = pwrite(fd, buf.p + first + done, (size_t)(n - done), (off_t)(base + first + done));
+          if(w <= 0) {
+            write_failed.store(1);
+            return;
+          }
+          done += w;
+        }
+      }
+    });
+  }
+  int rc = PM_OK;
+  for(int64_t k = 0; k < n_pieces && !rc; ++k) {
+    const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
+    rc = pm_job_text_fetch_range(job, buf.p + first, first, n);
+    if(!rc) {
+      ready.store(k + 1, std::memory_order_release);
+    }
+  }
+  if(rc) {
+    ready.store(-1, std::memory_order_release);
+  }
+  copied(); // nothing below needs the job
+  const double t1 = wall_now();
+  if(writer.joinable()) {
+    writer.join();
+    if(!rc && (write_failed.load() || fseeko(out.f, (off_t)(base + n_bytes), SEEK_SET) != 0)) {
+      rc = fail(PM_E_IO, "write failed");
+    }
+  }
+  else if(!rc && !out.write(buf.p, (size_t)n_bytes)) {
+    rc = fail(PM_E_IO, "write failed");
+  }
+  if(timing) {
+    fprintf(stderr, "[pm]   text to the host (%s buffer): %.4f s; the rest of the writing: %.4f s\n", buf.pinned ? "pinned" : "pageable", t1 - t0,
+            wall_now() - t1);
+  }
+  return rc;
 }
 
 // The device part of a translate job and the text of its output: upload + prepare + sizing, one pass, fetch, format + write.
@@ -696,19 +988,16 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
       rc = pm_job_text(job, ln.data(), rn.data(), &n_bytes, &failed, &failed_status);
     }
     double t4 = now();
+    // the job's forty device buffers are freed (milliseconds of hipFree) while the last pieces of the text are written
+    std::thread reaper;
+    auto reap = [&]() { reaper = std::thread([job]() { pm_job_destroy(job); }); };
     if(!rc && n_bytes > 0) {
-      HostArray<char> text((size_t)n_bytes); // not value-initialised; its pages are touched by a few threads before the copy lands
-      if(!text.ok()) {
-        pm_job_destroy(job);
-        return fail(PM_E_INVALID, "out of host memory");
-      }
-      touch_pages({{text.bytes(), text.size_bytes()}});
-      rc = pm_job_text_fetch(job, text.data());
-      if(!rc && !out.write(text.data(), (size_t)n_bytes)) {
-        rc = fail(PM_E_IO, "write failed");
-      }
+      rc = fetch_text(job, n_bytes, out, timing, reap);
     }
-    pm_job_destroy(job);
+    else {
+      reap();
+    }
+    reaper.join();
     if(rc) {
       return rc;
     }
@@ -808,8 +1097,9 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
     });
     std::thread warm([&]() {
       for(int k = 0; k < n_devices; ++k) {
-        (void)use_device(devices[k]);
-        (void)hipFree(nullptr);
+        if(use_device(devices[k]) == PM_OK) {
+          (void)warm_translate_kernels();
+        }
       }
     });
     int rc_l = load_side(left_dir, left);

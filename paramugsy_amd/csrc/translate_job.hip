@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 
 #include <rocprim/rocprim.hpp>
 
@@ -334,6 +335,16 @@ __global__ void s2p_batch_kernel(RowsD rows, i64 n, const int *row, const i64 *p
   int st = seq_idx_of_profile_idx(row_view(rows, r), pi[q], v, none);
   status[q] = st ? st : (none ? PM_ST_IS_NONE : PM_ST_OK);
   out[q] = v;
+}
+
+// The first launch of a kernel of this file makes the HIP runtime load the file's code object (tens of milliseconds in a fresh
+// process): a caller that still has host work to do (parsing) asks for that load early, on another thread, with this.
+__global__ void translate_warm_kernel() {}
+int warm_translate_kernels() {
+  translate_warm_kernel<<<1, 1>>>();
+  PM_HIP(hipGetLastError());
+  PM_HIP(hipDeviceSynchronize());
+  return PM_OK;
 }
 
 // ------------------------------------------------------------------ the writer's text, on the device
@@ -855,6 +866,21 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
       return rc_;      \
     }                  \
   } while(0)
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto wall = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+  };
+  double lap_t = wall();
+  auto lap = [&](const char *what) {
+    if(timing) {
+      (void)hipStreamSynchronize(stream);
+      const double t = wall();
+      fprintf(stderr, "[pm]   job create: %-34s %.4f s\n", what, t - lap_t);
+      lap_t = t;
+    }
+  };
   JTRY(j->maxabs.alloc(8));
   JTRY(j->narrow_trip.alloc(4));
   if(hipMemsetAsync(j->maxabs.p, 0, 8, stream) != hipSuccess || hipMemsetAsync(j->narrow_trip.p, 0, 4, stream) != hipSuccess) {
@@ -864,6 +890,7 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   JTRY(upload_rows(left, j->left, stream, (unsigned long long *)j->maxabs.p));
   JTRY(upload_rows(right, j->right, stream, (unsigned long long *)j->maxabs.p));
   JTRY(upload_deltas(deltas, j->deltas, stream, (unsigned long long *)j->maxabs.p));
+  lap("rows + deltas up, prepared");
   i64 U = j->n_units = units->n;
   JTRY(j->u_delta.upload(units->delta, (size_t)U * 4, stream));
   JTRY(j->u_left.upload(units->left, (size_t)U * 4, stream));
@@ -910,6 +937,7 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
     JTRY(j->scan_tmp32.alloc(tmp32 ? tmp32 : 8));
   }
   JTRY(j->scan_tmp.alloc(tmp ? tmp : 8));
+  lap("units up, per-unit arrays");
   // int or int64 tables?  int when every magnitude in the tables is below the limit (PM_TRANSLATE_WIDE=1 forces int64)
   {
     unsigned long long big = 0;
@@ -941,6 +969,7 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   }
   j->ent_cap = j->n_entries;
   j->off_cap = j->n_offsets;
+  lap("sizing pass");
   // units for the FIX pass (none unless the tables contradict themselves): their list, and room for the gaps of a segment --
   // a gap owns at least one of the unit's offsets, so twice the unit's offset count in words is always enough
   {
@@ -1010,6 +1039,7 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
     j->input_bytes = (j->left.n + j->right.n) * (2 * c + c + 8 + 4) + (j->left.G + j->right.G) * (2 * c + c) +
                      j->deltas.n * (4 * c + 16 + 4) + (j->deltas.Gr + j->deltas.Gq) * (2 * c + c) + U * 12;
   }
+  lap("states + output buffers");
 #undef JTRY
   *out = j;
   return PM_OK;
@@ -1229,6 +1259,17 @@ int pm_job_text(pm_job_t *j, const char *const *left_major, const char *const *r
     if(ff != no_fail) {
       PM_HIP(hipMemcpy(failed_status, (int *)j->status.p + ff, 4, hipMemcpyDeviceToHost));
     }
+  }
+  return PM_OK;
+}
+
+int pm_job_text_fetch_range(pm_job_t *j, char *out, int64_t first, int64_t n) {
+  if(!j || j->text_bytes < 0 || first < 0 || n < 0 || first + n > j->text_bytes || (n > 0 && !out)) {
+    return fail(PM_E_INVALID, "pm_job_text_fetch_range: bad range (or pm_job_text has not been called)");
+  }
+  PM_TRY(use_device(j->device));
+  if(n > 0) {
+    PM_HIP(hipMemcpy(out, (const char *)j->t_text.p + first, (size_t)n, hipMemcpyDeviceToHost));
   }
   return PM_OK;
 }
