@@ -23,6 +23,7 @@
 #include <cstring>
 #include <ctime>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,6 +34,7 @@
 
 namespace pm {
 int warm_translate_kernels(); // translate_job.hip
+void warm_text_staging();   // below
 }
 
 #include <sys/stat.h>
@@ -805,7 +807,14 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
       init_msg = pm_last_error(); // the error slot is per thread
     }
     else {
-      (void)warm_translate_kernels(); // the context and the kernels' code object, not just the device index
+      const double i1 = wall_now();
+      (void)hipFree(nullptr); // the context
+      const double i2 = wall_now();
+      (void)warm_translate_kernels(); // and the kernels' code object
+      warm_text_staging();
+      if(timing) {
+        fprintf(stderr, "[pm]   start-up: device %.4f s; context %.4f s; code object %.4f s\n", i1 - i0, i2 - i1, wall_now() - i2);
+      }
     }
     init_s = wall_now() - i0;
   });
@@ -826,55 +835,58 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   return run_workload(w, out, device);
 }
 
-// The job's text from HBM to the sink, in pieces: while piece k is written (a stream: by a second thread, straight to the file
-// descriptor at the piece's place), piece k + 1 is on its way.  The host buffer is this thread's own and is kept: a resident
-// worker's second call finds its pages mapped, and from then on the buffer is pinned (copies at the link's speed).
-struct TextBuffer {
-  char *p = nullptr;
-  size_t cap = 0;
-  bool pinned = false;
-  int uses = 0;
-  ~TextBuffer() { release(); }
-  void release() {
-    if(p) {
-      if(pinned) {
-        (void)hipHostFree(p);
-      }
-      else {
-        free(p);
+// The job's text from HBM to the sink, in pieces, through two pinned staging buffers: while piece k is written (a stream: by a
+// second thread, straight to the file descriptor at the piece's place; a string: appended), piece k + 1 is on its way.  No big
+// host buffer: nothing to allocate, fault in or pin for a 64 MB text, and the copies run at the link's speed.  (Copying pieces into
+// one big pageable buffer while earlier pieces of it are being written fails: the runtime pins the destination of a large copy in
+// place, and write(2) from a range that is being pinned or unpinned returns EFAULT.)  The staging buffers are this thread's own
+// and are kept for its next call.
+struct TextStaging {
+  static const int64_t piece = (int64_t)8 << 20;
+  char *p[2] = {nullptr, nullptr};
+  int reserve() {
+    for(int k = 0; k < 2; ++k) {
+      if(!p[k]) {
+        PM_HIP(hipHostMalloc((void **)&p[k], (size_t)piece, hipHostMallocPortable));
       }
     }
-    p = nullptr;
-    cap = 0;
-  }
-  bool reserve(size_t n) {
-    ++uses;
-    const bool want_pinned = uses > 1; // a process that comes back is a resident one
-    if(p && cap >= n && (pinned || !want_pinned)) {
-      return true;
-    }
-    release();
-    const size_t room = n + n / 8 + 4096;
-    if(want_pinned && hipHostMalloc((void **)&p, room, hipHostMallocDefault) == hipSuccess) {
-      pinned = true;
-      cap = room;
-      return true;
-    }
-    (void)hipGetLastError();
-    pinned = false;
-    p = (char *)malloc(room);
-    cap = p ? room : 0;
-    return p != nullptr;
+    return PM_OK;
   }
 };
+// Staging pairs not in use (kept for the life of the process: a resident worker reuses them, a short-lived tool leaves with them)
+static std::mutex g_staging_lock;
+static std::vector<TextStaging> g_staging_free;
+static int staging_acquire(TextStaging &st) {
+  {
+    std::lock_guard<std::mutex> hold(g_staging_lock);
+    if(!g_staging_free.empty()) {
+      st = g_staging_free.back();
+      g_staging_free.pop_back();
+      return PM_OK;
+    }
+  }
+  return st.reserve();
+}
+static void staging_release(const TextStaging &st) {
+  std::lock_guard<std::mutex> hold(g_staging_lock);
+  g_staging_free.push_back(st);
+}
+// start-up helper: a pair allocated ahead of its use (pinning 16 MB takes a millisecond or two)
+void warm_text_staging() {
+  TextStaging st;
+  if(st.reserve() == PM_OK) {
+    staging_release(st);
+  }
+  else {
+    (void)hipGetLastError();
+  }
+}
 
 static int fetch_text(pm_job_t *job, int64_t n_bytes, OutSink out, bool timing, const std::function<void()> &copied) {
-  static thread_local TextBuffer buf;
+  TextStaging stage;
   const double t0 = wall_now();
-  if(!buf.reserve((size_t)n_bytes)) {
-    return fail(PM_E_INVALID, "out of host memory");
-  }
-  const int64_t piece = (int64_t)8 << 20;
+  PM_TRY(staging_acquire(stage));
+  const int64_t piece = TextStaging::piece;
   const int64_t n_pieces = (n_bytes + piece - 1) / piece;
   // a stream sink: flush what the caller printed so far, then write the pieces at their places through the descriptor
   long long base = -1;
@@ -885,38 +897,50 @@ static int fetch_text(pm_job_t *job, int64_t n_bytes, OutSink out, bool timing, 
       fd = fileno(out.f);
     }
     if(base < 0 || fd < 0) {
-      base = -1; // not seekable (a pipe): plain fwrite below
+      base = -1; // not seekable (a pipe): fwrite, piece by piece
     }
   }
-  std::atomic<int64_t> ready(0);
+  if(out.mem) {
+    out.mem->reserve(out.mem->size() + (size_t)n_bytes);
+  }
+  // ready = pieces copied, written = pieces written: piece k lives in stage.p[k & 1], which may be overwritten by piece k + 2 once
+  // piece k has been written
+  std::atomic<int64_t> ready(0), written(0);
   std::atomic<int> write_failed(0);
-  std::thread writer;
-  if(base >= 0) {
-    writer = std::thread([&]() {
-      for(int64_t k = 0; k < n_pieces; ++k) {
-        while(ready.load(std::memory_order_acquire) <= k) {
-          if(ready.load(std::memory_order_acquire) < 0) {
-            return;
-          }
-          std::this_thread::yield();
+  std::thread writer([&]() {
+    for(int64_t k = 0; k < n_pieces; ++k) {
+      while(ready.load(std::memory_order_acquire) <= k) {
+        if(ready.load(std::memory_order_acquire) < 0) {
+          return;
         }
-        const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
+        std::this_thread::yield();
+      }
+      const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
+      const char *src = stage.p[k & 1];
+      if(base >= 0) {
         int64_t done = 0;
         while(done < n) {
-          const ssize_t w = pwrite(fd, buf.p + first + done, (size_t)(n - done), (off_t)(base + first + done));
+          const ssize_t w = pwrite(fd, src + done, (size_t)(n - done), (off_t)(base + first + done));
           if(w <= 0) {
-            write_failed.store(1);
-            return;
+            write_failed.store(errno ? errno : EIO);
+            break;
           }
           done += w;
         }
       }
-    });
-  }
+      else if(!out.write(src, (size_t)n)) {
+        write_failed.store(EIO);
+      }
+      written.store(k + 1, std::memory_order_release);
+    }
+  });
   int rc = PM_OK;
   for(int64_t k = 0; k < n_pieces && !rc; ++k) {
+    while(written.load(std::memory_order_acquire) + 2 <= k) { // the buffer still holds piece k - 2
+      std::this_thread::yield();
+    }
     const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
-    rc = pm_job_text_fetch_range(job, buf.p + first, first, n);
+    rc = pm_job_text_fetch_range(job, stage.p[k & 1], first, n);
     if(!rc) {
       ready.store(k + 1, std::memory_order_release);
     }
@@ -926,17 +950,16 @@ static int fetch_text(pm_job_t *job, int64_t n_bytes, OutSink out, bool timing, 
   }
   copied(); // nothing below needs the job
   const double t1 = wall_now();
-  if(writer.joinable()) {
-    writer.join();
-    if(!rc && (write_failed.load() || fseeko(out.f, (off_t)(base + n_bytes), SEEK_SET) != 0)) {
-      rc = fail(PM_E_IO, "write failed");
-    }
+  writer.join();
+  if(!rc && write_failed.load()) {
+    rc = fail(PM_E_IO, std::string("write failed: ") + strerror(write_failed.load()));
   }
-  else if(!rc && !out.write(buf.p, (size_t)n_bytes)) {
-    rc = fail(PM_E_IO, "write failed");
+  if(!rc && base >= 0 && fseeko(out.f, (off_t)(base + n_bytes), SEEK_SET) != 0) {
+    rc = fail(PM_E_IO, std::string("write failed: fseeko: ") + strerror(errno));
   }
+  staging_release(stage);
   if(timing) {
-    fprintf(stderr, "[pm]   text to the host (%s buffer): %.4f s; the rest of the writing: %.4f s\n", buf.pinned ? "pinned" : "pageable", t1 - t0,
+    fprintf(stderr, "[pm]   text to the host, piece by piece beside the writing: %.4f s; the last pieces' writing: %.4f s\n", t1 - t0,
             wall_now() - t1);
   }
   return rc;
