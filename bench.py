@@ -339,7 +339,10 @@ def dp_inputs_for(cfg_name, cfg, rank, world, scaling, device):
         lo, hi = 0, n_total
         seed += rank
     if cfg_name == "c1" and hi - lo == 10000 and rows == 2 and L == 1000:
-        return dpm.synth_pairs_fast(seed, 10000, rows, L), (n_total if scaling == "strong" else n_total * world)
+        # the generator rounds 1 and 2 measured c1 with, now keeping the rows it counts (for the text-fed transfer-inclusive pass)
+        inputs, side_a, side_b = dpm.synth_pairs_fast(seed, 10000, rows, L, with_rows=True)
+        inputs.row_texts = (side_a, side_b)
+        return inputs, (n_total if scaling == "strong" else n_total * world)
     if L > 0:
         la = np.full(n_total, L, dtype=np.int64)
         lb = la
@@ -553,6 +556,28 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
                                      "best of 3; results equal the resident batch's: %s"
                                      % ((pa.a.nbytes + pb.a.nbytes) / 1e6, po.a.nbytes / 1e6,
                                         bool(np.array_equal(ps.a, r_scores) and np.array_equal(pn.a, r_nops)))}
+        if getattr(inputs, "row_texts", None) is not None:
+            # the same from the ROWS the columns count (pm_dp_stream_align_text): rows x columns bytes up instead of 8 per column,
+            # packed on the device
+            sides, pins = [], []
+            for text, row_off, block_row in inputs.row_texts:
+                pt = dpm.PinnedArray(text.shape, np.uint8)
+                pt.a[...] = text
+                pins.append(pt)
+                sides.append((pt.a, row_off, block_row))
+            st.align_text(sides[0], sides[1], ps.a, po.a, pn.a)
+            best_t = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                st.align_text(sides[0], sides[1], ps.a, po.a, pn.a)
+                best_t = min(best_t, time.perf_counter() - t0)
+            out["end_to_end"]["from_row_texts"] = {
+                "value": cells / best_t / 1e9, "unit": "GCUPS", "ms": best_t * 1e3,
+                "what": "pm_dp_stream_align_text: pinned row texts in (%.0f MB), packed on the device, scores + paths out; best of 3; results "
+                        "equal the resident batch's: %s" % (sum(p.a.nbytes for p in pins) / 1e6,
+                                                            bool(np.array_equal(ps.a, r_scores) and np.array_equal(pn.a, r_nops)))}
+            for pt in pins:
+                pt.close()
         st.close()
         for x in (pa, pb, ps, pn, po):
             x.close()

@@ -263,6 +263,13 @@ void pm_dp_host_free(void *ptr);
 int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t workspace_bytes, int device, pm_dp_stream_t **out);
 int pm_dp_stream_align(pm_dp_stream_t *stream, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
                        int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops);
+/* The same fed with ROW TEXTS instead of packed columns: pair k = block k of each side in the flat description of pm_dp_pack_maf
+ * below (text, row_off, block_row).  The texts go up in the same segments and every segment is packed on the device as soon as it
+ * has arrived: the packed columns (8 bytes per column whatever the number of rows) never cross the link, so a 2-row profile moves
+ * a quarter of the bytes.  Results as pm_dp_stream_align's. */
+int pm_dp_stream_align_text(pm_dp_stream_t *stream, const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a,
+                            const int64_t *block_row_a, const uint8_t *text_b, const int64_t *row_off_b, int64_t n_rows_b,
+                            const int64_t *block_row_b, int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops);
 void pm_dp_stream_destroy(pm_dp_stream_t *stream);
 
 /* MAF blocks into the DP and out of it (csrc/dp_maf.hip).  A list of blocks is described flat: `text` holds the gapped texts of

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <vector>
 
 #include "dp_internal.hpp"
@@ -84,11 +85,18 @@ int dp_batch_load(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, c
 // piece 0 alone land in stats_first (pinned) behind ev_seg[0], those of the whole batch in the usual place behind the last event
 int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
                            int64_t n_pairs, int segments, int *stats_first, hipStream_t stream);
+int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int64_t *off_b, int64_t n_pairs, int segments, int *stats_first,
+                                hipStream_t stream, const std::function<int(int, i64, i64, i64, i64, hipStream_t)> &fill, bool have_a,
+                                bool have_b);
 // dp_batch_plan with the statistics given (dp_batch_plan itself reads the batch's own)
 int dp_batch_plan_with(pm_dp_batch *h, const int *stats, hipStream_t stream);
 // after the load has completed: validate against the statistics, choose the kernel variant, cut the batch into chunks of the
 // workspace, send the chunks' offset table on `stream`
 int dp_batch_plan(pm_dp_batch *h, hipStream_t stream);
 int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_path);
+// dp_maf.hip: the block-description check of pm_dp_pack_maf, and its kernel over a range of columns on a stream
+int dp_check_blocks(const int64_t *row_off, int64_t n_rows, const int64_t *block_row, int64_t n_blocks, const char *who);
+int dp_pack_launch(i64 first, i64 n_cols, i64 n_blocks, const i64 *col_off, const i64 *block_row, const i64 *row_off, const unsigned char *text,
+                   u64 *cols, hipStream_t stream);
 
 } // namespace pm

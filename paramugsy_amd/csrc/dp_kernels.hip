@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -657,6 +658,27 @@ int dp_batch_load(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, c
 int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
                            int64_t n_pairs, int segments, int *stats_first, hipStream_t stream) {
   const int64_t a0 = off_a[0], b0 = off_b[0];
+  return dp_batch_load_segments_from(h, off_a, off_b, n_pairs, segments, stats_first, stream,
+                                     [&](int side, i64, i64, i64 c0, i64 c1, hipStream_t st) {
+                                       if(side == 0) {
+                                         PM_HIP(hipMemcpyAsync((char *)h->cols_a.p + c0 * 8, cols_a + (a0 + c0) * 8, (size_t)(c1 - c0) * 8,
+                                                               hipMemcpyHostToDevice, st));
+                                       }
+                                       else {
+                                         PM_HIP(hipMemcpyAsync((char *)h->cols_b.p + c0 * 8, cols_b + (b0 + c0) * 8, (size_t)(c1 - c0) * 8,
+                                                               hipMemcpyHostToDevice, st));
+                                       }
+                                       return (int)PM_OK;
+                                     },
+                                     cols_a != nullptr, cols_b != nullptr);
+}
+
+// The same with the columns of a segment produced by `fill(side, first pair, end pair, first column, end column, stream)` -- a copy
+// from host columns above, or row texts copied and packed on the device (dp_maf.hip).
+int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int64_t *off_b, int64_t n_pairs, int segments, int *stats_first,
+                                hipStream_t stream, const std::function<int(int, i64, i64, i64, i64, hipStream_t)> &fill, bool have_a,
+                                bool have_b) {
+  const int64_t a0 = off_a[0], b0 = off_b[0];
   for(int64_t k = 0; k < n_pairs; ++k) {
     if(off_a[k + 1] < off_a[k] || off_b[k + 1] < off_b[k] || off_a[k + 1] - off_a[k] > (1 << 24) || off_b[k + 1] - off_b[k] > (1 << 24)) {
       return fail(PM_E_INVALID, "pm_dp_batch_create: bad profile length");
@@ -674,7 +696,7 @@ int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t 
   }
   h->total_a = h->off_a[(size_t)n_pairs];
   h->total_b = h->off_b[(size_t)n_pairs];
-  if((h->total_a > 0 && !cols_a) || (h->total_b > 0 && !cols_b)) {
+  if((h->total_a > 0 && !have_a) || (h->total_b > 0 && !have_b)) {
     return fail(PM_E_INVALID, "pm_dp_batch_create: null columns");
   }
   PM_TRY(dp_batch_reserve(h, n_pairs, h->total_a, h->total_b));
@@ -719,11 +741,11 @@ int dp_batch_load_segments(pm_dp_batch *h, const uint8_t *cols_a, const int64_t 
     const i64 lo = h->seg_first[sgi], hi = h->seg_first[sgi + 1];
     const i64 sa0 = h->off_a[(size_t)lo], sa1 = h->off_a[(size_t)hi], sb0 = h->off_b[(size_t)lo], sb1 = h->off_b[(size_t)hi];
     if(sa1 > sa0) {
-      PM_HIP(hipMemcpyAsync((char *)h->cols_a.p + sa0 * 8, cols_a + (a0 + sa0) * 8, (size_t)(sa1 - sa0) * 8, hipMemcpyHostToDevice, stream));
+      PM_TRY(fill(0, lo, hi, sa0, sa1, stream));
       dp_column_stats_kernel<<<256, 256, 0, stream>>>((const u64 *)h->cols_a.p + sa0, sa1 - sa0, (int *)h->stats.p, (int *)h->stats.p + 4);
     }
     if(sb1 > sb0) {
-      PM_HIP(hipMemcpyAsync((char *)h->cols_b.p + sb0 * 8, cols_b + (b0 + sb0) * 8, (size_t)(sb1 - sb0) * 8, hipMemcpyHostToDevice, stream));
+      PM_TRY(fill(1, lo, hi, sb0, sb1, stream));
       dp_column_stats_kernel<<<256, 256, 0, stream>>>((const u64 *)h->cols_b.p + sb0, sb1 - sb0, (int *)h->stats.p + 2, (int *)h->stats.p + 5);
     }
     PM_HIP(hipGetLastError());

@@ -49,12 +49,13 @@ __device__ __forceinline__ i64 owner_of(const i64 *off, i64 n, i64 g) {
   return lo;
 }
 
-__global__ void dp_pack_kernel(i64 n_cols, i64 n_blocks, const i64 *__restrict__ col_off, const i64 *__restrict__ block_row,
+__global__ void dp_pack_kernel(i64 first, i64 n_cols, i64 n_blocks, const i64 *__restrict__ col_off, const i64 *__restrict__ block_row,
                                const i64 *__restrict__ row_off, const unsigned char *__restrict__ text, u64 *__restrict__ cols) {
-  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(g >= n_cols) {
     return;
   }
+  g += first; // columns [first, first + n_cols) of the list of blocks
   const i64 b = owner_of(col_off, n_blocks, g);
   const i64 c = g - col_off[b];
   u64 acc = 0;
@@ -143,6 +144,21 @@ static int check_blocks(const int64_t *row_off, int64_t n_rows, const int64_t *b
         return fail(PM_E_INVALID, std::string(who) + ": rows of one block must have the same number of columns");
       }
     }
+  }
+  return PM_OK;
+}
+
+int dp_check_blocks(const int64_t *row_off, int64_t n_rows, const int64_t *block_row, int64_t n_blocks, const char *who) {
+  return check_blocks(row_off, n_rows, block_row, n_blocks, who);
+}
+
+// columns [first, first + n_cols) of a list of blocks whose texts and tables are in device memory, on `stream` (dp_stream.hip packs
+// a batch segment by segment with this)
+int dp_pack_launch(i64 first, i64 n_cols, i64 n_blocks, const i64 *col_off, const i64 *block_row, const i64 *row_off, const unsigned char *text,
+                   u64 *cols, hipStream_t stream) {
+  if(n_cols > 0) {
+    dp_pack_kernel<<<(unsigned)((n_cols + 255) / 256), 256, 0, stream>>>(first, n_cols, n_blocks, col_off, block_row, row_off, text, cols);
+    PM_HIP(hipGetLastError());
   }
   return PM_OK;
 }
@@ -266,7 +282,7 @@ struct MafSideDev {
   int pack() {
     PM_TRY(cols.alloc((size_t)std::max<i64>(n_cols, 1) * 8));
     if(n_cols > 0) {
-      dp_pack_kernel<<<(unsigned)((n_cols + 255) / 256), 256>>>(n_cols, n_blocks, (const i64 *)col_off.p, (const i64 *)block_row.p,
+      dp_pack_kernel<<<(unsigned)((n_cols + 255) / 256), 256>>>(0, n_cols, n_blocks, (const i64 *)col_off.p, (const i64 *)block_row.p,
                                                                 (const i64 *)row_off.p, (const unsigned char *)text.p, (u64 *)cols.p);
       PM_HIP(hipGetLastError());
     }

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -31,6 +32,8 @@ struct pm_dp_stream {
   hipStream_t up = nullptr, comp = nullptr, down = nullptr;
   hipEvent_t ev_comp = nullptr;
   int *host_words = nullptr; // pinned: [0..7] statistics of the first segment, [8] the fill kernel's pipe error
+  // pm_dp_stream_align_text: the two sides' row texts and tables in device memory (grow only)
+  DevBuf t_text[2], t_row_off[2], t_block_row[2], t_col_off[2];
   ~pm_dp_stream() {
     delete b;
     if(ev_comp) {
@@ -106,21 +109,14 @@ int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t 
   return PM_OK;
 }
 
-int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
-                       int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
-  if(!s || n_pairs < 0 || !off_a || !off_b || !scores) {
-    return fail(PM_E_INVALID, "pm_dp_stream_align: null argument");
-  }
-  if((ops == nullptr) != (n_ops == nullptr)) {
-    return fail(PM_E_INVALID, "pm_dp_stream_align: ops and n_ops go together");
-  }
-  PM_TRY(use_device(s->device));
-  if(n_pairs == 0) {
-    return PM_OK;
-  }
+} // extern "C"
+
+// The engine behind pm_dp_stream_align and pm_dp_stream_align_text: `load` enqueues the batch's segments on the upload stream
+// (dp_batch_load_segments*), the rest is the same.
+static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load, int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
   pm_dp_batch *b = s->b;
   const int traceback = ops != nullptr;
-  int rc = dp_batch_load_segments(b, cols_a, off_a, cols_b, off_b, n_pairs, s->segments, s->host_words, s->up);
+  int rc = load();
   auto drain = [&]() {
     for(hipStream_t st : {s->up, s->comp, s->down}) {
       hipError_t e = hipStreamSynchronize(st);
@@ -190,6 +186,86 @@ int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *
     rc = fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
   }
   return rc;
+}
+
+extern "C" {
+
+int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
+                       int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
+  if(!s || n_pairs < 0 || !off_a || !off_b || !scores) {
+    return fail(PM_E_INVALID, "pm_dp_stream_align: null argument");
+  }
+  if((ops == nullptr) != (n_ops == nullptr)) {
+    return fail(PM_E_INVALID, "pm_dp_stream_align: ops and n_ops go together");
+  }
+  PM_TRY(use_device(s->device));
+  if(n_pairs == 0) {
+    return PM_OK;
+  }
+  return stream_align_core(s, [&]() { return dp_batch_load_segments(s->b, cols_a, off_a, cols_b, off_b, n_pairs, s->segments, s->host_words, s->up); },
+                           n_pairs, scores, ops, n_ops);
+}
+
+// Row texts in instead of packed columns: pair k = block k of each side (the flat description of pm_dp_pack_maf).  The texts go up
+// in the same segments, each packed on the device by pm_dp_pack_maf's kernel as soon as it has arrived -- the packed columns
+// (8 bytes per column, whatever the number of rows) never cross the link: a 2-row profile moves a quarter of the bytes.
+int pm_dp_stream_align_text(pm_dp_stream_t *s, const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a,
+                            const uint8_t *text_b, const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs,
+                            int32_t *scores, uint8_t *ops, int32_t *n_ops) {
+  if(!s || n_pairs < 0 || !row_off_a || !row_off_b || !block_row_a || !block_row_b || !scores) {
+    return fail(PM_E_INVALID, "pm_dp_stream_align_text: null argument");
+  }
+  if((ops == nullptr) != (n_ops == nullptr)) {
+    return fail(PM_E_INVALID, "pm_dp_stream_align_text: ops and n_ops go together");
+  }
+  PM_TRY(use_device(s->device));
+  PM_TRY(dp_check_blocks(row_off_a, n_rows_a, block_row_a, n_pairs, "pm_dp_stream_align_text (A)"));
+  PM_TRY(dp_check_blocks(row_off_b, n_rows_b, block_row_b, n_pairs, "pm_dp_stream_align_text (B)"));
+  if(n_pairs == 0) {
+    return PM_OK;
+  }
+  if((row_off_a[n_rows_a] > 0 && !text_a) || (row_off_b[n_rows_b] > 0 && !text_b)) {
+    return fail(PM_E_INVALID, "pm_dp_stream_align_text: null text");
+  }
+  const uint8_t *text[2] = {text_a, text_b};
+  const int64_t *row_off[2] = {row_off_a, row_off_b}, *block_row[2] = {block_row_a, block_row_b};
+  const int64_t n_rows[2] = {n_rows_a, n_rows_b};
+  // a block has as many columns as its first row has bytes
+  std::vector<int64_t> col_off[2];
+  for(int sd = 0; sd < 2; ++sd) {
+    col_off[sd].assign((size_t)n_pairs + 1, 0);
+    for(int64_t k = 0; k < n_pairs; ++k) {
+      const int64_t r = block_row[sd][k];
+      col_off[sd][(size_t)k + 1] = col_off[sd][(size_t)k] + (r < block_row[sd][k + 1] ? row_off[sd][r + 1] - row_off[sd][r] : 0);
+    }
+  }
+  auto grow = [](DevBuf &buf, size_t bytes) { return buf.bytes >= bytes ? (int)PM_OK : buf.alloc(bytes + bytes / 8); };
+  auto load = [&]() {
+    for(int sd = 0; sd < 2; ++sd) { // the tables first (small): blocking copies from the caller's pageable arrays
+      PM_TRY(grow(s->t_text[sd], (size_t)row_off[sd][n_rows[sd]] + 16));
+      PM_TRY(grow(s->t_row_off[sd], (size_t)(n_rows[sd] + 1) * 8));
+      PM_TRY(grow(s->t_block_row[sd], (size_t)(n_pairs + 1) * 8));
+      PM_TRY(grow(s->t_col_off[sd], (size_t)(n_pairs + 1) * 8));
+      PM_HIP(hipMemcpyAsync(s->t_row_off[sd].p, row_off[sd], (size_t)(n_rows[sd] + 1) * 8, hipMemcpyHostToDevice, s->up));
+      PM_HIP(hipMemcpyAsync(s->t_block_row[sd].p, block_row[sd], (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, s->up));
+      PM_HIP(hipMemcpyAsync(s->t_col_off[sd].p, col_off[sd].data(), (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, s->up));
+    }
+    PM_HIP(hipStreamSynchronize(s->up)); // col_off's vectors and the caller's tables may be pageable
+    return dp_batch_load_segments_from(
+        s->b, col_off[0].data(), col_off[1].data(), n_pairs, s->segments, s->host_words, s->up,
+        [&](int sd, i64 lo, i64 hi, i64 c0, i64 c1, hipStream_t st) {
+          // the texts of the segment's rows (contiguous), then one thread per column of the segment
+          const int64_t t0 = row_off[sd][block_row[sd][lo]], t1 = row_off[sd][block_row[sd][hi]];
+          if(t1 > t0) {
+            PM_HIP(hipMemcpyAsync((char *)s->t_text[sd].p + t0, text[sd] + t0, (size_t)(t1 - t0), hipMemcpyHostToDevice, st));
+          }
+          return dp_pack_launch(c0, c1 - c0, n_pairs, (const i64 *)s->t_col_off[sd].p, (const i64 *)s->t_block_row[sd].p,
+                                (const i64 *)s->t_row_off[sd].p, (const unsigned char *)s->t_text[sd].p,
+                                (u64 *)(sd == 0 ? s->b->cols_a.p : s->b->cols_b.p), st);
+        },
+        true, true);
+  };
+  return stream_align_core(s, load, n_pairs, scores, ops, n_ops);
 }
 
 void pm_dp_stream_destroy(pm_dp_stream_t *s) {

@@ -95,6 +95,8 @@ def _lib():
         l.pm_dp_host_free.restype = None
         l.pm_dp_stream_create.argtypes = [C.POINTER(PmDpParams), C.c_int32, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
         l.pm_dp_stream_align.argtypes = [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 3
+        l.pm_dp_stream_align_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                              C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_dp_stream_destroy.argtypes = [C.c_void_p]
         l.pm_dp_stream_destroy.restype = None
         l._dp_bound = True
@@ -241,6 +243,23 @@ class DpStream:
             n_ops = np.zeros(n, dtype=np.int32)
         capi.check(_lib().pm_dp_stream_align(self._h, ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, n, scores.ctypes.data,
                                              ops.ctypes.data if with_paths else None, n_ops.ctypes.data if with_paths else None))
+        return scores, ops, n_ops
+
+    def align_text(self, side_a, side_b, scores: np.ndarray = None, ops: np.ndarray = None, n_ops: np.ndarray = None, with_paths: bool = True):
+        """Row texts in (pm_dp_stream_align_text): side = (text uint8, row_off int64, block_row int64), the flat description of
+        flatten_blocks; packed on the device segment by segment.  Same outputs as align()."""
+        ta, roa, bra = side_a
+        tb, rob, brb = side_b
+        n = len(bra) - 1
+        cols = lambda ro, br: sum(int(ro[br[k] + 1] - ro[br[k]]) for k in range(n) if br[k + 1] > br[k])  # noqa: E731
+        if scores is None:
+            scores = np.zeros(max(1, n), dtype=np.int32)
+        if with_paths and ops is None:
+            ops = np.zeros(max(1, cols(roa, bra) + cols(rob, brb)), dtype=np.uint8)
+            n_ops = np.zeros(max(1, n), dtype=np.int32)
+        capi.check(_lib().pm_dp_stream_align_text(self._h, ta.ctypes.data, roa.ctypes.data, len(roa) - 1, bra.ctypes.data, tb.ctypes.data,
+                                                  rob.ctypes.data, len(rob) - 1, brb.ctypes.data, n, scores.ctypes.data,
+                                                  ops.ctypes.data if with_paths else None, n_ops.ctypes.data if with_paths else None))
         return scores, ops, n_ops
 
     def close(self) -> None:
@@ -442,9 +461,11 @@ def synth_pairs(seed: int, n_pairs: int, rows: int, length: int, sub_rate: float
 
 
 def synth_pairs_fast(seed: int, n_pairs: int, rows: int, length: int, sub_rate: float = 0.08, row_noise: float = 0.1,
-                     gap_col_rate: float = 0.05, shift_rate: float = 0.3) -> DpInputs:
+                     gap_col_rate: float = 0.05, shift_rate: float = 0.3, with_rows: bool = False):
     """Vectorised generator for large benches: equal lengths; B = A's consensus with substitutions and, for a
-    fraction of pairs, a cyclic shift by a few columns (so optimal paths carry gaps)."""
+    fraction of pairs, a cyclic shift by a few columns (so optimal paths carry gaps).
+    with_rows: also return the two sides' row texts as flat block descriptions (text uint8, row_off, block_row) -- the
+    rows the packed columns count, for the entries that take MAF rows (pm_dp_stream_align_text, pm_dp_align_blocks)."""
     rng = np.random.default_rng(seed)
     L = length
     ca = rng.integers(0, 4, size=(n_pairs, L), dtype=np.int8)
@@ -454,20 +475,31 @@ def synth_pairs_fast(seed: int, n_pairs: int, rows: int, length: int, sub_rate: 
     shift = np.where(rng.random(n_pairs) < shift_rate, rng.integers(1, 6, size=n_pairs), 0)
     for k in np.nonzero(shift)[0]:
         cb[k] = np.roll(cb[k], int(shift[k]))
+    letters = np.frombuffer(SYMBOLS, dtype=np.uint8)
 
-    def counts(cons: np.ndarray) -> np.ndarray:
+    def counts(cons: np.ndarray):
         out = np.zeros((n_pairs, L, 8), dtype=np.uint8)
-        for _r in range(rows):
+        text = np.zeros((n_pairs, rows, L), dtype=np.uint8) if with_rows else None
+        for k in range(rows):
             r = cons.copy()
             noise = rng.random((n_pairs, L)) < row_noise
             r[noise] = rng.integers(0, 4, size=int(noise.sum()), dtype=np.int8)
             r[rng.random((n_pairs, L)) < gap_col_rate] = 4
             for s in range(5):
                 out[:, :, s] += (r == s)
-        return out.reshape(n_pairs * L, 8)
+            if with_rows:
+                text[:, k, :] = letters[r]
+        return out.reshape(n_pairs * L, 8), text
 
     off = (np.arange(n_pairs + 1, dtype=np.int64) * L)
-    return DpInputs(counts(ca), off, counts(cb), off.copy())
+    cols_a, text_a = counts(ca)
+    cols_b, text_b = counts(cb)
+    inputs = DpInputs(cols_a, off, cols_b, off.copy())
+    if not with_rows:
+        return inputs
+    row_off = np.arange(n_pairs * rows + 1, dtype=np.int64) * L
+    block_row = np.arange(n_pairs + 1, dtype=np.int64) * rows
+    return inputs, (text_a.reshape(-1), row_off, block_row), (text_b.reshape(-1), row_off.copy(), block_row.copy())
 
 
 def synth_batch(seed: int, la, lb, rows_a: int, rows_b: int, sub_rate: float = 0.08, row_noise: float = 0.1,

@@ -102,3 +102,60 @@ def test_variant_chosen_from_the_first_segment_is_corrected(oracle_build):
     assert np.array_equal(scores, r_scores) and np.array_equal(n_ops, r_nops)
     for p, q in zip(dp.paths_of(inputs, ops, n_ops), dp.paths_of(inputs, r_ops, r_nops)):
         assert np.array_equal(p, q)
+
+
+@pytest.mark.parametrize("segments", [1, 4, 9])
+def test_row_texts_in_equal_packed_columns_in(segments, oracle_build, monkeypatch):
+    """pm_dp_stream_align_text: the rows of MAF blocks go up and are packed on the device segment by segment; scores and paths
+    equal the resident batch over the columns pm_dp_pack_maf makes of the same rows -- blocks of different depths and widths,
+    lower case, N's, an empty block on either side."""
+    monkeypatch.setenv("PM_DP_MODE", "ckpt" if segments % 2 else "bits")
+    from test_dp_maf import random_blocks
+    rng = np.random.default_rng(segments)
+    A = random_blocks(rng, 37, max_rows=5, max_cols=700)
+    B = random_blocks(rng, 37, max_rows=5, max_cols=700)
+    A[5], B[9] = [], []
+    params = dp.make_params(3, 3)
+    ca, oa = dp.pack_maf(A)
+    cb, ob = dp.pack_maf(B)
+    inputs = dp.DpInputs(ca, oa, cb, ob)
+    r_scores, r_ops, r_nops = resident(inputs, params)
+    st = dp.DpStream(params, segments)
+    for _ in range(2):
+        scores, ops, n_ops = st.align_text(dp.flatten_blocks(A), dp.flatten_blocks(B))
+        assert np.array_equal(scores[:37], r_scores) and np.array_equal(n_ops[:37], r_nops)
+        for p, q in zip(dp.paths_of(inputs, ops, n_ops[:37]), dp.paths_of(inputs, r_ops, r_nops)):
+            assert np.array_equal(p, q)
+    s_only, _, _ = st.align_text(dp.flatten_blocks(A), dp.flatten_blocks(B), with_paths=False)
+    assert np.array_equal(s_only[:37], r_scores)
+    # the column engine still works on the same stream object afterwards
+    scores, ops, n_ops = st.align(inputs)
+    assert np.array_equal(scores, r_scores)
+    st.close()
+
+
+def test_row_texts_from_pinned_memory_large_batch(oracle_build):
+    """BASELINE configs[1]'s shape through the text entry from pinned buffers: 2-row x 1 kbp pairs, 2 bytes per column up instead
+    of 8; a sample under the oracle."""
+    import pyoracle
+    from paramugsy_amd.shard import slice_pairs
+    n, rows, L = 3000, 2, 1000
+    inputs, side_a, side_b = dp.synth_pairs_fast(23, n, rows, L, with_rows=True)
+    params = dp.make_params(rows, rows)
+    pins = []
+
+    def pinned(side):
+        t = dp.PinnedArray(side[0].shape, np.uint8)
+        t.a[...] = side[0]
+        pins.append(t)
+        return (t.a, side[1], side[2])
+    st = dp.DpStream(params, 4)
+    scores, ops, n_ops = st.align_text(pinned(side_a), pinned(side_b))
+    st.close()
+    r_scores, r_ops, r_nops = resident(inputs, params)
+    assert np.array_equal(scores, r_scores) and np.array_equal(n_ops, r_nops)
+    o_scores, o_paths = pyoracle.dp_align(slice_pairs(inputs, 0, 25), params)
+    assert np.array_equal(scores[:25], o_scores)
+    assert all(np.array_equal(p, q) for p, q in zip(dp.paths_of(inputs, ops, n_ops)[:25], o_paths))
+    for t in pins:
+        t.close()

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): the default bench line, and per workload (DP ns, DP c1, translate) one rocprofv3
+# Runs on the GPU box (through gpurun): the default bench line, and per workload (DP ns, c1, c2, deep; translate) one rocprofv3
 # kernel-trace pass and three PMC passes (FETCH_SIZE, WRITE_SIZE, SQ counters: separate runs, as the TCC slots require).
-# Outputs land in gpurun_out/refresh/; tools/refresh_profiles_local.py condenses them into profiles/ afterwards.
-# Delete the local gpurun_out/refresh/ before the call: gpurun merges new files into it and older runs would linger.
+# Raw outputs land in gpurun_out/refresh/ and are condensed on the box by tools/refresh_profiles_local.py into
+# gpurun_out/profiles_new/ (copy that into profiles/ afterwards).
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O
@@ -16,5 +16,10 @@ run() { # name, bench arguments...
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${name}_write -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/${name}_write.log 2>&1 &&
   rocprofv3 --pmc $SQ --output-format csv -d $O/${name}_sq -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/${name}_sq.log 2>&1
 }
-run ns --path dp --config ns --no-c1 && run c1 --path dp --config c1 && run tr --path translate
+run ns --path dp --config ns --no-ride-alongs && run c1 --path dp --config c1 --no-ride-alongs && run c2 --path dp --config c2 --no-ride-alongs &&
+  run deep --path dp --config deep --no-ride-alongs && run tr --path translate
+# condensed here: the raw directories are hundreds of MB, gpurun carries 64 MiB back
+cd $R && PM_PROFILE_OUT=$R/gpurun_out/profiles_new python3 tools/refresh_profiles_local.py ${1:-r03} > $R/gpurun_out/profiles_new.log 2>&1
+cp $O/bench.json $O/bench.err $R/gpurun_out/profiles_new/ 2>/dev/null
+rm -rf $O
 true

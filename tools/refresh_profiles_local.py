@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""After `gpurun -- bash tools/refresh_profiles.sh`: condense gpurun_out/refresh/ into profiles/ (see profiles/README.md).
-Round tag as first argument (default r02)."""
+"""Condenses gpurun_out/refresh/ (the rocprofv3 output directories of tools/refresh_profiles.sh) into the small files kept under
+profiles/ (see profiles/README.md).  refresh_profiles.sh runs it on the GPU box with PM_PROFILE_OUT=gpurun_out/profiles_new (the raw
+directories are far bigger than what gpurun carries back) and deletes the raw output; copy gpurun_out/profiles_new/* into
+profiles/ afterwards.  Round tag as first argument (default r03)."""
 import csv
 import json
 import os
@@ -10,17 +12,19 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "refresh")
-P = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+P = os.environ.get("PM_PROFILE_OUT") or os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 tool = os.path.join(ROOT, "tools", "summarize_prof.py")
 bench = json.load(open(os.path.join(O, "bench.json")))
 shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "%s_bench_default.json" % TAG))
 table_path = os.path.join(P, "pmc_traffic.json")
-table = json.load(open(table_path)) if os.path.exists(table_path) else {}
+old_table = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+table = json.load(open(old_table)) if os.path.exists(old_table) else {}
 keep = ("FETCH_SIZE", "WRITE_SIZE")
 sq_all = {}
 keys = {"ns": "dp:ns:%d:%d:%d" % (bench["config"]["pairs_per_rank"], bench["config"]["rows"], bench["config"]["columns"]),
-        "c1": "dp:c1:10000:2:1000", "tr": "translate:4:1000000:2500:16:6000"}
+        "c1": "dp:c1:10000:2:1000", "c2": "dp:c2:100000:4:0", "deep": "dp:deep:4096:32:10000", "tr": "translate:4:1000000:2500:16:6000"}
 for name, key in keys.items():
     if not os.path.isdir(os.path.join(O, name + "_stats")):
         continue
@@ -39,8 +43,9 @@ table["_about"] = ("per-kernel means over the dispatches of `rocprofv3 --pmc FET
 json.dump(table, open(table_path, "w"), indent=1)
 json.dump(sq_all, open(os.path.join(P, "%s_sq_counters.json" % TAG), "w"), indent=1)
 print("DP   %.1f GCUPS  %.3f ms/step  %s" % (bench["value"], bench["ms_per_step"], bench["kernel_ms"]))
-if "c1" in bench:
-    print("c1   %.1f GCUPS  %.3f ms/step  %s" % (bench["c1"]["value"], bench["c1"]["ms_per_step"], bench["c1"]["kernel_ms"]))
+for ride in ("c1", "c2", "deep"):
+    if ride in bench:
+        print("%-4s %.1f GCUPS  %.3f ms/step  %s" % (ride, bench[ride]["value"], bench[ride]["ms_per_step"], bench[ride]["kernel_ms"]))
 t = bench.get("translate")
 if t:
     print("TR   %.3g units/s  %.3f ms/step  %s  frac %.3f" % (t["value"], t["ms_per_step"], t["kernel_ms"], t["roofline"]["frac"]))
