@@ -31,6 +31,7 @@
 #include "multi.hpp"
 #include "dp_internal.hpp"
 #include "pm_internal.hpp"
+#include "translate_host.hpp"
 
 namespace pm {
 
@@ -127,6 +128,60 @@ __global__ void dp_emit_kernel(i64 n_out, i64 n_pairs, const i64 *__restrict__ o
   out[g] = ch;
 }
 
+// The merged blocks straight into the bytes of the MAF file they are written to.  One thread per (pair, path position): it reads
+// its op and the two column positions once and writes that column's byte of EVERY row of the merged block -- rows(A) + rows(B)
+// stores, each coalesced with the neighbouring threads' (consecutive positions of one output line).  line_text[q] = where the text
+// of output line q starts in the file image; pair p's lines are first_line[p] .. (A's rows first).
+__global__ void dp_emit_file_kernel(i64 n_pairs, const i64 *__restrict__ ops_off, const int *__restrict__ n_ops, const unsigned char *__restrict__ ops,
+                                    const int *__restrict__ pos_a, const int *__restrict__ pos_b, const i64 *__restrict__ block_row_a,
+                                    const i64 *__restrict__ row_off_a, const unsigned char *__restrict__ text_a, const i64 *__restrict__ block_row_b,
+                                    const i64 *__restrict__ row_off_b, const unsigned char *__restrict__ text_b, const i64 *__restrict__ first_line,
+                                    const i64 *__restrict__ line_text, char *__restrict__ out, int *bad) {
+  for(i64 p = blockIdx.y; p < n_pairs; p += gridDim.y) {
+    const i64 len = n_ops[p];
+    for(i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < len; k += (i64)gridDim.x * blockDim.x) {
+      const i64 o = ops_off[p] + k;
+      const unsigned char op = ops[o];
+      if(op > 2) {
+        atomicOr(bad, 1);
+      }
+      const i64 ca = pos_a[o] - pos_a[ops_off[p]], cb = pos_b[o] - pos_b[ops_off[p]];
+      const i64 ra0 = block_row_a[p], ra = block_row_a[p + 1] - ra0, rb0 = block_row_b[p], rb = block_row_b[p + 1] - rb0;
+      const i64 q0 = first_line[p];
+      if(ra > 0 && op != 1 && ca >= row_off_a[ra0 + 1] - row_off_a[ra0]) {
+        atomicOr(bad, 2);
+      }
+      else {
+        for(i64 r = 0; r < ra; ++r) {
+          out[line_text[q0 + r] + k] = op != 1 ? (char)text_a[row_off_a[ra0 + r] + ca] : '-';
+        }
+      }
+      if(rb > 0 && op != 2 && cb >= row_off_b[rb0 + 1] - row_off_b[rb0]) {
+        atomicOr(bad, 2);
+      }
+      else {
+        for(i64 r = 0; r < rb; ++r) {
+          out[line_text[q0 + ra + r] + k] = op != 2 ? (char)text_b[row_off_b[rb0 + r] + cb] : '-';
+        }
+      }
+    }
+  }
+}
+
+// Everything of the file that is not a row's text -- `a score=` lines, the fields in front of every text, line ends, blank lines --
+// prepared by the host as short pieces of one blob: piece q = blob[src[q] .. src[q + 1]) copied to out + dst[q].
+__global__ void dp_pieces_kernel(i64 n_pieces, const i64 *__restrict__ dst, const i64 *__restrict__ src, const char *__restrict__ blob,
+                                 char *__restrict__ out) {
+  const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(q >= n_pieces) {
+    return;
+  }
+  char *d = out + dst[q];
+  for(i64 c = src[q]; c < src[q + 1]; ++c) {
+    *d++ = blob[c];
+  }
+}
+
 // rows of one block must have one length
 static int check_blocks(const int64_t *row_off, int64_t n_rows, const int64_t *block_row, int64_t n_blocks, const char *who) {
   if(!row_off || !block_row || n_rows < 0 || n_blocks < 0 || block_row[0] != 0 || block_row[n_blocks] != n_rows || row_off[0] != 0) {
@@ -176,37 +231,17 @@ struct MafDpBlocks {
 
 // `a` opens a block, `s` lines are its rows, anything else (comments, `##maf`, blank lines, other line types) is skipped:
 // the block structure of lib/profiles_lib/maf_read_stream.cc:7-45 without its end-of-file quirks.
-static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
-  FILE *f = fopen(path.c_str(), "rb");
-  if(!f) {
-    return fail(PM_E_IO, "cannot open " + path);
-  }
-  std::string text;
-  {
-    long size = 0;
-    if(fseek(f, 0, SEEK_END) == 0 && (size = ftell(f)) > 0 && fseek(f, 0, SEEK_SET) == 0) {
-      text.resize((size_t)size);
-      text.resize(fread(&text[0], 1, (size_t)size, f));
-    }
-    char buf[1 << 16]; // whatever a non-seekable source still holds
-    size_t n;
-    while((n = fread(buf, 1, sizeof buf, f)) > 0) {
-      text.append(buf, n);
-    }
-  }
-  fclose(f);
+// The lines of text[begin, end) into `out` (tables local to the range); `open`: the range starts inside a block.
+static int parse_maf_range(const std::string &text, size_t begin, size_t end, const std::string &path, MafDpBlocks &out, bool open) {
   out.block_row.clear();
   out.rows.clear();
   out.text.clear();
-  out.text.reserve(text.size());
+  out.text.reserve(end - begin);
   out.row_off.assign(1, 0);
-  bool open = false;
-  size_t p = 0;
-  while(p < text.size()) {
-    size_t e = text.find('\n', p);
-    if(e == std::string::npos) {
-      e = text.size();
-    }
+  size_t p = begin;
+  while(p < end) {
+    const char *nl = (const char *)memchr(text.data() + p, '\n', end - p);
+    size_t e = nl ? (size_t)(nl - text.data()) : end;
     size_t le = e;
     if(le > p && text[le - 1] == '\r') {
       --le;
@@ -262,7 +297,118 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
     }
     p = e + 1;
   }
-  out.block_row.push_back((int64_t)out.rows.size()); // a file without any `a` line: block_row = {0}, no blocks
+  return PM_OK;
+}
+
+// The file is cut at block starts into a few ranges parsed side by side; their tables are then joined (the row texts copied to
+// their places by the same threads).
+static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if(!f) {
+    return fail(PM_E_IO, "cannot open " + path);
+  }
+  std::string text;
+  {
+    long size = 0;
+    if(fseek(f, 0, SEEK_END) == 0 && (size = ftell(f)) > 0 && fseek(f, 0, SEEK_SET) == 0) {
+      text.resize((size_t)size);
+      text.resize(fread(&text[0], 1, (size_t)size, f));
+    }
+    char buf[1 << 16]; // whatever a non-seekable source still holds
+    size_t n;
+    while((n = fread(buf, 1, sizeof buf, f)) > 0) {
+      text.append(buf, n);
+    }
+  }
+  fclose(f);
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t n_ranges = hw == 0 ? 1 : (hw > 16 ? 8 : (hw + 1) / 2); // two files are parsed at once: half the threads each
+  if(text.size() < ((size_t)4 << 20)) {
+    n_ranges = 1;
+  }
+  // range k starts at the first block start at or after its share of the bytes
+  std::vector<size_t> cut(n_ranges + 1, text.size());
+  cut[0] = 0;
+  for(size_t k = 1; k < n_ranges; ++k) {
+    size_t p = std::max(cut[k - 1], text.size() * k / n_ranges);
+    while(p < text.size()) {
+      const char *nl = (const char *)memchr(text.data() + p, '\n', text.size() - p);
+      if(!nl) {
+        p = text.size();
+        break;
+      }
+      p = (size_t)(nl - text.data()) + 1;
+      if(p < text.size() && text[p] == 'a' && (p + 1 == text.size() || text[p + 1] == ' ' || text[p + 1] == '\t' || text[p + 1] == '\n' || text[p + 1] == '\r')) {
+        break;
+      }
+    }
+    cut[k] = p;
+  }
+  std::vector<MafDpBlocks> part(n_ranges);
+  std::vector<int> rc(n_ranges, PM_OK);
+  std::vector<std::string> msg(n_ranges);
+  {
+    std::vector<std::thread> th;
+    auto work = [&](size_t k) {
+      rc[k] = parse_maf_range(text, cut[k], cut[k + 1], path, part[k], k > 0 && cut[k] < text.size());
+      if(rc[k]) {
+        msg[k] = pm_last_error();
+      }
+    };
+    for(size_t k = 1; k < n_ranges; ++k) {
+      th.emplace_back(work, k);
+    }
+    work(0);
+    for(size_t k = 0; k < th.size(); ++k) {
+      th[k].join();
+    }
+  }
+  for(size_t k = 0; k < n_ranges; ++k) {
+    if(rc[k]) {
+      return fail(rc[k], msg[k]);
+    }
+  }
+  if(n_ranges == 1) {
+    out = std::move(part[0]);
+    out.block_row.push_back((int64_t)out.rows.size()); // a file without any `a` line: block_row = {0}, no blocks
+    return PM_OK;
+  }
+  std::vector<size_t> row0(n_ranges + 1, 0), text0(n_ranges + 1, 0), block0(n_ranges + 1, 0);
+  for(size_t k = 0; k < n_ranges; ++k) {
+    row0[k + 1] = row0[k] + part[k].rows.size();
+    text0[k + 1] = text0[k] + part[k].text.size();
+    block0[k + 1] = block0[k] + part[k].block_row.size();
+  }
+  out.rows.resize(row0[n_ranges]);
+  out.row_off.resize(row0[n_ranges] + 1);
+  out.block_row.resize(block0[n_ranges] + 1);
+  out.text.resize(text0[n_ranges]);
+  out.row_off[row0[n_ranges]] = (int64_t)text0[n_ranges];
+  out.block_row[block0[n_ranges]] = (int64_t)row0[n_ranges];
+  {
+    std::vector<std::thread> th;
+    auto work = [&](size_t k) {
+      MafDpBlocks &p = part[k];
+      for(size_t r = 0; r < p.rows.size(); ++r) {
+        out.rows[row0[k] + r] = std::move(p.rows[r]);
+        out.row_off[row0[k] + r] = (int64_t)text0[k] + p.row_off[r];
+      }
+      for(size_t bk = 0; bk < p.block_row.size(); ++bk) {
+        out.block_row[block0[k] + bk] = (int64_t)row0[k] + p.block_row[bk];
+      }
+      if(!p.text.empty()) {
+        memcpy(&out.text[text0[k]], p.text.data(), p.text.size());
+      }
+      p = MafDpBlocks();
+    };
+    for(size_t k = 1; k < n_ranges; ++k) {
+      th.emplace_back(work, k);
+    }
+    work(0);
+    for(size_t k = 0; k < th.size(); ++k) {
+      th[k].join();
+    }
+  }
   return PM_OK;
 }
 
@@ -415,41 +561,6 @@ int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_ro
 
 } // extern "C"
 
-// The MAF file of the merged blocks: `a score=<DP score>`, then A's rows and B's rows, every `s` line keeping its leading fields;
-// merged_of(k) = the text of merged block k (rows x n_ops[k] bytes, A's rows first).
-static int write_merged_maf(const char *out_maf, const MafDpBlocks &A, const MafDpBlocks &B, int64_t n, const std::vector<int32_t> &scores,
-                            const std::vector<int32_t> &n_ops, const std::function<const uint8_t *(int64_t)> &merged_of) {
-  FILE *f = fopen(out_maf, "wb");
-  if(!f) {
-    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
-  }
-  bool ok = true;
-  std::string o = "##maf version=1 scoring=paramugsy_amd\n";
-  for(int64_t k = 0; k < n; ++k) {
-    o += "a score=" + std::to_string(scores[(size_t)k]) + "\n";
-    const int64_t ra = A.block_row[k + 1] - A.block_row[k], rb = B.block_row[k + 1] - B.block_row[k];
-    const int64_t len = n_ops[(size_t)k];
-    const uint8_t *text = merged_of(k);
-    for(int64_t r = 0; r < ra + rb; ++r) {
-      const MafDpRow &row = r < ra ? A.rows[(size_t)(A.block_row[k] + r)] : B.rows[(size_t)(B.block_row[k] + r - ra)];
-      o += row.head;
-      o += ' ';
-      o.append((const char *)text + r * len, (size_t)len);
-      o += '\n';
-    }
-    o += '\n';
-    if(o.size() > (1u << 22)) {
-      ok = ok && fwrite(o.data(), 1, o.size(), f) == o.size();
-      o.clear();
-    }
-  }
-  ok = ok && fwrite(o.data(), 1, o.size(), f) == o.size();
-  if(fclose(f) != 0 || !ok) {
-    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
-  }
-  return PM_OK;
-}
-
 // Both files parsed side by side; each parser reports through its own return value (pm_last_error is per thread).
 static int parse_two_mafs(const char *maf_a, const char *maf_b, MafDpBlocks &A, MafDpBlocks &B, const char *who) {
   int rc_b = PM_OK;
@@ -545,6 +656,170 @@ static int align_blocks_core(const uint8_t *text_a, const int64_t *row_off_a, in
   return PM_OK;
 }
 
+// Pairs [lo, hi) of a flat block description as a description of their own (tables rebased to 0; the text is not copied).
+struct BlockSlice {
+  const uint8_t *text;
+  std::vector<int64_t> row_off, block_row;
+  int64_t n_rows;
+  BlockSlice(const uint8_t *t, const int64_t *ro, const int64_t *br, int64_t lo, int64_t hi) {
+    const int64_t r0 = br[lo], r1 = br[hi];
+    n_rows = r1 - r0;
+    text = t ? t + ro[r0] : nullptr;
+    row_off.resize((size_t)n_rows + 1);
+    for(int64_t r = r0; r <= r1; ++r) {
+      row_off[(size_t)(r - r0)] = ro[r] - ro[r0];
+    }
+    block_row.resize((size_t)(hi - lo) + 1);
+    for(int64_t k = lo; k <= hi; ++k) {
+      block_row[(size_t)(k - lo)] = br[k] - r0;
+    }
+  }
+};
+
+// Blocks [of A and B, pair k = block k] -> the bytes of the MAF file of their merged blocks, into `out`: texts up, pack, DP, then
+// the file image assembled ON THE DEVICE (dp_emit_file_kernel for the rows' texts, dp_pieces_kernel for everything around them)
+// and brought back through pinned staging pieces beside the writing (device_bytes_to_sink).  with_header: the `##maf` line first.
+// What the host does in between is arithmetic on 2 numbers per block and a few dozen bytes per row.
+static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t lo, int64_t hi, const pm_dp_params_t *params, int device,
+                             bool with_header, OutSink out, const std::function<void(const char *)> &lap) {
+  const int64_t n = hi - lo;
+  std::string blob;
+  if(with_header) {
+    blob = "##maf version=1 scoring=paramugsy_amd\n";
+  }
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  if(n == 0) {
+    return out.write(blob.data(), blob.size()) ? (int)PM_OK : fail(PM_E_IO, "write failed");
+  }
+  BlockSlice sa((const uint8_t *)A.text.data(), A.row_off.data(), A.block_row.data(), lo, hi);
+  BlockSlice sb((const uint8_t *)B.text.data(), B.row_off.data(), B.block_row.data(), lo, hi);
+  PM_TRY(check_blocks(sa.row_off.data(), sa.n_rows, sa.block_row.data(), n, "pm_dp_align_maf (A)"));
+  PM_TRY(check_blocks(sb.row_off.data(), sb.n_rows, sb.block_row.data(), n, "pm_dp_align_maf (B)"));
+  std::vector<int64_t> coa((size_t)n + 1, 0), cob((size_t)n + 1, 0);
+  for(int64_t k = 0; k < n; ++k) {
+    const int64_t ra = sa.block_row[(size_t)k], rb = sb.block_row[(size_t)k];
+    coa[(size_t)k + 1] = coa[(size_t)k] + (ra < sa.block_row[(size_t)k + 1] ? sa.row_off[(size_t)ra + 1] - sa.row_off[(size_t)ra] : 0);
+    cob[(size_t)k + 1] = cob[(size_t)k] + (rb < sb.block_row[(size_t)k + 1] ? sb.row_off[(size_t)rb + 1] - sb.row_off[(size_t)rb] : 0);
+  }
+  MafSideDev SA, SB;
+  PM_TRY(SA.upload(sa.text, sa.row_off.data(), sa.n_rows, sa.block_row.data(), n, coa.data()));
+  PM_TRY(SB.upload(sb.text, sb.row_off.data(), sb.n_rows, sb.block_row.data(), n, cob.data()));
+  PM_TRY(SA.pack());
+  PM_TRY(SB.pack());
+  lap("upload + pack (device)");
+  PM_TRY(dp_batch_check_params(params));
+  std::unique_ptr<pm_dp_batch> batch(new(std::nothrow) pm_dp_batch());
+  if(!batch) {
+    return fail(PM_E_INVALID, "out of host memory");
+  }
+  PM_TRY(dp_batch_init(batch.get(), params, 0, device));
+  PM_TRY(dp_batch_load(batch.get(), (const uint8_t *)SA.cols.p, coa.data(), (const uint8_t *)SB.cols.p, cob.data(), n, nullptr));
+  PM_HIP(hipStreamSynchronize(nullptr));
+  PM_TRY(dp_batch_plan(batch.get(), nullptr));
+  PM_TRY(dp_run(batch.get(), nullptr, 1, nullptr, nullptr));
+  std::vector<int32_t> scores((size_t)n), n_ops((size_t)n);
+  int perr = 0;
+  PM_HIP(hipMemcpy(scores.data(), batch->scores.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PM_HIP(hipMemcpy(n_ops.data(), batch->n_ops.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  PM_HIP(hipMemcpy(&perr, batch->pipe_error.p, 4, hipMemcpyDeviceToHost));
+  if(perr) {
+    return fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
+  }
+  lap("DP (device)");
+  // the file image: where every line's text goes, and the pieces around the texts
+  const int64_t ops_end = coa[(size_t)n] + cob[(size_t)n];
+  if(ops_end >= ((int64_t)1 << 31)) {
+    return fail(PM_E_INVALID, "pm_dp_align_maf: more than 2^31 columns in one call");
+  }
+  const int64_t n_lines = sa.n_rows + sb.n_rows;
+  std::vector<int64_t> ops_off((size_t)n), first_line((size_t)n + 1, 0), line_text((size_t)n_lines + 1, 0), dst, src;
+  dst.reserve((size_t)(n_lines + n + 2));
+  src.reserve((size_t)(n_lines + n + 3));
+  int64_t pos = 0;
+  int64_t max_len = 1;
+  auto piece = [&](const char *p, size_t len) { // appended to the piece that is open (pieces are cut where a row's text lies between)
+    blob.append(p, len);
+    pos += (int64_t)len;
+  };
+  auto cut = [&]() { // the open piece ends here; the next starts at `pos`
+    src.push_back((int64_t)blob.size());
+    dst.push_back(pos);
+  };
+  dst.push_back(0);
+  src.push_back(0);
+  pos = (int64_t)blob.size(); // the header line, if any, opens the first piece
+  for(int64_t k = 0; k < n; ++k) {
+    const int64_t ra = sa.block_row[(size_t)k + 1] - sa.block_row[(size_t)k], rb = sb.block_row[(size_t)k + 1] - sb.block_row[(size_t)k];
+    const int64_t len = n_ops[(size_t)k];
+    max_len = std::max(max_len, len);
+    ops_off[(size_t)k] = coa[(size_t)k + 1] + cob[(size_t)k + 1] - len; // the path is the last n_ops bytes of the pair's slot
+    char a_line[48];
+    const int al = snprintf(a_line, sizeof a_line, "a score=%d\n", (int)scores[(size_t)k]);
+    piece(a_line, (size_t)al);
+    first_line[(size_t)k + 1] = first_line[(size_t)k] + ra + rb;
+    for(int64_t r = 0; r < ra + rb; ++r) {
+      const MafDpRow &row = r < ra ? A.rows[(size_t)(A.block_row[lo + k] + r)] : B.rows[(size_t)(B.block_row[lo + k] + r - ra)];
+      piece(row.head.data(), row.head.size());
+      piece(" ", 1);
+      line_text[(size_t)(first_line[(size_t)k] + r)] = pos;
+      pos += len; // the row's text: written by dp_emit_file_kernel
+      cut();
+      piece("\n", 1);
+    }
+    piece("\n", 1);
+  }
+  src.push_back((int64_t)blob.size()); // the last piece's end
+  const int64_t n_pieces = (int64_t)dst.size();
+  const int64_t n_out = pos;
+  DevBuf d_ops_off, d_n_ops, d_first_line, d_line_text, d_dst, d_src, d_blob, d_out, d_bad;
+  PM_TRY(d_ops_off.upload(ops_off.data(), (size_t)n * 8, nullptr));
+  PM_TRY(d_n_ops.upload(n_ops.data(), (size_t)n * 4, nullptr));
+  PM_TRY(d_first_line.upload(first_line.data(), (size_t)(n + 1) * 8, nullptr));
+  PM_TRY(d_line_text.upload(line_text.data(), (size_t)(n_lines + 1) * 8, nullptr));
+  PM_TRY(d_dst.upload(dst.data(), (size_t)n_pieces * 8, nullptr));
+  PM_TRY(d_src.upload(src.data(), (size_t)(n_pieces + 1) * 8, nullptr));
+  PM_TRY(d_blob.upload(blob.data(), blob.size(), nullptr));
+  PM_TRY(d_out.alloc((size_t)n_out));
+  PM_TRY(d_bad.alloc(4));
+  PM_HIP(hipMemset(d_bad.p, 0, 4));
+  {
+    // every op's column on either side: one scan each over the ops of the whole batch
+    DevBuf d_fa, d_fb, d_pa, d_pb, d_tmp;
+    PM_TRY(d_fa.alloc((size_t)ops_end * 4 + 4));
+    PM_TRY(d_fb.alloc((size_t)ops_end * 4 + 4));
+    PM_TRY(d_pa.alloc((size_t)ops_end * 4 + 4));
+    PM_TRY(d_pb.alloc((size_t)ops_end * 4 + 4));
+    if(ops_end > 0) {
+      dp_op_flags_kernel<<<(unsigned)((ops_end + 255) / 256), 256>>>(ops_end, (const unsigned char *)batch->ops.p, (int *)d_fa.p, (int *)d_fb.p);
+      PM_HIP(hipGetLastError());
+      size_t tmp_bytes = 0;
+      PM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+      PM_TRY(d_tmp.alloc(tmp_bytes));
+      PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+      PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fb.p, (int *)d_pb.p, 0, (size_t)ops_end, rocprim::plus<int>()));
+      const unsigned gx = (unsigned)std::min<int64_t>((max_len + 255) / 256, 1024), gy = (unsigned)std::min<int64_t>(n, 65535);
+      dp_emit_file_kernel<<<dim3(gx, gy), 256>>>(n, (const i64 *)d_ops_off.p, (const int *)d_n_ops.p, (const unsigned char *)batch->ops.p,
+                                                 (const int *)d_pa.p, (const int *)d_pb.p, (const i64 *)SA.block_row.p, (const i64 *)SA.row_off.p,
+                                                 (const unsigned char *)SA.text.p, (const i64 *)SB.block_row.p, (const i64 *)SB.row_off.p,
+                                                 (const unsigned char *)SB.text.p, (const i64 *)d_first_line.p, (const i64 *)d_line_text.p,
+                                                 (char *)d_out.p, (int *)d_bad.p);
+      PM_HIP(hipGetLastError());
+    }
+    dp_pieces_kernel<<<(unsigned)((n_pieces + 255) / 256), 256>>>(n_pieces, (const i64 *)d_dst.p, (const i64 *)d_src.p, (const char *)d_blob.p,
+                                                                  (char *)d_out.p);
+    PM_HIP(hipGetLastError());
+    int bad = 0;
+    PM_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost)); // waits for the kernels
+    if(bad) {
+      return fail(PM_E_INVALID, "pm_dp_align_maf: an op outside {0, 1, 2} or a path that leaves its block");
+    }
+  }
+  lap("file image (device)");
+  PM_TRY(device_bytes_to_sink((const char *)d_out.p, n_out, out, timing, []() {}));
+  lap("to the host + write");
+  return PM_OK;
+}
+
 extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, int device) {
   if(!maf_a || !maf_b || !params || !out_maf) {
     return fail(PM_E_INVALID, "pm_dp_align_maf: null argument");
@@ -564,12 +839,21 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
   PM_TRY(parse_two_mafs(maf_a, maf_b, A, B, "pm_dp_align_maf"));
   const int64_t n = (int64_t)A.block_row.size() - 1;
   lap("parse (two threads)");
-  std::vector<int32_t> scores, n_ops;
-  std::vector<uint8_t> merged;
-  std::vector<int64_t> out_off;
-  PM_TRY(align_blocks_core((const uint8_t *)A.text.data(), A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(), (const uint8_t *)B.text.data(),
-                           B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, params, device, scores, n_ops, merged, out_off, lap));
-  PM_TRY(write_merged_maf(out_maf, A, B, n, scores, n_ops, [&](int64_t k) { return merged.data() + out_off[(size_t)k]; }));
+  FILE *f = fopen(out_maf, "wb");
+  if(!f) {
+    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
+  }
+  int rc = align_maf_to_sink(A, B, 0, n, params, device, true, OutSink(f), lap);
+  std::string msg = rc ? pm_last_error() : "";
+  if(fclose(f) != 0 && !rc) {
+    rc = fail(PM_E_IO, std::string("cannot write ") + out_maf);
+  }
+  else if(rc) {
+    rc = fail(rc, msg);
+  }
+  if(rc) {
+    return rc;
+  }
   lap("write");
   return PM_OK;
 }
@@ -604,26 +888,6 @@ extern "C" int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_
 }
 
 // ------------------------------------------------------------------ several devices (multi.hpp)
-
-// Pairs [lo, hi) of a flat block description as a description of their own (tables rebased to 0; the text is not copied).
-struct BlockSlice {
-  const uint8_t *text;
-  std::vector<int64_t> row_off, block_row;
-  int64_t n_rows;
-  BlockSlice(const uint8_t *t, const int64_t *ro, const int64_t *br, int64_t lo, int64_t hi) {
-    const int64_t r0 = br[lo], r1 = br[hi];
-    n_rows = r1 - r0;
-    text = t ? t + ro[r0] : nullptr;
-    row_off.resize((size_t)n_rows + 1);
-    for(int64_t r = r0; r <= r1; ++r) {
-      row_off[(size_t)(r - r0)] = ro[r] - ro[r0];
-    }
-    block_row.resize((size_t)(hi - lo) + 1);
-    for(int64_t k = lo; k <= hi; ++k) {
-      block_row[(size_t)(k - lo)] = br[k] - r0;
-    }
-  }
-};
 
 // pack -> DP -> expansion of the pairs' contiguous slices on their devices; worker w's merged texts stay in merged[w], its scores
 // and merged widths go to their places in the whole job's arrays, part_off[w] = the slice's own text offsets (n_w + 1 values).
@@ -705,25 +969,24 @@ extern "C" int pm_dp_align_maf_multi(const char *maf_a, const char *maf_b, const
   MafDpBlocks A, B;
   PM_TRY(parse_two_mafs(maf_a, maf_b, A, B, "pm_dp_align_maf_multi"));
   const int64_t n = (int64_t)A.block_row.size() - 1;
-  std::vector<int32_t> scores, n_ops;
-  std::vector<std::vector<uint8_t> > merged;
-  std::vector<std::vector<int64_t> > part_off;
-  PM_TRY(align_blocks_multi_core((const uint8_t *)A.text.data(), A.row_off.data(), (int64_t)A.rows.size(), A.block_row.data(),
-                                 (const uint8_t *)B.text.data(), B.row_off.data(), (int64_t)B.rows.size(), B.block_row.data(), n, params, devices,
-                                 n_devices, scores, n_ops, merged, part_off));
-  // merged block k lives in the buffer of the worker whose slice holds pair k
-  std::vector<int> owner((size_t)n);
-  std::vector<int64_t> first((size_t)n_devices + 1, n);
-  for(int w = 0; w < n_devices; ++w) {
+  // every worker assembles the file bytes of its slice's merged blocks on its device and brings them to a buffer of its own; the
+  // host-side gather is writing the buffers in pair order
+  std::vector<std::string> part((size_t)n_devices);
+  PM_TRY(run_on_devices(devices, n_devices, [&](int w, int device) {
     int64_t lo, hi;
     partition(n, n_devices, w, lo, hi);
-    first[(size_t)w] = lo;
-    for(int64_t k = lo; k < hi; ++k) {
-      owner[(size_t)k] = w;
-    }
+    return align_maf_to_sink(A, B, lo, hi, params, device, w == 0, OutSink(&part[(size_t)w]), [](const char *) {});
+  }));
+  FILE *f = fopen(out_maf, "wb");
+  if(!f) {
+    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
   }
-  return write_merged_maf(out_maf, A, B, n, scores, n_ops, [&](int64_t k) {
-    const int w = owner[(size_t)k];
-    return (const uint8_t *)merged[(size_t)w].data() + part_off[(size_t)w][(size_t)(k - first[(size_t)w])];
-  });
+  bool ok = true;
+  for(int w = 0; w < n_devices; ++w) {
+    ok = ok && (part[(size_t)w].empty() || fwrite(part[(size_t)w].data(), 1, part[(size_t)w].size(), f) == part[(size_t)w].size());
+  }
+  if(fclose(f) != 0 || !ok) {
+    return fail(PM_E_IO, std::string("cannot write ") + out_maf);
+  }
+  return PM_OK;
 }

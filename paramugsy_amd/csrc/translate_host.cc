@@ -33,8 +33,9 @@
 #include "translate_host.hpp"
 
 namespace pm {
-int warm_translate_kernels(); // translate_job.hip
-void warm_text_staging();   // below
+int warm_translate_kernels();                   // translate_job.hip
+const char *job_text_device(pm_job_t *job);     // translate_job.hip: where pm_job_text left the text
+void warm_text_staging();                       // below
 }
 
 #include <sys/stat.h>
@@ -835,17 +836,18 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   return run_workload(w, out, device);
 }
 
-// The job's text from HBM to the sink, in pieces, through two pinned staging buffers: while piece k is written (a stream: by a
-// second thread, straight to the file descriptor at the piece's place; a string: appended), piece k + 1 is on its way.  No big
-// host buffer: nothing to allocate, fault in or pin for a 64 MB text, and the copies run at the link's speed.  (Copying pieces into
-// one big pageable buffer while earlier pieces of it are being written fails: the runtime pins the destination of a large copy in
-// place, and write(2) from a range that is being pinned or unpinned returns EFAULT.)  The staging buffers are this thread's own
-// and are kept for its next call.
+// Bytes in HBM to a sink, in pieces, through a few pinned staging buffers: while earlier pieces are written (a stream: by writer
+// threads, straight to the file descriptor at each piece's place; a string: appended in order), later ones are on their way.
+// No big host buffer: nothing to allocate, fault in or pin for a 64 MB text, and the copies run at the link's speed.  (Copying
+// pieces into one big pageable buffer while earlier pieces of it are being written fails: the runtime pins the destination of a
+// large copy in place, and write(2) from a range that is being pinned or unpinned returns EFAULT.)  The staging buffers are kept
+// for the life of the process: a resident worker reuses them, a short-lived tool leaves with them.
 struct TextStaging {
   static const int64_t piece = (int64_t)8 << 20;
-  char *p[2] = {nullptr, nullptr};
+  static const int n_buf = 4;
+  char *p[n_buf] = {nullptr, nullptr, nullptr, nullptr};
   int reserve() {
-    for(int k = 0; k < 2; ++k) {
+    for(int k = 0; k < n_buf; ++k) {
       if(!p[k]) {
         PM_HIP(hipHostMalloc((void **)&p[k], (size_t)piece, hipHostMallocPortable));
       }
@@ -853,7 +855,6 @@ struct TextStaging {
     return PM_OK;
   }
 };
-// Staging pairs not in use (kept for the life of the process: a resident worker reuses them, a short-lived tool leaves with them)
 static std::mutex g_staging_lock;
 static std::vector<TextStaging> g_staging_free;
 static int staging_acquire(TextStaging &st) {
@@ -871,7 +872,7 @@ static void staging_release(const TextStaging &st) {
   std::lock_guard<std::mutex> hold(g_staging_lock);
   g_staging_free.push_back(st);
 }
-// start-up helper: a pair allocated ahead of its use (pinning 16 MB takes a millisecond or two)
+// start-up helper: a set allocated ahead of its use (pinning 32 MB takes a few milliseconds)
 void warm_text_staging() {
   TextStaging st;
   if(st.reserve() == PM_OK) {
@@ -882,11 +883,18 @@ void warm_text_staging() {
   }
 }
 
-static int fetch_text(pm_job_t *job, int64_t n_bytes, OutSink out, bool timing, const std::function<void()> &copied) {
+// `copied` runs as soon as the last byte has left the device (the caller may then free the device buffer while the last pieces
+// are still being written).  The calling thread's current device must be the one `dev` lives on.
+int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool timing, const std::function<void()> &copied) {
+  if(n_bytes <= 0) {
+    copied();
+    return PM_OK;
+  }
   TextStaging stage;
   const double t0 = wall_now();
   PM_TRY(staging_acquire(stage));
   const int64_t piece = TextStaging::piece;
+  const int n_buf = TextStaging::n_buf;
   const int64_t n_pieces = (n_bytes + piece - 1) / piece;
   // a stream sink: flush what the caller printed so far, then write the pieces at their places through the descriptor
   long long base = -1;
@@ -897,60 +905,76 @@ static int fetch_text(pm_job_t *job, int64_t n_bytes, OutSink out, bool timing, 
       fd = fileno(out.f);
     }
     if(base < 0 || fd < 0) {
-      base = -1; // not seekable (a pipe): fwrite, piece by piece
+      base = -1; // not seekable (a pipe): fwrite, piece by piece, in order
     }
   }
   if(out.mem) {
     out.mem->reserve(out.mem->size() + (size_t)n_bytes);
   }
-  // ready = pieces copied, written = pieces written: piece k lives in stage.p[k & 1], which may be overwritten by piece k + 2 once
-  // piece k has been written
-  std::atomic<int64_t> ready(0), written(0);
+  // pieces at their places can be written by two threads side by side; a sink that only appends has one writer
+  const int n_writers = base >= 0 && n_pieces > 2 ? 2 : 1;
+  // ready = pieces copied so far; written[k] = piece k is out of its buffer (piece k lives in buffer k % n_buf)
+  std::atomic<int64_t> ready(0);
+  std::vector<std::atomic<int> > written((size_t)n_pieces);
+  for(int64_t k = 0; k < n_pieces; ++k) {
+    written[(size_t)k].store(0);
+  }
   std::atomic<int> write_failed(0);
-  std::thread writer([&]() {
-    for(int64_t k = 0; k < n_pieces; ++k) {
-      while(ready.load(std::memory_order_acquire) <= k) {
-        if(ready.load(std::memory_order_acquire) < 0) {
-          return;
-        }
-        std::this_thread::yield();
-      }
-      const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
-      const char *src = stage.p[k & 1];
-      if(base >= 0) {
-        int64_t done = 0;
-        while(done < n) {
-          const ssize_t w = pwrite(fd, src + done, (size_t)(n - done), (off_t)(base + first + done));
-          if(w <= 0) {
-            write_failed.store(errno ? errno : EIO);
-            break;
+  std::vector<std::thread> writers;
+  for(int w = 0; w < n_writers; ++w) {
+    writers.emplace_back([&, w]() {
+      for(int64_t k = w; k < n_pieces; k += n_writers) {
+        while(ready.load(std::memory_order_acquire) <= k) {
+          if(ready.load(std::memory_order_acquire) < 0) {
+            return;
           }
-          done += w;
+          std::this_thread::yield();
         }
+        const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
+        const char *src = stage.p[k % n_buf];
+        if(base >= 0) {
+          int64_t done = 0;
+          while(done < n) {
+            const ssize_t wr = pwrite(fd, src + done, (size_t)(n - done), (off_t)(base + first + done));
+            if(wr <= 0) {
+              write_failed.store(errno ? errno : EIO);
+              break;
+            }
+            done += wr;
+          }
+        }
+        else if(!out.write(src, (size_t)n)) {
+          write_failed.store(EIO);
+        }
+        written[(size_t)k].store(1, std::memory_order_release);
       }
-      else if(!out.write(src, (size_t)n)) {
-        write_failed.store(EIO);
-      }
-      written.store(k + 1, std::memory_order_release);
-    }
-  });
+    });
+  }
   int rc = PM_OK;
   for(int64_t k = 0; k < n_pieces && !rc; ++k) {
-    while(written.load(std::memory_order_acquire) + 2 <= k) { // the buffer still holds piece k - 2
+    while(k >= n_buf && !written[(size_t)(k - n_buf)].load(std::memory_order_acquire)) { // the buffer still holds piece k - n_buf
+      if(write_failed.load()) {
+        break;
+      }
       std::this_thread::yield();
     }
     const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
-    rc = pm_job_text_fetch_range(job, stage.p[k & 1], first, n);
-    if(!rc) {
+    hipError_t e = hipMemcpy(stage.p[k % n_buf], dev + first, (size_t)n, hipMemcpyDeviceToHost);
+    if(e != hipSuccess) {
+      rc = fail(PM_E_HIP, std::string("hipMemcpy (device to host): ") + hipGetErrorString(e));
+    }
+    else {
       ready.store(k + 1, std::memory_order_release);
     }
   }
   if(rc) {
     ready.store(-1, std::memory_order_release);
   }
-  copied(); // nothing below needs the job
+  copied(); // nothing below needs the device buffer
   const double t1 = wall_now();
-  writer.join();
+  for(size_t w = 0; w < writers.size(); ++w) {
+    writers[w].join();
+  }
   if(!rc && write_failed.load()) {
     rc = fail(PM_E_IO, std::string("write failed: ") + strerror(write_failed.load()));
   }
@@ -959,8 +983,8 @@ static int fetch_text(pm_job_t *job, int64_t n_bytes, OutSink out, bool timing, 
   }
   staging_release(stage);
   if(timing) {
-    fprintf(stderr, "[pm]   text to the host, piece by piece beside the writing: %.4f s; the last pieces' writing: %.4f s\n", t1 - t0,
-            wall_now() - t1);
+    fprintf(stderr, "[pm]   %lld bytes to the host, piece by piece beside the writing: %.4f s; the last pieces' writing: %.4f s\n",
+            (long long)n_bytes, t1 - t0, wall_now() - t1);
   }
   return rc;
 }
@@ -1015,7 +1039,7 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
     std::thread reaper;
     auto reap = [&]() { reaper = std::thread([job]() { pm_job_destroy(job); }); };
     if(!rc && n_bytes > 0) {
-      rc = fetch_text(job, n_bytes, out, timing, reap);
+      rc = device_bytes_to_sink(job_text_device(job), n_bytes, out, timing, reap);
     }
     else {
       reap();

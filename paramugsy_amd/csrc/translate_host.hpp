@@ -3,6 +3,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -76,6 +77,9 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
                OutSink out, int device);
 int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w);
 void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units);
+// Bytes in device memory to a sink through pinned staging pieces, the writing beside the copying; `copied` runs once the last byte
+// has left the device.  The calling thread's current device must be the buffer's.
+int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool timing, const std::function<void()> &copied);
 // multi.hpp: the job's delta-file list over several devices, texts joined in list order (header rule re-applied at the seams)
 int merge_shard_texts(const std::vector<std::string> &parts, size_t n_parts, OutSink out);
 int translate_to_file_multi(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,

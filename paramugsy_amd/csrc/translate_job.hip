@@ -828,6 +828,10 @@ static int job_read_totals(pm_job *j, hipStream_t stream) {
   return PM_OK;
 }
 
+namespace pm {
+const char *job_text_device(pm_job_t *j) { return (const char *)j->t_text.p; }
+} // namespace pm
+
 extern "C" {
 
 int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units, int device,

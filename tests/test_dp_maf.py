@@ -199,3 +199,43 @@ def test_score_less_a_lines_open_blocks(oracle_build, tmp_path):
     got = ora.parse_maf(po)
     assert len(got) == 2
     assert got[0][1] == [b"ACGT", b"ACGT"] and got[1][1] == [b"TTG", b"TTG"]
+
+
+@pytest.mark.gpu
+def test_large_maf_files_parsed_in_ranges_and_emitted_on_the_device(oracle_build, tmp_path):
+    """Files big enough (> 4 MB) for the parser to cut them into ranges parsed side by side, with comment lines, CR line ends and
+    blocks of different depths; the output file is the in-memory entry's merged blocks (pm_dp_align_blocks, checked against the
+    oracle elsewhere) under `a score=` lines, every `s` line keeping its six leading fields, byte for byte."""
+    rng = np.random.default_rng(77)
+    A = random_blocks(rng, 300, max_rows=6, max_cols=3500)
+    B = random_blocks(rng, 300, max_rows=6, max_cols=3500)
+    A[7], B[11], A[299], B[299] = [], [], [b"ACGT" * 3], []
+
+    def write(path, blocks, tag, cr):
+        eol = b"\r\n" if cr else b"\n"
+        with open(path, "wb") as f:
+            f.write(b"##maf version=1" + eol + b"# comment" + eol)
+            for k, b in enumerate(blocks):
+                f.write((b"a" if k % 5 == 0 else b"a score=%d" % k) + eol)
+                for r, row in enumerate(b):
+                    f.write(b"s %s.g%d\t%d %d + 100000 %s" % (tag, r, 10 * k, sum(ch not in b"-" for ch in row), row) + eol)
+                f.write(eol + (b"# between blocks" + eol if k % 7 == 0 else b""))
+    pa, pb, po = str(tmp_path / "a.maf"), str(tmp_path / "b.maf"), str(tmp_path / "out.maf")
+    write(pa, A, b"L", False)
+    write(pb, B, b"R", True)
+    assert os.path.getsize(pa) > (4 << 20) and os.path.getsize(pb) > (4 << 20)
+    params = dp.make_params(3, 3)
+    dp.align_maf_files(pa, pb, params, po)
+    scores, merged = dp.align_blocks(A, B, params)
+    want = [b"##maf version=1 scoring=paramugsy_amd\n"]
+    for k in range(300):
+        want.append(b"a score=%d\n" % scores[k])
+        heads = [b"s L.g%d\t%d %d + 100000" % (r, 10 * k, sum(ch not in b"-" for ch in row)) for r, row in enumerate(A[k])]
+        heads += [b"s R.g%d\t%d %d + 100000" % (r, 10 * k, sum(ch not in b"-" for ch in row)) for r, row in enumerate(B[k])]
+        for h, t in zip(heads, merged[k]):
+            want.append(h + b" " + t + b"\n")
+        want.append(b"\n")
+    assert open(po, "rb").read() == b"".join(want)
+    many = str(tmp_path / "many.maf")
+    dp.align_maf_files(pa, pb, params, many, devices=[0, 0, 0])
+    assert open(many, "rb").read() == open(po, "rb").read()

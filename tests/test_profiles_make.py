@@ -44,6 +44,25 @@ def test_oracle_matches_second_hand_derived_fixture():
     assert fasta == open(os.path.join(GOLDEN, "make_handmade2.fasta")).read()
 
 
+def test_oracle_matches_third_hand_derived_fixture():
+    """tests/golden/make_handmade3.* (basename hm3), derived by hand from the cited lines before the transcription was run on it:
+      * `a` without a score does NOT open a block: drop_until_score (m_profile_stream.ml:23-32) looks for the prefix "a score=" and
+        drops everything else, so the `a` line, its `s Z.c` row and the blank line vanish and the first SCORED block is _0000;
+      * a `#` line between the rows of a block is skipped and does not advance the row index (m_profile_stream.ml:52-53);
+      * fields separated by runs of blanks (split_maf filters empty tokens, :16-21);
+      * rows on the strand boundary: A.c 0 3 - 10 -> of_maf Reverse (m_range.ml:60-65) = (10-0, 10-0-2) = (10, 8); T-GA -> gaps (2,2)
+                                     B.c 7 3 - 10 -> (10-7, 10-7-2) = (3, 1) (the row ends at base 1); TTG- -> gaps (4,4)
+      * a row that is all gap: C.c 5 0 + 12 ---- -> Forward (5+1, 5+0) = (6, 5) (start past end: size 0), gaps (1,4), length 4
+        consensus of the block, combine_text folded (m_make.ml:15-28,35-45): T-GA x TTG- = TTGA; TTGA x ---- = TTGA
+      * a line that is neither blank, `#` nor `a score=` between two blocks is dropped by drop_until_score; `a score=0 x=1` opens
+        _0001, whose ONLY row is all gap: D.c 5 0 + 12 ---- -> (6, 5), gaps (1,4); its consensus is ---- itself
+      * last block, ended by the end of the file (idx > 0, :55-56): A.c 9 1 + 10 g -> (10, 10); B.c 9 1 - 10 C -> (10-9, 10-9-0) =
+        (1, 1); consensus g x C: both bases, unequal -> N."""
+    prof, fasta = make_oracle.make(open(os.path.join(GOLDEN, "make_handmade3.maf")).read(), "hm3")
+    assert prof == open(os.path.join(GOLDEN, "make_handmade3.profiles")).read()
+    assert fasta == open(os.path.join(GOLDEN, "make_handmade3.fasta")).read()
+
+
 def test_oracle_rejects_what_the_reference_rejects():
     with pytest.raises(ValueError):
         make_oracle.make("a score=1\ns\ttabbed 0 1 + 1 A\n", "x")  # "Unknown line": not prefixed by "s "
@@ -73,14 +92,14 @@ def test_profiles_written_by_oracle_are_read_back_by_the_translate_parser(tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["handmade", "handmade2", "synthetic", "empty"])
+@pytest.mark.parametrize("case", ["handmade", "handmade2", "handmade3", "synthetic", "empty"])
 def test_gpu_make_equals_oracle(case, tmp_path):
     import numpy as np
     from paramugsy_amd import capi, synth
     if case == "handmade":
         maf = open(os.path.join(GOLDEN, "make_handmade.maf")).read()
-    elif case == "handmade2":
-        maf = open(os.path.join(GOLDEN, "make_handmade2.maf")).read()
+    elif case in ("handmade2", "handmade3"):
+        maf = open(os.path.join(GOLDEN, "make_%s.maf" % case)).read()
     elif case == "synthetic":
         rng = np.random.default_rng(11)
         maf = synth.side_to_maf_text(synth.gen_side(rng, ["A.c", "B.c", "C.c"], 60000, 80, mean_cols=500, gap_rate=0.03, edge_gap_prob=0.4))
@@ -94,10 +113,10 @@ def test_gpu_make_equals_oracle(case, tmp_path):
     prof, fasta = make_oracle.make(maf, "x")
     assert (out / "profiles").read_text() == prof
     assert (out / "sequences.fasta").read_text() == fasta
-    if case == "handmade2":  # and the hand-derived bytes themselves (the fixture's basename is y)
-        capi.check(capi.lib().pm_profiles_make(str(src).encode(), str(out).encode(), b"y", 0))
-        assert (out / "profiles").read_text() == open(os.path.join(GOLDEN, "make_handmade2.profiles")).read()
-        assert (out / "sequences.fasta").read_text() == open(os.path.join(GOLDEN, "make_handmade2.fasta")).read()
+    if case in ("handmade2", "handmade3"):  # and the hand-derived bytes themselves (the fixtures' basenames are y and hm3)
+        capi.check(capi.lib().pm_profiles_make(str(src).encode(), str(out).encode(), b"y" if case == "handmade2" else b"hm3", 0))
+        assert (out / "profiles").read_text() == open(os.path.join(GOLDEN, "make_%s.profiles" % case)).read()
+        assert (out / "sequences.fasta").read_text() == open(os.path.join(GOLDEN, "make_%s.fasta" % case)).read()
 
 
 @pytest.mark.gpu

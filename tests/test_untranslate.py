@@ -64,6 +64,30 @@ def test_oracle_matches_second_hand_derived_fixture():
     assert got == open(os.path.join(case, "expected.maf")).read()
 
 
+def test_oracle_matches_third_hand_derived_fixture():
+    """tests/golden/untranslate_handmade3 (profiles = tests/golden/make_handmade3.profiles), derived by hand from
+    m_untranslate.ml:38-151 and m_profile.ml:163-264 before the transcription was run on it.  Rows of hm3.hm3_0000: A.c (10,8) gaps
+    (2,2) T-GA src 10; B.c (3,1) gaps (4,4) TTG- (both on '-', B ending at base 1: the strand boundary); C.c (6,5) gaps (1,4) ----
+    (all gap).  hm3.hm3_0001: D.c all gap.  hm3.hm3_0002: A.c (10,10) g; B.c (1,1) C.
+      `s hm3.hm3_0000 0 4 + 4 TT-GA` -> columns (1,4) forward:
+         A: seq(1) = 10, seq(4) = 10-2 = 8 -> real (10,8) Reverse: start 10-10 = 0, size 3, '-'; T-GA over TT-GA          => T--GA
+         B: gap (4,4) ends the range -> seq(3) = 3-2 = 1: real (3,1): start 10-3 = 7, size 3, '-'; TTG- over TT-GA       => TT-G-
+         C: its one gap IS the range: subset_profile = None, no line
+      the `#` line inside the block passes through where it stands (m_untranslate.ml:131-137)
+      `s hm3.hm3_0002 0 1 - 1 g` -> of_maf Reverse (1-0, 1-0-0) = (1,1), Forward by get_direction (s <= e): no reversal, no
+         complement; A (10,10): start 9 size 1 '+'; B (1,1) -- a '-' row in the MAF `make` read -- reads Forward: start 0, '+'
+      `s hm3.hm3_0001 0 4 + 4 ----` -> D is all gap: the block keeps only its `a score=1` line
+      `s hm3.hm3_0000 1 2 - 4 C-A` -> of_maf Reverse (4-1, 4-1-1) = (3,2): columns (2,3), reversed:
+         A: gap (2,2) starts the range -> seq(3) = 10-1 = 9 twice; real = reverse (9,9), Forward: start 8 size 1; strand of
+            reverse (10,8) = (8,10) = '+'; -G reversed G-, over C-A: G - -, complemented                                  => C--
+         B: no gap in (2,3): seq(2) = 2, seq(3) = 1 -> real = reverse (2,1) = (1,2): start 0 size 2 '+'; TG reversed GT over C-A:
+            G - T, complemented                                                                                            => C-A
+         C: gap (1,4) clipped to (2,3) is the whole range: None."""
+    case = os.path.join(GOLDEN, "untranslate_handmade3")
+    got = uo.untranslate([open(os.path.join(case, "profiles")).read()], open(os.path.join(case, "in.maf")).read())
+    assert got == open(os.path.join(case, "expected.maf")).read()
+
+
 def synthetic_case(seed):
     """Two profile sets from `make`, and a fake mugsy MAF whose `s` lines cover random column ranges of random blocks on
     either strand, with a few gap columns sprinkled into the line text."""
@@ -108,7 +132,7 @@ def test_oracle_output_is_a_consistent_maf(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["handmade", "handmade2", "synthetic1", "synthetic2"])
+@pytest.mark.parametrize("case", ["handmade", "handmade2", "handmade3", "synthetic1", "synthetic2"])
 def test_gpu_untranslate_equals_oracle(case, tmp_path):
     import ctypes as C
     from paramugsy_amd import capi
