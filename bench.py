@@ -209,10 +209,14 @@ def measured_traffic(kernel_substr, config_key, launches=1):
     entry = table.get(config_key)
     if not entry:
         return None
+    # every instantiation of the kernel the step launched (a batch's chunks may take different variants), weighted by dispatches
+    kb, n = 0.0, 0
     for name, c in entry.items():
         if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return int((2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)
-    return None
+            d = min(c["FETCH_SIZE"]["dispatches"], c["WRITE_SIZE"]["dispatches"])
+            kb += (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * d
+            n += d
+    return int(kb / n * 1024) if n else None
 
 
 def host_cores():

@@ -16,6 +16,9 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <functional>
 #include <new>
 #include <vector>
@@ -116,7 +119,22 @@ int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t 
 static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load, int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
   pm_dp_batch *b = s->b;
   const int traceback = ops != nullptr;
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto wall = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+  };
+  double lap_t = wall();
+  auto lap = [&](const char *what) {
+    if(timing) {
+      const double t = wall();
+      fprintf(stderr, "[pm]   stream align: %-44s %.4f s\n", what, t - lap_t);
+      lap_t = t;
+    }
+  };
   int rc = load();
+  lap("segments enqueued");
   auto drain = [&]() {
     for(hipStream_t st : {s->up, s->comp, s->down}) {
       hipError_t e = hipStreamSynchronize(st);
@@ -152,9 +170,11 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
       rc = fail(PM_E_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
     }
   }
+  lap("first segment arrived");
   if(!rc) {
     rc = dp_batch_plan_with(b, s->host_words, s->comp);
   }
+  lap("plan (first segment's statistics)");
   bool first_dot4 = false, first_uni = false;
   int first_rows = 0;
   if(!rc) {
@@ -163,6 +183,7 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
     first_rows = b->params.rows_a;
     rc = run_and_fetch();
   }
+  lap("kernels and downloads enqueued");
   if(!rc) {
     // the whole batch's statistics: refuse what pm_dp_batch_create refuses, and run again if they change the variant
     hipError_t e = hipStreamSynchronize(s->up);
@@ -179,7 +200,9 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
       }
     }
   }
+  lap("second plan (whole batch's statistics)");
   drain();
+  lap("drained");
   if(!rc && s->host_words[8]) {
     (void)hipMemset(b->pipe_error.p, 0, 4); // reported: the stream's batch is reused by the next call
     s->host_words[8] = 0;
