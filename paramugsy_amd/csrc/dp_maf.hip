@@ -27,6 +27,11 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "dp_batch.hpp"
 #include "multi.hpp"
 #include "dp_internal.hpp"
@@ -135,8 +140,9 @@ __global__ void dp_emit_kernel(i64 n_out, i64 n_pairs, const i64 *__restrict__ o
 __global__ void dp_emit_file_kernel(i64 n_pairs, const i64 *__restrict__ ops_off, const int *__restrict__ n_ops, const unsigned char *__restrict__ ops,
                                     const int *__restrict__ pos_a, const int *__restrict__ pos_b, const i64 *__restrict__ block_row_a,
                                     const i64 *__restrict__ row_off_a, const unsigned char *__restrict__ text_a, const i64 *__restrict__ block_row_b,
-                                    const i64 *__restrict__ row_off_b, const unsigned char *__restrict__ text_b, const i64 *__restrict__ first_line,
-                                    const i64 *__restrict__ line_text, char *__restrict__ out, int *bad) {
+                                    const i64 *__restrict__ row_off_b, const unsigned char *__restrict__ text_b, const i64 *__restrict__ col_off_a,
+                                    const i64 *__restrict__ col_off_b, const i64 *__restrict__ first_line, const i64 *__restrict__ line_text,
+                                    char *__restrict__ out, int *bad) {
   for(i64 p = blockIdx.y; p < n_pairs; p += gridDim.y) {
     const i64 len = n_ops[p];
     for(i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < len; k += (i64)gridDim.x * blockDim.x) {
@@ -148,7 +154,7 @@ __global__ void dp_emit_file_kernel(i64 n_pairs, const i64 *__restrict__ ops_off
       const i64 ca = pos_a[o] - pos_a[ops_off[p]], cb = pos_b[o] - pos_b[ops_off[p]];
       const i64 ra0 = block_row_a[p], ra = block_row_a[p + 1] - ra0, rb0 = block_row_b[p], rb = block_row_b[p + 1] - rb0;
       const i64 q0 = first_line[p];
-      if(ra > 0 && op != 1 && ca >= row_off_a[ra0 + 1] - row_off_a[ra0]) {
+      if(ra > 0 && op != 1 && ca >= col_off_a[p + 1] - col_off_a[p]) { // (the rows' starts may lie anywhere in the text: a mapped file)
         atomicOr(bad, 2);
       }
       else {
@@ -156,7 +162,7 @@ __global__ void dp_emit_file_kernel(i64 n_pairs, const i64 *__restrict__ ops_off
           out[line_text[q0 + r] + k] = op != 1 ? (char)text_a[row_off_a[ra0 + r] + ca] : '-';
         }
       }
-      if(rb > 0 && op != 2 && cb >= row_off_b[rb0 + 1] - row_off_b[rb0]) {
+      if(rb > 0 && op != 2 && cb >= col_off_b[p + 1] - col_off_b[p]) {
         atomicOr(bad, 2);
       }
       else {
@@ -222,26 +228,42 @@ int dp_pack_launch(i64 first, i64 n_cols, i64 n_blocks, const i64 *col_off, cons
 struct MafDpRow {
   std::string head; // "s name start size strand srcSize"
 };
+// A MAF file as the DP's file entries see it: the file mapped read-only, and where its blocks' rows lie in it.  Nothing of the
+// rows' texts is copied on the host: row r is bytes [row_off[r], row_off[r] + row_len[r]) of the mapping, and the device gets the
+// file's bytes as they are (the kernels take a start per row; lengths come from the blocks' column counts).
 struct MafDpBlocks {
   std::vector<MafDpRow> rows;
   std::vector<int64_t> block_row; // [n_blocks + 1]
-  std::string text;               // the rows' texts back to back, as pm_dp_pack_maf / pm_dp_emit_maf take them
-  std::vector<int64_t> row_off;   // [n_rows + 1]
+  std::vector<int64_t> row_off;   // [n_rows + 1]: where each row's text starts in `bytes`; the last entry is n_bytes
+  std::vector<int64_t> row_len;   // [n_rows]
+  const char *bytes = nullptr;
+  size_t n_bytes = 0;
+  void *map = nullptr; // the mapping (or nullptr when the file was read into `held`)
+  std::string held;
+  MafDpBlocks() = default;
+  MafDpBlocks(const MafDpBlocks &) = delete;
+  MafDpBlocks &operator=(const MafDpBlocks &) = delete;
+  ~MafDpBlocks() {
+    if(map) {
+      munmap(map, n_bytes);
+    }
+  }
+};
+
+// What one range of the file holds (tables local to the range; offsets are file offsets)
+struct MafDpRange {
+  std::vector<MafDpRow> rows;
+  std::vector<int64_t> block_row, row_off, row_len;
 };
 
 // `a` opens a block, `s` lines are its rows, anything else (comments, `##maf`, blank lines, other line types) is skipped:
 // the block structure of lib/profiles_lib/maf_read_stream.cc:7-45 without its end-of-file quirks.
-// The lines of text[begin, end) into `out` (tables local to the range); `open`: the range starts inside a block.
-static int parse_maf_range(const std::string &text, size_t begin, size_t end, const std::string &path, MafDpBlocks &out, bool open) {
-  out.block_row.clear();
-  out.rows.clear();
-  out.text.clear();
-  out.text.reserve(end - begin);
-  out.row_off.assign(1, 0);
+// The lines of text[begin, end) into `out`; `open`: the range starts inside a block.
+static int parse_maf_range(const char *text, size_t begin, size_t end, const std::string &path, MafDpRange &out, bool open) {
   size_t p = begin;
   while(p < end) {
-    const char *nl = (const char *)memchr(text.data() + p, '\n', end - p);
-    size_t e = nl ? (size_t)(nl - text.data()) : end;
+    const char *nl = (const char *)memchr(text + p, '\n', end - p);
+    size_t e = nl ? (size_t)(nl - text) : end;
     size_t le = e;
     if(le > p && text[le - 1] == '\r') {
       --le;
@@ -269,9 +291,9 @@ static int parse_maf_range(const std::string &text, size_t begin, size_t end, co
           text_at = q;
         }
         if(fields >= 7) { // the sequence text: long, and blanks in it are rare -- find them with memchr
-          const char *b0 = (const char *)memchr(&text[q], ' ', le - q), *b1 = (const char *)memchr(&text[q], '\t', le - q);
+          const char *b0 = (const char *)memchr(text + q, ' ', le - q), *b1 = (const char *)memchr(text + q, '\t', le - q);
           const char *stop = b0 && b1 ? (b0 < b1 ? b0 : b1) : (b0 ? b0 : b1);
-          q = stop ? (size_t)(stop - text.data()) : le;
+          q = stop ? (size_t)(stop - text) : le;
           continue;
         }
         while(q < le && text[q] != ' ' && text[q] != '\t') {
@@ -286,13 +308,13 @@ static int parse_maf_range(const std::string &text, size_t begin, size_t end, co
         --head_end;
       }
       MafDpRow r;
-      r.head.assign(text, p, head_end - p);
+      r.head.assign(text + p, head_end - p);
       size_t te = text_at;
       while(te < le && text[te] != ' ' && text[te] != '\t') {
         ++te;
       }
-      out.text.append(text, text_at, te - text_at);
-      out.row_off.push_back((int64_t)out.text.size());
+      out.row_off.push_back((int64_t)text_at);
+      out.row_len.push_back((int64_t)(te - text_at));
       out.rows.push_back(std::move(r));
     }
     p = e + 1;
@@ -300,57 +322,70 @@ static int parse_maf_range(const std::string &text, size_t begin, size_t end, co
   return PM_OK;
 }
 
-// The file is cut at block starts into a few ranges parsed side by side; their tables are then joined (the row texts copied to
-// their places by the same threads).
+// The file is mapped and cut at block starts into a few ranges whose lines are indexed side by side.
 static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
-  FILE *f = fopen(path.c_str(), "rb");
-  if(!f) {
-    return fail(PM_E_IO, "cannot open " + path);
-  }
-  std::string text;
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto wall = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = wall();
   {
-    long size = 0;
-    if(fseek(f, 0, SEEK_END) == 0 && (size = ftell(f)) > 0 && fseek(f, 0, SEEK_SET) == 0) {
-      text.resize((size_t)size);
-      text.resize(fread(&text[0], 1, (size_t)size, f));
+    const int fd = open(path.c_str(), O_RDONLY);
+    if(fd < 0) {
+      return fail(PM_E_IO, "cannot open " + path);
     }
-    char buf[1 << 16]; // whatever a non-seekable source still holds
-    size_t n;
-    while((n = fread(buf, 1, sizeof buf, f)) > 0) {
-      text.append(buf, n);
+    struct stat st;
+    void *m = MAP_FAILED;
+    if(fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
     }
+    if(m != MAP_FAILED) {
+      out.map = m;
+      out.bytes = (const char *)m;
+      out.n_bytes = (size_t)st.st_size;
+    }
+    else { // not a regular file (a pipe), or empty: read it
+      char buf[1 << 16];
+      ssize_t n;
+      while((n = read(fd, buf, sizeof buf)) > 0) {
+        out.held.append(buf, (size_t)n);
+      }
+      out.bytes = out.held.data();
+      out.n_bytes = out.held.size();
+    }
+    close(fd);
   }
-  fclose(f);
+  const char *text = out.bytes;
+  const size_t size = out.n_bytes;
+  const double t_read = wall();
   unsigned hw = std::thread::hardware_concurrency();
   size_t n_ranges = hw == 0 ? 1 : (hw > 16 ? 8 : (hw + 1) / 2); // two files are parsed at once: half the threads each
-  if(text.size() < ((size_t)4 << 20)) {
+  if(size < ((size_t)4 << 20)) {
     n_ranges = 1;
   }
   // range k starts at the first block start at or after its share of the bytes
-  std::vector<size_t> cut(n_ranges + 1, text.size());
+  std::vector<size_t> cut(n_ranges + 1, size);
   cut[0] = 0;
   for(size_t k = 1; k < n_ranges; ++k) {
-    size_t p = std::max(cut[k - 1], text.size() * k / n_ranges);
-    while(p < text.size()) {
-      const char *nl = (const char *)memchr(text.data() + p, '\n', text.size() - p);
+    size_t p = std::max(cut[k - 1], size * k / n_ranges);
+    while(p < size) {
+      const char *nl = (const char *)memchr(text + p, '\n', size - p);
       if(!nl) {
-        p = text.size();
+        p = size;
         break;
       }
-      p = (size_t)(nl - text.data()) + 1;
-      if(p < text.size() && text[p] == 'a' && (p + 1 == text.size() || text[p + 1] == ' ' || text[p + 1] == '\t' || text[p + 1] == '\n' || text[p + 1] == '\r')) {
+      p = (size_t)(nl - text) + 1;
+      if(p < size && text[p] == 'a' && (p + 1 == size || text[p + 1] == ' ' || text[p + 1] == '\t' || text[p + 1] == '\n' || text[p + 1] == '\r')) {
         break;
       }
     }
     cut[k] = p;
   }
-  std::vector<MafDpBlocks> part(n_ranges);
+  std::vector<MafDpRange> part(n_ranges);
   std::vector<int> rc(n_ranges, PM_OK);
   std::vector<std::string> msg(n_ranges);
   {
     std::vector<std::thread> th;
     auto work = [&](size_t k) {
-      rc[k] = parse_maf_range(text, cut[k], cut[k + 1], path, part[k], k > 0 && cut[k] < text.size());
+      rc[k] = parse_maf_range(text, cut[k], cut[k + 1], path, part[k], k > 0 && cut[k] < size);
       if(rc[k]) {
         msg[k] = pm_last_error();
       }
@@ -368,46 +403,43 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
       return fail(rc[k], msg[k]);
     }
   }
-  if(n_ranges == 1) {
-    out = std::move(part[0]);
-    out.block_row.push_back((int64_t)out.rows.size()); // a file without any `a` line: block_row = {0}, no blocks
-    return PM_OK;
-  }
-  std::vector<size_t> row0(n_ranges + 1, 0), text0(n_ranges + 1, 0), block0(n_ranges + 1, 0);
+  const double t_parsed = wall();
+  size_t n_rows = 0, n_blocks = 0;
   for(size_t k = 0; k < n_ranges; ++k) {
-    row0[k + 1] = row0[k] + part[k].rows.size();
-    text0[k + 1] = text0[k] + part[k].text.size();
-    block0[k + 1] = block0[k] + part[k].block_row.size();
+    n_rows += part[k].rows.size();
+    n_blocks += part[k].block_row.size();
   }
-  out.rows.resize(row0[n_ranges]);
-  out.row_off.resize(row0[n_ranges] + 1);
-  out.block_row.resize(block0[n_ranges] + 1);
-  out.text.resize(text0[n_ranges]);
-  out.row_off[row0[n_ranges]] = (int64_t)text0[n_ranges];
-  out.block_row[block0[n_ranges]] = (int64_t)row0[n_ranges];
-  {
-    std::vector<std::thread> th;
-    auto work = [&](size_t k) {
-      MafDpBlocks &p = part[k];
-      for(size_t r = 0; r < p.rows.size(); ++r) {
-        out.rows[row0[k] + r] = std::move(p.rows[r]);
-        out.row_off[row0[k] + r] = (int64_t)text0[k] + p.row_off[r];
-      }
-      for(size_t bk = 0; bk < p.block_row.size(); ++bk) {
-        out.block_row[block0[k] + bk] = (int64_t)row0[k] + p.block_row[bk];
-      }
-      if(!p.text.empty()) {
-        memcpy(&out.text[text0[k]], p.text.data(), p.text.size());
-      }
-      p = MafDpBlocks();
-    };
-    for(size_t k = 1; k < n_ranges; ++k) {
-      th.emplace_back(work, k);
+  out.rows.reserve(n_rows);
+  out.row_off.reserve(n_rows + 1);
+  out.row_len.reserve(n_rows);
+  out.block_row.reserve(n_blocks + 1);
+  for(size_t k = 0; k < n_ranges; ++k) { // file offsets need no rebasing; the block tables count rows from the range's first
+    MafDpRange &p = part[k];
+    const int64_t row0 = (int64_t)out.rows.size();
+    for(size_t bk = 0; bk < p.block_row.size(); ++bk) {
+      out.block_row.push_back(row0 + p.block_row[bk]);
     }
-    work(0);
-    for(size_t k = 0; k < th.size(); ++k) {
-      th[k].join();
+    std::move(p.rows.begin(), p.rows.end(), std::back_inserter(out.rows));
+    out.row_off.insert(out.row_off.end(), p.row_off.begin(), p.row_off.end());
+    out.row_len.insert(out.row_len.end(), p.row_len.begin(), p.row_len.end());
+  }
+  out.row_off.push_back((int64_t)size);
+  out.block_row.push_back((int64_t)out.rows.size()); // a file without any `a` line: block_row = {0}, no blocks
+  // what pm_dp_pack_maf's check refuses: blocks deeper than a byte counts, rows of one block of different lengths
+  for(size_t bk = 0; bk + 1 < out.block_row.size(); ++bk) {
+    const int64_t r0 = out.block_row[bk], r1 = out.block_row[bk + 1];
+    if(r1 - r0 > 255) {
+      return fail(PM_E_INVALID, path + ": a block has more than 255 rows (a packed column counts rows in a byte)");
     }
+    for(int64_t r = r0 + 1; r < r1; ++r) {
+      if(out.row_len[(size_t)r] != out.row_len[(size_t)r0]) {
+        return fail(PM_E_INVALID, path + ": rows of one block must have the same number of columns");
+      }
+    }
+  }
+  if(timing) {
+    fprintf(stderr, "[pm]   %s: mapped in %.4f s, %zu ranges indexed in %.4f s, joined in %.4f s\n", path.c_str(), t_read - t_begin, n_ranges,
+            t_parsed - t_read, wall() - t_parsed);
   }
   return PM_OK;
 }
@@ -691,19 +723,42 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
   if(n == 0) {
     return out.write(blob.data(), blob.size()) ? (int)PM_OK : fail(PM_E_IO, "write failed");
   }
-  BlockSlice sa((const uint8_t *)A.text.data(), A.row_off.data(), A.block_row.data(), lo, hi);
-  BlockSlice sb((const uint8_t *)B.text.data(), B.row_off.data(), B.block_row.data(), lo, hi);
-  PM_TRY(check_blocks(sa.row_off.data(), sa.n_rows, sa.block_row.data(), n, "pm_dp_align_maf (A)"));
-  PM_TRY(check_blocks(sb.row_off.data(), sb.n_rows, sb.block_row.data(), n, "pm_dp_align_maf (B)"));
+  // the slice's part of either mapped file: from its first row's text to the start of the row after its last (the lines' other
+  // fields in between travel along; the kernels only look at [row start, row start + the block's columns))
+  BlockSlice sa((const uint8_t *)A.bytes, A.row_off.data(), A.block_row.data(), lo, hi);
+  BlockSlice sb((const uint8_t *)B.bytes, B.row_off.data(), B.block_row.data(), lo, hi);
+  // a block has as many columns as its rows have bytes (one length per block: checked by the parser)
   std::vector<int64_t> coa((size_t)n + 1, 0), cob((size_t)n + 1, 0);
   for(int64_t k = 0; k < n; ++k) {
-    const int64_t ra = sa.block_row[(size_t)k], rb = sb.block_row[(size_t)k];
-    coa[(size_t)k + 1] = coa[(size_t)k] + (ra < sa.block_row[(size_t)k + 1] ? sa.row_off[(size_t)ra + 1] - sa.row_off[(size_t)ra] : 0);
-    cob[(size_t)k + 1] = cob[(size_t)k] + (rb < sb.block_row[(size_t)k + 1] ? sb.row_off[(size_t)rb + 1] - sb.row_off[(size_t)rb] : 0);
+    const int64_t ra = A.block_row[(size_t)(lo + k)], rb = B.block_row[(size_t)(lo + k)];
+    coa[(size_t)k + 1] = coa[(size_t)k] + (ra < A.block_row[(size_t)(lo + k) + 1] ? A.row_len[(size_t)ra] : 0);
+    cob[(size_t)k + 1] = cob[(size_t)k] + (rb < B.block_row[(size_t)(lo + k) + 1] ? B.row_len[(size_t)rb] : 0);
   }
-  MafSideDev SA, SB;
-  PM_TRY(SA.upload(sa.text, sa.row_off.data(), sa.n_rows, sa.block_row.data(), n, coa.data()));
-  PM_TRY(SB.upload(sb.text, sb.row_off.data(), sb.n_rows, sb.block_row.data(), n, cob.data()));
+  // (owned through pointers: they are released by a helper thread while the file image is on its way to the host)
+  std::unique_ptr<MafSideDev> SAp(new MafSideDev()), SBp(new MafSideDev());
+  MafSideDev &SA = *SAp, &SB = *SBp;
+  {
+    // the two sides go up side by side (two copies from mapped files, each bound by the host's copy into staging memory)
+    int rc_b = PM_OK;
+    std::string msg_b;
+    std::thread other([&]() {
+      rc_b = use_device(device);
+      if(!rc_b) {
+        rc_b = SB.upload(sb.text, sb.row_off.data(), sb.n_rows, sb.block_row.data(), n, cob.data());
+      }
+      if(rc_b) {
+        msg_b = pm_last_error();
+      }
+    });
+    const int rc_a = SA.upload(sa.text, sa.row_off.data(), sa.n_rows, sa.block_row.data(), n, coa.data());
+    other.join();
+    if(rc_a) {
+      return rc_a;
+    }
+    if(rc_b) {
+      return fail(rc_b, msg_b);
+    }
+  }
   PM_TRY(SA.pack());
   PM_TRY(SB.pack());
   lap("upload + pack (device)");
@@ -801,7 +856,8 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
       dp_emit_file_kernel<<<dim3(gx, gy), 256>>>(n, (const i64 *)d_ops_off.p, (const int *)d_n_ops.p, (const unsigned char *)batch->ops.p,
                                                  (const int *)d_pa.p, (const int *)d_pb.p, (const i64 *)SA.block_row.p, (const i64 *)SA.row_off.p,
                                                  (const unsigned char *)SA.text.p, (const i64 *)SB.block_row.p, (const i64 *)SB.row_off.p,
-                                                 (const unsigned char *)SB.text.p, (const i64 *)d_first_line.p, (const i64 *)d_line_text.p,
+                                                 (const unsigned char *)SB.text.p, (const i64 *)SA.col_off.p, (const i64 *)SB.col_off.p,
+                                                 (const i64 *)d_first_line.p, (const i64 *)d_line_text.p,
                                                  (char *)d_out.p, (int *)d_bad.p);
       PM_HIP(hipGetLastError());
     }
@@ -815,7 +871,17 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
     }
   }
   lap("file image (device)");
-  PM_TRY(device_bytes_to_sink((const char *)d_out.p, n_out, out, timing, []() {}));
+  // everything but the image is released beside its way to the host (a dozen milliseconds of hipFree for a few GB)
+  std::thread reaper([&]() {
+    if(use_device(device) == PM_OK) {
+      batch.reset();
+      SAp.reset();
+      SBp.reset();
+    }
+  });
+  const int rc_out = device_bytes_to_sink((const char *)d_out.p, n_out, out, timing, []() {});
+  reaper.join();
+  PM_TRY(rc_out);
   lap("to the host + write");
   return PM_OK;
 }

@@ -207,9 +207,10 @@ def test_large_maf_files_parsed_in_ranges_and_emitted_on_the_device(oracle_build
     blocks of different depths; the output file is the in-memory entry's merged blocks (pm_dp_align_blocks, checked against the
     oracle elsewhere) under `a score=` lines, every `s` line keeping its six leading fields, byte for byte."""
     rng = np.random.default_rng(77)
-    A = random_blocks(rng, 300, max_rows=6, max_cols=3500)
-    B = random_blocks(rng, 300, max_rows=6, max_cols=3500)
-    A[7], B[11], A[299], B[299] = [], [], [b"ACGT" * 3], []
+    n = 800
+    A = random_blocks(rng, n, max_rows=6, max_cols=3500)
+    B = random_blocks(rng, n, max_rows=6, max_cols=3500)
+    A[7], B[11], A[n - 1], B[n - 1] = [], [], [b"ACGT" * 3], []
 
     def write(path, blocks, tag, cr):
         eol = b"\r\n" if cr else b"\n"
@@ -228,7 +229,7 @@ def test_large_maf_files_parsed_in_ranges_and_emitted_on_the_device(oracle_build
     dp.align_maf_files(pa, pb, params, po)
     scores, merged = dp.align_blocks(A, B, params)
     want = [b"##maf version=1 scoring=paramugsy_amd\n"]
-    for k in range(300):
+    for k in range(n):
         want.append(b"a score=%d\n" % scores[k])
         heads = [b"s L.g%d\t%d %d + 100000" % (r, 10 * k, sum(ch not in b"-" for ch in row)) for r, row in enumerate(A[k])]
         heads += [b"s R.g%d\t%d %d + 100000" % (r, 10 * k, sum(ch not in b"-" for ch in row)) for r, row in enumerate(B[k])]

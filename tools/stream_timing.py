@@ -19,10 +19,11 @@ pb.a[...] = inputs.cols_b
 pin = dp.DpInputs(pa.a, inputs.off_a, pb.a, inputs.off_b)
 ps, pn = dp.PinnedArray((n,), np.int32), dp.PinnedArray((n,), np.int32)
 po = dp.PinnedArray((2 * n * L,), np.uint8)
-sides = []
+sides, pins = [], []
 for text, ro, br in (side_a, side_b):
     pt = dp.PinnedArray(text.shape, np.uint8)
     pt.a[...] = text
+    pins.append(pt)  # the array lives as long as its PinnedArray
     sides.append((pt.a, ro, br))
 st = dp.DpStream(params, int(os.environ.get("SEGMENTS", "4")))
 for what in ("columns", "texts"):
