@@ -322,11 +322,8 @@ static int parse_maf_range(const char *text, size_t begin, size_t end, const std
   return PM_OK;
 }
 
-// The file is mapped and cut at block starts into a few ranges whose lines are indexed side by side.
-static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
-  const bool timing = getenv("PM_TIMING") != nullptr;
-  auto wall = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t_begin = wall();
+// The file mapped read-only (or read, when it cannot be mapped).
+static int maf_map(const std::string &path, MafDpBlocks &out) {
   {
     const int fd = open(path.c_str(), O_RDONLY);
     if(fd < 0) {
@@ -353,6 +350,13 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
     }
     close(fd);
   }
+  return PM_OK;
+}
+
+// The mapped file cut at block starts into a few ranges whose lines are indexed side by side.
+static int maf_index(const std::string &path, MafDpBlocks &out) {
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto wall = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const char *text = out.bytes;
   const size_t size = out.n_bytes;
   const double t_read = wall();
@@ -438,27 +442,48 @@ static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
     }
   }
   if(timing) {
-    fprintf(stderr, "[pm]   %s: mapped in %.4f s, %zu ranges indexed in %.4f s, joined in %.4f s\n", path.c_str(), t_read - t_begin, n_ranges,
-            t_parsed - t_read, wall() - t_parsed);
+    fprintf(stderr, "[pm]   %s: %zu ranges indexed in %.4f s, joined in %.4f s\n", path.c_str(), n_ranges, t_parsed - t_read, wall() - t_parsed);
   }
   return PM_OK;
 }
 
-// One side's blocks in device memory: the flat text and its tables, and (after pack()) the packed columns.
+static int parse_maf_blocks(const std::string &path, MafDpBlocks &out) {
+  PM_TRY(maf_map(path, out));
+  return maf_index(path, out);
+}
+
+// One side's blocks in device memory: the flat text and its tables, and (after pack()) the packed columns.  The two big
+// buffers come from the pool of kept device buffers (pm_internal.hpp).
 struct MafSideDev {
-  DevBuf text, row_off, block_row, col_off, cols;
+  PooledBuf text, cols;
+  DevBuf row_off, block_row, col_off;
   i64 n_blocks = 0, n_cols = 0;
+  bool text_up = false; // the text was sent ahead (pm_dp_align_maf starts the copies while the files are still being indexed)
+  int upload_text(const uint8_t *t, size_t bytes) {
+    int device = 0;
+    PM_HIP(hipGetDevice(&device));
+    PM_TRY(text.alloc(bytes, device));
+    if(bytes > 0) {
+      PM_HIP(hipMemcpy(text.p, t, bytes, hipMemcpyHostToDevice));
+    }
+    text_up = true;
+    return PM_OK;
+  }
   int upload(const uint8_t *t, const int64_t *ro, int64_t n_rows, const int64_t *br, int64_t nb, const int64_t *co) {
     n_blocks = nb;
     n_cols = co[nb];
-    PM_TRY(text.upload(t, (size_t)ro[n_rows], nullptr));
+    if(!text_up) {
+      PM_TRY(upload_text(t, (size_t)ro[n_rows]));
+    }
     PM_TRY(row_off.upload(ro, (size_t)(n_rows + 1) * 8, nullptr));
     PM_TRY(block_row.upload(br, (size_t)(nb + 1) * 8, nullptr));
     PM_TRY(col_off.upload(co, (size_t)(nb + 1) * 8, nullptr));
     return PM_OK;
   }
   int pack() {
-    PM_TRY(cols.alloc((size_t)std::max<i64>(n_cols, 1) * 8));
+    int device = 0;
+    PM_HIP(hipGetDevice(&device));
+    PM_TRY(cols.alloc((size_t)std::max<i64>(n_cols, 1) * 8, device));
     if(n_cols > 0) {
       dp_pack_kernel<<<(unsigned)((n_cols + 255) / 256), 256>>>(0, n_cols, n_blocks, (const i64 *)col_off.p, (const i64 *)block_row.p,
                                                                 (const i64 *)row_off.p, (const unsigned char *)text.p, (u64 *)cols.p);
@@ -693,13 +718,15 @@ struct BlockSlice {
   const uint8_t *text;
   std::vector<int64_t> row_off, block_row;
   int64_t n_rows;
-  BlockSlice(const uint8_t *t, const int64_t *ro, const int64_t *br, int64_t lo, int64_t hi) {
+  // absolute: the offsets stay relative to `t` (the whole text is, or will be, in device memory as it is)
+  BlockSlice(const uint8_t *t, const int64_t *ro, const int64_t *br, int64_t lo, int64_t hi, bool absolute = false) {
     const int64_t r0 = br[lo], r1 = br[hi];
     n_rows = r1 - r0;
-    text = t ? t + ro[r0] : nullptr;
+    const int64_t base = absolute ? 0 : ro[r0];
+    text = t ? t + base : nullptr;
     row_off.resize((size_t)n_rows + 1);
     for(int64_t r = r0; r <= r1; ++r) {
-      row_off[(size_t)(r - r0)] = ro[r] - ro[r0];
+      row_off[(size_t)(r - r0)] = ro[r] - base;
     }
     block_row.resize((size_t)(hi - lo) + 1);
     for(int64_t k = lo; k <= hi; ++k) {
@@ -712,8 +739,10 @@ struct BlockSlice {
 // the file image assembled ON THE DEVICE (dp_emit_file_kernel for the rows' texts, dp_pieces_kernel for everything around them)
 // and brought back through pinned staging pieces beside the writing (device_bytes_to_sink).  with_header: the `##maf` line first.
 // What the host does in between is arithmetic on 2 numbers per block and a few dozen bytes per row.
+// sent_a / sent_b: the sides' texts already in device memory (the whole files; only with lo = 0 and hi = every block), or null.
 static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t lo, int64_t hi, const pm_dp_params_t *params, int device,
-                             bool with_header, OutSink out, const std::function<void(const char *)> &lap) {
+                             bool with_header, OutSink out, const std::function<void(const char *)> &lap,
+                             std::unique_ptr<MafSideDev> sent_a = nullptr, std::unique_ptr<MafSideDev> sent_b = nullptr) {
   const int64_t n = hi - lo;
   std::string blob;
   if(with_header) {
@@ -725,8 +754,8 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
   }
   // the slice's part of either mapped file: from its first row's text to the start of the row after its last (the lines' other
   // fields in between travel along; the kernels only look at [row start, row start + the block's columns))
-  BlockSlice sa((const uint8_t *)A.bytes, A.row_off.data(), A.block_row.data(), lo, hi);
-  BlockSlice sb((const uint8_t *)B.bytes, B.row_off.data(), B.block_row.data(), lo, hi);
+  BlockSlice sa((const uint8_t *)A.bytes, A.row_off.data(), A.block_row.data(), lo, hi, sent_a != nullptr);
+  BlockSlice sb((const uint8_t *)B.bytes, B.row_off.data(), B.block_row.data(), lo, hi, sent_b != nullptr);
   // a block has as many columns as its rows have bytes (one length per block: checked by the parser)
   std::vector<int64_t> coa((size_t)n + 1, 0), cob((size_t)n + 1, 0);
   for(int64_t k = 0; k < n; ++k) {
@@ -735,7 +764,7 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
     cob[(size_t)k + 1] = cob[(size_t)k] + (rb < B.block_row[(size_t)(lo + k) + 1] ? B.row_len[(size_t)rb] : 0);
   }
   // (owned through pointers: they are released by a helper thread while the file image is on its way to the host)
-  std::unique_ptr<MafSideDev> SAp(new MafSideDev()), SBp(new MafSideDev());
+  std::unique_ptr<MafSideDev> SAp(sent_a ? sent_a.release() : new MafSideDev()), SBp(sent_b ? sent_b.release() : new MafSideDev());
   MafSideDev &SA = *SAp, &SB = *SBp;
   {
     // the two sides go up side by side (two copies from mapped files, each bound by the host's copy into staging memory)
@@ -826,7 +855,8 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
   src.push_back((int64_t)blob.size()); // the last piece's end
   const int64_t n_pieces = (int64_t)dst.size();
   const int64_t n_out = pos;
-  DevBuf d_ops_off, d_n_ops, d_first_line, d_line_text, d_dst, d_src, d_blob, d_out, d_bad;
+  DevBuf d_ops_off, d_n_ops, d_first_line, d_line_text, d_dst, d_src, d_blob, d_bad;
+  PooledBuf d_out;
   PM_TRY(d_ops_off.upload(ops_off.data(), (size_t)n * 8, nullptr));
   PM_TRY(d_n_ops.upload(n_ops.data(), (size_t)n * 4, nullptr));
   PM_TRY(d_first_line.upload(first_line.data(), (size_t)(n + 1) * 8, nullptr));
@@ -834,16 +864,17 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
   PM_TRY(d_dst.upload(dst.data(), (size_t)n_pieces * 8, nullptr));
   PM_TRY(d_src.upload(src.data(), (size_t)(n_pieces + 1) * 8, nullptr));
   PM_TRY(d_blob.upload(blob.data(), blob.size(), nullptr));
-  PM_TRY(d_out.alloc((size_t)n_out));
+  PM_TRY(d_out.alloc((size_t)n_out, device));
   PM_TRY(d_bad.alloc(4));
   PM_HIP(hipMemset(d_bad.p, 0, 4));
   {
     // every op's column on either side: one scan each over the ops of the whole batch
-    DevBuf d_fa, d_fb, d_pa, d_pb, d_tmp;
-    PM_TRY(d_fa.alloc((size_t)ops_end * 4 + 4));
-    PM_TRY(d_fb.alloc((size_t)ops_end * 4 + 4));
-    PM_TRY(d_pa.alloc((size_t)ops_end * 4 + 4));
-    PM_TRY(d_pb.alloc((size_t)ops_end * 4 + 4));
+    PooledBuf d_fa, d_fb, d_pa, d_pb;
+    DevBuf d_tmp;
+    PM_TRY(d_fa.alloc((size_t)ops_end * 4 + 4, device));
+    PM_TRY(d_fb.alloc((size_t)ops_end * 4 + 4, device));
+    PM_TRY(d_pa.alloc((size_t)ops_end * 4 + 4, device));
+    PM_TRY(d_pb.alloc((size_t)ops_end * 4 + 4, device));
     if(ops_end > 0) {
       dp_op_flags_kernel<<<(unsigned)((ops_end + 255) / 256), 256>>>(ops_end, (const unsigned char *)batch->ops.p, (int *)d_fa.p, (int *)d_fb.p);
       PM_HIP(hipGetLastError());
@@ -902,14 +933,44 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
     }
   };
   MafDpBlocks A, B;
-  PM_TRY(parse_two_mafs(maf_a, maf_b, A, B, "pm_dp_align_maf"));
+  PM_TRY(maf_map(maf_a, A));
+  PM_TRY(maf_map(maf_b, B));
+  lap("files mapped");
+  // the files' bytes go to the device as they are, while their lines are being indexed (four threads: two copies, two indexers,
+  // each indexer with its range threads)
+  std::unique_ptr<MafSideDev> sent_a(new MafSideDev()), sent_b(new MafSideDev());
+  {
+    int rc4[4] = {PM_OK, PM_OK, PM_OK, PM_OK};
+    std::string msg4[4];
+    auto guarded = [&](int k, const std::function<int()> &fn) {
+      rc4[k] = fn();
+      if(rc4[k]) {
+        msg4[k] = pm_last_error();
+      }
+    };
+    std::thread t1([&]() { guarded(1, [&]() { PM_TRY(use_device(device)); return sent_a->upload_text((const uint8_t *)A.bytes, A.n_bytes); }); });
+    std::thread t2([&]() { guarded(2, [&]() { PM_TRY(use_device(device)); return sent_b->upload_text((const uint8_t *)B.bytes, B.n_bytes); }); });
+    std::thread t3([&]() { guarded(3, [&]() { return maf_index(maf_b, B); }); });
+    guarded(0, [&]() { return maf_index(maf_a, A); });
+    t1.join();
+    t2.join();
+    t3.join();
+    for(int k : {0, 3, 1, 2}) {
+      if(rc4[k]) {
+        return fail(rc4[k], msg4[k]);
+      }
+    }
+  }
+  if(A.block_row.size() != B.block_row.size()) {
+    return fail(PM_E_INVALID, "pm_dp_align_maf: the two MAF files must hold the same number of blocks (pair k = block k of each)");
+  }
   const int64_t n = (int64_t)A.block_row.size() - 1;
-  lap("parse (two threads)");
+  lap("indexed, and the bytes on the device");
   FILE *f = fopen(out_maf, "wb");
   if(!f) {
     return fail(PM_E_IO, std::string("cannot write ") + out_maf);
   }
-  int rc = align_maf_to_sink(A, B, 0, n, params, device, true, OutSink(f), lap);
+  int rc = align_maf_to_sink(A, B, 0, n, params, device, true, OutSink(f), lap, std::move(sent_a), std::move(sent_b));
   std::string msg = rc ? pm_last_error() : "";
   if(fclose(f) != 0 && !rc) {
     rc = fail(PM_E_IO, std::string("cannot write ") + out_maf);

@@ -2,6 +2,8 @@
 #include "pm_internal.hpp"
 
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace pm {
 
@@ -27,6 +29,58 @@ int use_device(int device) {
     return fail(PM_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
   }
   return PM_OK;
+}
+
+// ---- DevPool (pm_internal.hpp)
+namespace {
+struct PoolEntry {
+  int device;
+  void *p;
+  size_t bytes;
+};
+std::mutex g_pool_lock;
+std::vector<PoolEntry> g_pool;
+size_t g_pool_bytes = 0;
+const size_t POOL_MAX_ONE = (size_t)1 << 30, POOL_MAX_ALL = (size_t)4 << 30;
+} // namespace
+
+void *DevPool::take(int device, size_t bytes, size_t *got) {
+  std::lock_guard<std::mutex> hold(g_pool_lock);
+  size_t best = g_pool.size();
+  for(size_t k = 0; k < g_pool.size(); ++k) { // the smallest kept buffer that is big enough (and not wastefully so)
+    if(g_pool[k].device == device && g_pool[k].bytes >= bytes && g_pool[k].bytes <= 2 * bytes + (1 << 20) &&
+       (best == g_pool.size() || g_pool[k].bytes < g_pool[best].bytes)) {
+      best = k;
+    }
+  }
+  if(best == g_pool.size()) {
+    return nullptr;
+  }
+  void *p = g_pool[best].p;
+  *got = g_pool[best].bytes;
+  g_pool_bytes -= g_pool[best].bytes;
+  g_pool.erase(g_pool.begin() + (long)best);
+  return p;
+}
+
+void DevPool::give(int device, void *p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> hold(g_pool_lock);
+    if(bytes <= POOL_MAX_ONE && g_pool_bytes + bytes <= POOL_MAX_ALL) {
+      g_pool.push_back(PoolEntry{device, p, bytes});
+      g_pool_bytes += bytes;
+      return;
+    }
+  }
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  if(cur != device) {
+    (void)hipSetDevice(device);
+  }
+  (void)hipFree(p);
+  if(cur != device && cur >= 0) {
+    (void)hipSetDevice(cur);
+  }
 }
 
 } // namespace pm

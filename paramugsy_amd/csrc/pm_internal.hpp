@@ -76,4 +76,47 @@ struct DevBuf {
   }
 };
 
+// Device buffers kept from call to call (per device, at most 4 GiB in all, none above 1 GiB): a resident caller's second
+// file-level call finds its hundred-megabyte scratch buffers allocated -- hipMalloc + hipFree of them cost more than the
+// kernels that use them.  PooledBuf behaves like DevBuf; what does not fit the pool's limits is simply freed.
+class DevPool {
+public:
+  static void *take(int device, size_t bytes, size_t *got);
+  static void give(int device, void *p, size_t bytes);
+};
+
+struct PooledBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int device = 0;
+  PooledBuf() = default;
+  PooledBuf(const PooledBuf &) = delete;
+  PooledBuf &operator=(const PooledBuf &) = delete;
+  ~PooledBuf() { release(); }
+  void release() {
+    if(p) {
+      DevPool::give(device, p, bytes);
+      p = nullptr;
+      bytes = 0;
+    }
+  }
+  int alloc(size_t n, int dev) {
+    release();
+    if(n == 0) {
+      n = 16;
+    }
+    device = dev;
+    p = DevPool::take(dev, n, &bytes);
+    if(!p) {
+      hipError_t e = hipMalloc(&p, n);
+      if(e != hipSuccess) {
+        p = nullptr;
+        return fail(PM_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+      }
+      bytes = n;
+    }
+    return PM_OK;
+  }
+};
+
 } // namespace pm
