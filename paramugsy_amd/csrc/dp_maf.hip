@@ -20,6 +20,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -642,6 +643,38 @@ static int parse_two_mafs(const char *maf_a, const char *maf_b, MafDpBlocks &A, 
   return PM_OK;
 }
 
+// DP batches kept from call to call, per device (their workspace and buffers only grow: dp_batch.hpp): a resident caller's next
+// file finds gigabytes of path workspace allocated -- allocating and freeing it costs more than the kernels that use it.  A batch
+// whose workspace has grown past 24 GiB is not kept.
+static std::mutex g_batch_lock;
+static std::vector<std::unique_ptr<pm_dp_batch> > g_batch_cache;
+static std::unique_ptr<pm_dp_batch> batch_acquire(int device) {
+  {
+    std::lock_guard<std::mutex> hold(g_batch_lock);
+    for(size_t k = 0; k < g_batch_cache.size(); ++k) {
+      if(g_batch_cache[k]->device == device) {
+        std::unique_ptr<pm_dp_batch> b = std::move(g_batch_cache[k]);
+        g_batch_cache.erase(g_batch_cache.begin() + (long)k);
+        return b;
+      }
+    }
+  }
+  return std::unique_ptr<pm_dp_batch>(new(std::nothrow) pm_dp_batch());
+}
+static void batch_release(std::unique_ptr<pm_dp_batch> b) {
+  if(!b) {
+    return;
+  }
+  if(b->tb.bytes <= ((size_t)24 << 30)) {
+    std::lock_guard<std::mutex> hold(g_batch_lock);
+    if(g_batch_cache.size() < 8) {
+      g_batch_cache.push_back(std::move(b));
+      return;
+    }
+  }
+  b.reset();
+}
+
 // Blocks in, merged blocks out, through the device once: texts up, pack, DP, expansion along the paths, merged texts down.
 // scores / n_ops: n values each (n_ops[k] = columns of merged block k); out_off: n + 1 byte offsets into `merged`.
 static int align_blocks_core(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a, const uint8_t *text_b,
@@ -668,11 +701,12 @@ static int align_blocks_core(const uint8_t *text_a, const int64_t *row_off_a, in
   MafSideDev SA, SB;
   PM_TRY(SA.upload(text_a, row_off_a, n_rows_a, block_row_a, n, coa.data()));
   PM_TRY(SB.upload(text_b, row_off_b, n_rows_b, block_row_b, n, cob.data()));
+  lap("tables (and texts not sent ahead) on the device");
   PM_TRY(SA.pack());
   PM_TRY(SB.pack());
-  lap("upload + pack (device)");
+  lap("pack kernels launched");
   PM_TRY(dp_batch_check_params(params));
-  std::unique_ptr<pm_dp_batch> batch(new(std::nothrow) pm_dp_batch());
+  std::unique_ptr<pm_dp_batch> batch = batch_acquire(device);
   if(!batch) {
     return fail(PM_E_INVALID, "out of host memory");
   }
@@ -710,6 +744,7 @@ static int align_blocks_core(const uint8_t *text_a, const int64_t *row_off_a, in
     PM_HIP(hipMemcpy(merged.data(), d_out.p, (size_t)out_off[(size_t)n], hipMemcpyDeviceToHost));
   }
   lap("emit (device)");
+  batch_release(std::move(batch));
   return PM_OK;
 }
 
@@ -788,11 +823,12 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
       return fail(rc_b, msg_b);
     }
   }
+  lap("tables (and texts not sent ahead) on the device");
   PM_TRY(SA.pack());
   PM_TRY(SB.pack());
-  lap("upload + pack (device)");
+  lap("pack kernels launched");
   PM_TRY(dp_batch_check_params(params));
-  std::unique_ptr<pm_dp_batch> batch(new(std::nothrow) pm_dp_batch());
+  std::unique_ptr<pm_dp_batch> batch = batch_acquire(device);
   if(!batch) {
     return fail(PM_E_INVALID, "out of host memory");
   }
@@ -905,7 +941,7 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
   // everything but the image is released beside its way to the host (a dozen milliseconds of hipFree for a few GB)
   std::thread reaper([&]() {
     if(use_device(device) == PM_OK) {
-      batch.reset();
+      batch_release(std::move(batch));
       SAp.reset();
       SBp.reset();
     }
