@@ -968,6 +968,22 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
       t0 = t1;
     }
   };
+  // the output file is opened beside everything below (truncating a big file that is already there takes as long as the DP)
+  FILE *f = nullptr;
+  std::thread opener([&]() { f = fopen(out_maf, "wb"); });
+  struct JoinOpener {
+    std::thread &t;
+    FILE *&f;
+    bool keep = false;
+    ~JoinOpener() {
+      if(t.joinable()) {
+        t.join();
+      }
+      if(f && !keep) {
+        fclose(f);
+      }
+    }
+  } join_opener{opener, f};
   MafDpBlocks A, B;
   PM_TRY(maf_map(maf_a, A));
   PM_TRY(maf_map(maf_b, B));
@@ -1002,12 +1018,15 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
   }
   const int64_t n = (int64_t)A.block_row.size() - 1;
   lap("indexed, and the bytes on the device");
-  FILE *f = fopen(out_maf, "wb");
+  opener.join();
   if(!f) {
     return fail(PM_E_IO, std::string("cannot write ") + out_maf);
   }
+  join_opener.keep = true; // closed below, with its error checked
+  lap("output file opened");
   int rc = align_maf_to_sink(A, B, 0, n, params, device, true, OutSink(f), lap, std::move(sent_a), std::move(sent_b));
   std::string msg = rc ? pm_last_error() : "";
+  lap("small device buffers released");
   if(fclose(f) != 0 && !rc) {
     rc = fail(PM_E_IO, std::string("cannot write ") + out_maf);
   }
