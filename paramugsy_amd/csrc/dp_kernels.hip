@@ -714,7 +714,18 @@ int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int6
   PM_HIP(hipMemcpyAsync(h->d_off_a.p, pa, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
   PM_HIP(hipMemcpyAsync(h->d_off_b.p, pb, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, stream));
   PM_HIP(hipMemsetAsync(h->stats.p, 0, 32, stream));
-  // segments of about equal numbers of columns (A + B), cut at pair boundaries
+  // segments of about equal numbers of columns (A + B), cut at pair boundaries -- but no more of them than leave every fill
+  // launch about 5e9 cells: a launch of a few thousand short pairs cannot fill the chip (2.4 wavefronts per SIMD at 2 500 pairs),
+  // and four such launches cost more than the upload they hide (10 000 pairs of 2 x 1 kbp: 5.1 ms in four segments, 4.6 in two)
+  {
+    double cells = 0;
+    for(int64_t k = 0; k < n_pairs; ++k) {
+      cells += (double)(h->off_a[(size_t)k + 1] - h->off_a[(size_t)k]) * (double)(h->off_b[(size_t)k + 1] - h->off_b[(size_t)k]);
+    }
+    const char *env = getenv("PM_DP_SEGMENT_CELLS"); // tests cut tiny batches into many segments
+    const double per_segment = env ? std::max(1.0, atof(env)) : 5e9;
+    segments = (int)std::min<int64_t>(segments, std::max<int64_t>(1, (int64_t)(cells / per_segment)));
+  }
   segments = (int)std::max<int64_t>(1, std::min<int64_t>(segments, std::max<int64_t>(n_pairs, 1)));
   h->seg_first.assign(1, 0);
   {

@@ -8,6 +8,13 @@ from paramugsy_amd import dp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def segments_as_asked(monkeypatch):
+    """The engine uses fewer segments than asked for when they would hold less than 5e9 cells each; these tests want tiny batches in
+    many segments."""
+    monkeypatch.setenv("PM_DP_SEGMENT_CELLS", "1")
+
+
 def resident(inputs, params):
     b = dp.DpBatch(inputs, params)
     b.run(True)

@@ -10,7 +10,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import numpy as np  # noqa: E402
+import numpy as np
+
+os.environ.setdefault("PM_DP_SEGMENT_CELLS", "1")  # the host-fed engine in as many segments as drawn, however small the batch  # noqa: E402
 import pyoracle  # noqa: E402
 from paramugsy_amd import dp  # noqa: E402
 
