@@ -1272,25 +1272,17 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
     }
   }
   unsigned *tb = (unsigned *)h->tb.p;
-  // The chunks hold the pairs longest first.  With several chunks the LAST one (the shortest pairs) is run FIRST: the path kernel of
-  // a chunk runs beside the fill kernel of the next, except for the chunk that comes last, whose path kernel runs alone -- and the
-  // walk is dearest, relative to the fill, for short pairs (it recomputes 64 (La + Lb) of La Lb cells), cheapest for the long
-  // ones.  (Not when the columns arrive in upload segments: those come in the caller's order.)  Slot i of the events and the
-  // workspace half i % 2 belong to the i-th chunk RUN.
-  static const bool forward_env = getenv("PM_DP_CHUNK_ORDER") && strcmp(getenv("PM_DP_CHUNK_ORDER"), "forward") == 0;
-  const bool reversed = nc > 1 && !h->seg_events_armed && !forward_env;
-  for(size_t i = 0; i < nc; ++i) {
-    const size_t c = reversed ? nc - 1 - i : i;
+  for(size_t c = 0; c < nc; ++c) {
     if(h->chunk_first[c + 1] - h->chunk_first[c] <= 0) {
       continue;
     }
-    unsigned *tbw = tb + (h->tb_half_words ? (i & 1) * h->tb_half_words : 0);
+    unsigned *tbw = tb + (h->tb_half_words ? (c & 1) * h->tb_half_words : 0);
     hipStream_t ps = pipelined ? h->path_stream : stream;
-    if(pipelined && i >= 2) {
-      PM_HIP(hipStreamWaitEvent(stream, h->ev_path[i - 2], 0)); // the half is free again
+    if(pipelined && c >= 2) {
+      PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c - 2], 0)); // the half is free again
     }
     if(timed) {
-      PM_HIP(hipEventRecord(h->tv_fill0[i], stream));
+      PM_HIP(hipEventRecord(h->tv_fill0[c], stream));
     }
     // the chunk's pairs, one launch per upload segment (a batch that was loaded in one piece has none: one launch)
     {
@@ -1312,43 +1304,42 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       }
     }
     if(timed) {
-      PM_HIP(hipEventRecord(h->tv_fill1[i], stream));
+      PM_HIP(hipEventRecord(h->tv_fill1[c], stream));
     }
     if(traceback) {
       if(pipelined) {
-        PM_HIP(hipEventRecord(h->ev_fill[i], stream));
-        PM_HIP(hipStreamWaitEvent(ps, h->ev_fill[i], 0));
+        PM_HIP(hipEventRecord(h->ev_fill[c], stream));
+        PM_HIP(hipStreamWaitEvent(ps, h->ev_fill[c], 0));
       }
       if(timed) {
-        PM_HIP(hipEventRecord(h->tv_path0[i], ps));
+        PM_HIP(hipEventRecord(h->tv_path0[c], ps));
       }
       PM_TRY(dp_launch_path(h, c, tbw, ps));
       if(timed) {
-        PM_HIP(hipEventRecord(h->tv_path1[i], ps));
+        PM_HIP(hipEventRecord(h->tv_path1[c], ps));
       }
       if(pipelined) {
-        PM_HIP(hipEventRecord(h->ev_path[i], ps));
+        PM_HIP(hipEventRecord(h->ev_path[c], ps));
       }
     }
   }
   if(pipelined) { // the caller's stream is done when the last two path kernels are
-    for(size_t i = nc >= 2 ? nc - 2 : 0; i < nc; ++i) {
-      PM_HIP(hipStreamWaitEvent(stream, h->ev_path[i], 0));
+    for(size_t c = nc >= 2 ? nc - 2 : 0; c < nc; ++c) {
+      PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c], 0));
     }
   }
   h->last_stream = stream;
   if(timed) {
     PM_HIP(hipStreamSynchronize(stream));
     float acc_fill = 0, acc_path = 0;
-    for(size_t i = 0; i < nc; ++i) {
-      const size_t c = reversed ? nc - 1 - i : i;
+    for(size_t c = 0; c < nc; ++c) {
       if(h->chunk_first[c + 1] - h->chunk_first[c] <= 0) {
         continue;
       }
       float a = 0, b = 0;
-      PM_HIP(hipEventElapsedTime(&a, h->tv_fill0[i], h->tv_fill1[i]));
+      PM_HIP(hipEventElapsedTime(&a, h->tv_fill0[c], h->tv_fill1[c]));
       if(traceback) {
-        PM_HIP(hipEventElapsedTime(&b, h->tv_path0[i], h->tv_path1[i]));
+        PM_HIP(hipEventElapsedTime(&b, h->tv_path0[c], h->tv_path1[c]));
       }
       acc_fill += a;
       acc_path += b;
