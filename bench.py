@@ -310,12 +310,17 @@ def bench_translate(args, rank, world, local, torch, dist):
             # whole-job time of the drop-in CLI on the same files, PCIe and text I/O included
             cli = os.path.join(ROOT, "bin", "m_translate")
             if os.path.exists(cli):
-                t0 = time.perf_counter()
-                r2 = subprocess.run([cli, w.left_dir, w.right_dir, w.list_path, os.path.join(tmp, "gpu.delta")])
-                cli_dt = time.perf_counter() - t0
+                runs = []
+                for _ in range(3):  # fresh processes; the first also pays for a cold file cache of the library's code objects
+                    t0 = time.perf_counter()
+                    r2 = subprocess.run([cli, w.left_dir, w.right_dir, w.list_path, os.path.join(tmp, "gpu.delta")])
+                    runs.append(time.perf_counter() - t0)
+                cli_dt = min(runs)
                 same = open(os.path.join(tmp, "gpu.delta"), "rb").read() == open(os.path.join(tmp, "cpu.delta"), "rb").read()
-                out["cli_whole_job"] = {"units_per_s": units / cli_dt, "seconds": cli_dt, "rc": r2.returncode,
-                                        "bytes_identical_to_cpu_baseline": bool(same)}
+                out["cli_whole_job"] = {"units_per_s": units / cli_dt, "seconds": cli_dt, "seconds_each_of_3_fresh_processes": runs,
+                                        "rc": r2.returncode, "bytes_identical_to_cpu_baseline": bool(same),
+                                        "note": "best of three fresh processes; 0.05-0.19 s of each is the HIP runtime's start-up "
+                                                "(profiles/r03_cli_timing.txt)"}
     job.close()
     wl.close()
     import shutil
