@@ -41,25 +41,31 @@ def random_case(rng):
         lb.append(b)
     related = rng.random() < 0.6
 
-    def cols_random(total):
-        c = np.zeros((total, 8), dtype=np.uint8)
-        pick = rng.integers(0, 5 if rng.random() < 0.5 else 4, size=(total, rows))
+    def picks_random(total):  # the symbol (0-3 ACGT, 4 gap) every row holds in every column
+        return rng.integers(0, 5 if rng.random() < 0.5 else 4, size=(total, rows))
+
+    def cols_of(pick):
+        c = np.zeros((len(pick), 8), dtype=np.uint8)
         for s in range(5):
             c[:, s] = (pick == s).sum(axis=1)
         return c
-    A = [cols_random(x) for x in la]
-    B = []
+    PA = [picks_random(x) for x in la]
+    PB = []
     for k, x in enumerate(lb):
         if related and la[k] > 0 and x > 0:  # B = A resampled to lb columns with some columns replaced
             idx = np.minimum((np.arange(x) * la[k]) // x, la[k] - 1)
-            b = A[k][idx].copy()
+            b = PA[k][idx].copy()
             noise = rng.random(x) < 0.1
-            b[noise] = cols_random(int(noise.sum()))
-            B.append(b)
+            b[noise] = picks_random(int(noise.sum()))
+            PB.append(b)
         else:
-            B.append(cols_random(x))
+            PB.append(picks_random(x))
+    A, B = [cols_of(x) for x in PA], [cols_of(x) for x in PB]
     cat = lambda parts: np.concatenate(parts) if sum(len(p) for p in parts) else np.zeros((0, 8), np.uint8)
     inputs = dp.DpInputs(cat(A), np.concatenate([[0], np.cumsum(la)]).astype(np.int64), cat(B), np.concatenate([[0], np.cumsum(lb)]).astype(np.int64))
+    letters = np.frombuffer(b"ACGT-", dtype=np.uint8)
+    # the rows themselves, as MAF blocks (a profile of 0 columns is a block without rows)
+    inputs.blocks = [[[letters[pk[:, r]].tobytes() for r in range(rows)] if len(pk) else [] for pk in side] for side in (PA, PB)]
     p = dp.make_params(rows, rows)
     if extreme:
         hi = int(rng.choice([1, 3, 20, 32767 // rows]))
@@ -86,14 +92,28 @@ while time.time() < t_end:
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
-    streamed = rng.random() < 0.25 and inputs.n_pairs > 0  # through the host-fed engine (upload segments, variant re-check)
+    # engines: the resident batch; the host-fed engine (upload segments, variant re-check) with packed columns or with the rows'
+    # texts; the device-list entry with two to four workers on the one GPU
+    draw = rng.random()
+    engine = "batch" if draw >= 0.45 or inputs.n_pairs == 0 else ("stream" if draw < 0.2 else ("stream_text" if draw < 0.33 else "multi"))
+    if engine == "stream_text" and rows > 255:
+        engine = "stream"
+    streamed = engine != "batch"
     try:
-        if streamed:
+        if engine in ("stream", "stream_text"):
             st = dp.DpStream(p, segments=int(rng.integers(1, 7)))
             try:
-                scores, ops, n_ops = st.align(inputs)
+                if engine == "stream":
+                    scores, ops, n_ops = st.align(inputs)
+                else:
+                    scores, ops, n_ops = st.align_text(dp.flatten_blocks(inputs.blocks[0]), dp.flatten_blocks(inputs.blocks[1]))
+                    scores, n_ops = scores[:inputs.n_pairs], n_ops[:inputs.n_pairs]
             finally:
                 st.close()
+            paths = dp.paths_of(inputs, ops, n_ops)
+            v = {"checkpoints": "?", "cols_per_lane": "?"}
+        elif engine == "multi":
+            scores, ops, n_ops = dp.align_multi(inputs, p, [0] * int(rng.integers(2, 5)))
             paths = dp.paths_of(inputs, ops, n_ops)
             v = {"checkpoints": "?", "cols_per_lane": "?"}
         else:
@@ -108,7 +128,7 @@ while time.time() < t_end:
         seed += 1
         continue
     if streamed:
-        env = dict(env, engine="stream")
+        env = dict(env, engine=engine)
     o_scores, o_paths = pyoracle.dp_align(inputs, p)
     ok = np.array_equal(scores, o_scores) and all(np.array_equal(x, y) for x, y in zip(paths, o_paths))
     print("seed", seed, "pairs", len(la), "rows", rows, "max", max(la + [0]), "x", max(lb + [0]), env, ("ckpt" if v["checkpoints"] else "bits") if v["checkpoints"] != "?" else "-", "cols", v["cols_per_lane"],

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 from paramugsy_amd import capi, synth  # noqa: E402
-from paramugsy_amd.translate import translate  # noqa: E402
+from paramugsy_amd.translate import translate, translate_multi  # noqa: E402
 from test_translate_gpu import MODES  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
@@ -56,16 +56,24 @@ while time.time() < t_end:
             mode = "wild"
         w = synth.make_workload(os.path.join(d, "job"), seed, **kw)
         rc = subprocess.run([os.path.join(REF, "m_translate"), w.left_dir, w.right_dir, w.list_path, a], capture_output=True).returncode
+        multi = int(rng.integers(2, 5)) if rng.random() < 0.3 else 0  # a third of the jobs over a device list (workers share the GPU)
         try:
-            translate(w.left_dir, w.right_dir, w.delta_paths, b)
+            if multi:
+                translate_multi(w.left_dir, w.right_dir, w.delta_paths, b, [0] * multi)
+            else:
+                translate(w.left_dir, w.right_dir, w.delta_paths, b)
             failed = False
         except capi.PmError:
             failed = True
-        what = mode
+        what = mode + (" x%d devices" % multi if multi else "")
         if rc != 0 or failed:  # input the reference dies on (the generator can write a delta file it cannot parse): the library must fail too
             print("seed", seed, kind, what, "reference exit", rc, "library", "fails" if failed else "succeeds", "AGREE" if (rc != 0) == failed else "DISAGREE",
                   flush=True)
             if (rc != 0) != failed:
+                shutil.copytree(d, os.path.join(ROOT, "gpurun_out", "ref_fuzz_seed%d" % seed), dirs_exist_ok=True)
+                sys.exit(1)
+            if open(a, "rb").read() != open(b, "rb").read():  # what was written before the failure: the same bytes
+                print("seed", seed, "partial outputs differ", flush=True)
                 shutil.copytree(d, os.path.join(ROOT, "gpurun_out", "ref_fuzz_seed%d" % seed), dirs_exist_ok=True)
                 sys.exit(1)
             count["both fail"] = count.get("both fail", 0) + 1
