@@ -72,7 +72,9 @@ while time.time() < t_end:
             if (rc != 0) != failed:
                 shutil.copytree(d, os.path.join(ROOT, "gpurun_out", "ref_fuzz_seed%d" % seed), dirs_exist_ok=True)
                 sys.exit(1)
-            if open(a, "rb").read() != open(b, "rb").read():  # what was written before the failure: the same bytes
+            # what was written before the failure: the reference dies with its stream's last buffer unflushed, so its file is a
+            # prefix of the library's
+            if not open(b, "rb").read().startswith(open(a, "rb").read()):
                 print("seed", seed, "partial outputs differ", flush=True)
                 shutil.copytree(d, os.path.join(ROOT, "gpurun_out", "ref_fuzz_seed%d" % seed), dirs_exist_ok=True)
                 sys.exit(1)
