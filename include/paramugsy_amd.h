@@ -104,6 +104,10 @@ typedef struct pm_entry {
 typedef struct pm_job pm_job_t; /* opaque; owns device memory */
 
 const char *pm_last_error(void);
+/* The file-level entries keep some buffers from call to call for a resident caller's sake: a few pinned staging pieces (32 MB a
+ * set), device scratch buffers (at most 4 GiB in all, none above 1 GiB) and the DP batches of the MAF entries with their path
+ * workspace (batches that have grown past 24 GiB are not kept).  This frees them all. */
+int pm_release_caches(void);
 int pm_device_count(void);
 /* name/CU count of device `dev`; name buffer of `cap` bytes */
 int pm_device_info(int dev, char *name, int cap, int *compute_units, int64_t *hbm_bytes);

@@ -50,7 +50,7 @@ ENTRY_DTYPE = np.dtype([("ref_start", "<i8"), ("ref_end", "<i8"), ("qry_start", 
 
 # every symbol include/paramugsy_amd.h declares (tests check that the library exports each of them)
 EXPORTS = [
-    "pm_last_error", "pm_device_count", "pm_device_info",
+    "pm_last_error", "pm_release_caches", "pm_device_count", "pm_device_info",
     "pm_job_create", "pm_job_text", "pm_job_text_fetch", "pm_job_text_fetch_range", "pm_job_run", "pm_job_run_profiled", "pm_job_sizes", "pm_job_fetch", "pm_job_algorithmic_bytes", "pm_job_kernel_bytes", "pm_job_coordinate_bits", "pm_job_destroy",
     "pm_rows_profile_idx_of_seq_idx_batch", "pm_rows_seq_idx_of_profile_idx_batch",
     "pm_workload_load", "pm_workload_tables", "pm_workload_row_name", "pm_workload_destroy",

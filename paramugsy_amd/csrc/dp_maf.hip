@@ -661,6 +661,24 @@ static std::unique_ptr<pm_dp_batch> batch_acquire(int device) {
   }
   return std::unique_ptr<pm_dp_batch>(new(std::nothrow) pm_dp_batch());
 }
+namespace pm {
+void dp_batch_cache_trim() {
+  std::vector<std::unique_ptr<pm_dp_batch> > all;
+  {
+    std::lock_guard<std::mutex> hold(g_batch_lock);
+    all.swap(g_batch_cache);
+  }
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  for(size_t k = 0; k < all.size(); ++k) {
+    (void)hipSetDevice(all[k]->device);
+    all[k].reset();
+  }
+  if(cur >= 0) {
+    (void)hipSetDevice(cur);
+  }
+}
+} // namespace pm
 static void batch_release(std::unique_ptr<pm_dp_batch> b) {
   if(!b) {
     return;

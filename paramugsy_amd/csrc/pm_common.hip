@@ -83,9 +83,35 @@ void DevPool::give(int device, void *p, size_t bytes) {
   }
 }
 
+void DevPool::trim() {
+  std::vector<PoolEntry> all;
+  {
+    std::lock_guard<std::mutex> hold(g_pool_lock);
+    all.swap(g_pool);
+    g_pool_bytes = 0;
+  }
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  for(size_t k = 0; k < all.size(); ++k) {
+    (void)hipSetDevice(all[k].device);
+    (void)hipFree(all[k].p);
+  }
+  if(cur >= 0) {
+    (void)hipSetDevice(cur);
+  }
+}
+
 } // namespace pm
 
 extern "C" {
+
+int pm_release_caches(void) {
+  pm::dp_batch_cache_trim();
+  pm::text_staging_trim();
+  pm::DevPool::trim();
+  return PM_OK;
+}
+
 
 const char *pm_last_error(void) { return pm::g_last_error.c_str(); }
 

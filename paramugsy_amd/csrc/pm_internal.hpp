@@ -83,6 +83,7 @@ class DevPool {
 public:
   static void *take(int device, size_t bytes, size_t *got);
   static void give(int device, void *p, size_t bytes);
+  static void trim(); // frees everything kept
 };
 
 struct PooledBuf {
@@ -118,5 +119,9 @@ struct PooledBuf {
     return PM_OK;
   }
 };
+
+// what pm_release_caches() frees besides the pool: the pinned staging pieces (translate_host.cc), the kept DP batches (dp_maf.hip)
+void text_staging_trim();
+void dp_batch_cache_trim();
 
 } // namespace pm

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 
 #include <rocprim/rocprim.hpp>
 
@@ -28,18 +29,40 @@ namespace pm {
 
 typedef long long i64;
 
-// start[i] = 1 when byte i opens a run of '-' within its row, stop[i] = 1 when it closes one.
-__global__ void gap_flags_kernel(i64 n, const unsigned char *text, const unsigned char *row_first, const unsigned char *row_last, int *start,
-                                 int *stop) {
+// start[i] = 1 when byte i opens a run of '-' within its row, stop[i] = 1 when it closes one; col[i] = the byte's column in its
+// row (the row is found by a search in row_off: rows are a few kilobytes, the table a few thousand entries).
+__global__ void gap_flags_kernel(i64 n, const unsigned char *text, const i64 *row_off, int n_rows, int *start, int *stop, int *col) {
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(i >= n) {
     return;
   }
+  int lo = 0, hi = n_rows; // the last r with row_off[r] <= i (rows without bytes repeat their neighbour's offset)
+  while(hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if(row_off[mid] <= i) {
+      lo = mid;
+    }
+    else {
+      hi = mid;
+    }
+  }
+  const bool first = i == row_off[lo], last = i + 1 == row_off[lo + 1];
   bool g = text[i] == '-';
-  bool prev = !row_first[i] && text[i - 1] == '-';
-  bool next = !row_last[i] && text[i + 1] == '-';
+  bool prev = !first && text[i - 1] == '-';
+  bool next = !last && text[i + 1] == '-';
   start[i] = g && !prev;
   stop[i] = g && !next;
+  col[i] = (int)(i - row_off[lo]);
+}
+
+// gap_off[r] = runs opened before row r's first byte (start_scan there), gap_off[n_rows] = all of them
+__global__ void gap_offsets_kernel(int n_rows, i64 n, const i64 *row_off, const int *start, const int *start_scan, i64 *gap_off) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if(r > n_rows) {
+    return;
+  }
+  const i64 total = (i64)start_scan[n - 1] + start[n - 1];
+  gap_off[r] = r < n_rows && row_off[r] < n ? (i64)start_scan[row_off[r]] : total;
 }
 
 // k-th opening and k-th closing byte of the whole buffer belong to the same run (runs never cross a row).
@@ -207,6 +230,20 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
   if(rc) {
     return rc;
   }
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto wall = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+  };
+  double lap_t = wall();
+  auto lap = [&](const char *what) {
+    if(timing) {
+      const double t = wall();
+      fprintf(stderr, "[pm]   make %s: %-36s %.4f s\n", basename, what, t - lap_t);
+      lap_t = t;
+    }
+  };
   std::string maf;
   {
     FILE *f = fopen(in_maf, "rb");
@@ -216,11 +253,13 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
     read_stream(f, maf);
     fclose(f);
   }
+  lap("file read");
   std::vector<MakeRow> rows;
   std::string text;
   std::vector<i64> row_off;
   std::vector<int> block_first_row;
   PM_TRY(parse_maf_for_make(maf, rows, text, row_off, block_first_row));
+  lap("lines parsed");
   int n_rows = (int)rows.size(), n_blocks = (int)block_first_row.size() - 1;
   i64 n = (i64)text.size();
   // every row of a block must have the block's column count (assert at m_make.ml:16)
@@ -238,45 +277,30 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
   std::vector<i64> gap_off((size_t)n_rows + 1, 0), gap_start, gap_end;
   std::string cons((size_t)cons_off[n_blocks], '\0');
   if(n > 0) {
-    // per-byte helpers: column within the row, first/last byte of a row
-    std::vector<int> col((size_t)n);
-    std::vector<unsigned char> first((size_t)n, 0), last((size_t)n, 0);
-    for(int r = 0; r < n_rows; ++r) {
-      i64 a = row_off[r], z = row_off[(size_t)r + 1];
-      for(i64 i = a; i < z; ++i) {
-        col[(size_t)i] = (int)(i - a);
-      }
-      if(z > a) {
-        first[(size_t)a] = 1;
-        last[(size_t)z - 1] = 1;
-      }
-    }
-    DevBuf d_text, d_first, d_last, d_col, d_start, d_stop, d_sscan, d_escan, d_tmp, d_gs, d_ge;
+    lap("(nothing per byte on the host)");
+    DevBuf d_text, d_roff0, d_col, d_start, d_stop, d_sscan, d_escan, d_tmp, d_gs, d_ge, d_goff;
     PM_TRY(d_text.upload(text.data(), (size_t)n, nullptr));
-    PM_TRY(d_first.upload(first.data(), (size_t)n, nullptr));
-    PM_TRY(d_last.upload(last.data(), (size_t)n, nullptr));
-    PM_TRY(d_col.upload(col.data(), (size_t)n * 4, nullptr));
+    PM_TRY(d_roff0.upload(row_off.data(), ((size_t)n_rows + 1) * 8, nullptr));
+    PM_TRY(d_col.alloc((size_t)n * 4));
     PM_TRY(d_start.alloc((size_t)n * 4));
     PM_TRY(d_stop.alloc((size_t)n * 4));
     PM_TRY(d_sscan.alloc((size_t)n * 4));
     PM_TRY(d_escan.alloc((size_t)n * 4));
+    PM_TRY(d_goff.alloc(((size_t)n_rows + 1) * 8));
     unsigned blocks = (unsigned)((n + 255) / 256);
-    gap_flags_kernel<<<blocks, 256>>>(n, (const unsigned char *)d_text.p, (const unsigned char *)d_first.p, (const unsigned char *)d_last.p,
-                                      (int *)d_start.p, (int *)d_stop.p);
+    gap_flags_kernel<<<blocks, 256>>>(n, (const unsigned char *)d_text.p, (const i64 *)d_roff0.p, n_rows, (int *)d_start.p, (int *)d_stop.p,
+                                      (int *)d_col.p);
     PM_HIP(hipGetLastError());
     size_t bytes = 0;
     PM_HIP(rocprim::exclusive_scan(nullptr, bytes, (int *)d_start.p, (int *)d_sscan.p, 0, (size_t)n, rocprim::plus<int>()));
     PM_TRY(d_tmp.alloc(bytes ? bytes : 8));
     PM_HIP(rocprim::exclusive_scan(d_tmp.p, bytes, (int *)d_start.p, (int *)d_sscan.p, 0, (size_t)n, rocprim::plus<int>()));
     PM_HIP(rocprim::exclusive_scan(d_tmp.p, bytes, (int *)d_stop.p, (int *)d_escan.p, 0, (size_t)n, rocprim::plus<int>()));
-    std::vector<int> sscan((size_t)n), sflag((size_t)n);
-    PM_HIP(hipMemcpy(sscan.data(), d_sscan.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    PM_HIP(hipMemcpy(sflag.data(), d_start.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    i64 total = sscan[(size_t)n - 1] + sflag[(size_t)n - 1];
-    for(int r = 0; r < n_rows; ++r) {
-      gap_off[r] = row_off[r] < n ? sscan[(size_t)row_off[r]] : total;
-    }
-    gap_off[n_rows] = total;
+    gap_offsets_kernel<<<(unsigned)((n_rows + 256) / 256), 256>>>(n_rows, n, (const i64 *)d_roff0.p, (const int *)d_start.p, (const int *)d_sscan.p,
+                                                                  (i64 *)d_goff.p);
+    PM_HIP(hipGetLastError());
+    PM_HIP(hipMemcpy(gap_off.data(), d_goff.p, ((size_t)n_rows + 1) * 8, hipMemcpyDeviceToHost));
+    i64 total = gap_off[n_rows];
     gap_start.resize((size_t)total);
     gap_end.resize((size_t)total);
     if(total > 0) {
@@ -301,6 +325,7 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
       PM_HIP(hipMemcpy(&cons[0], d_cons.p, (size_t)nc, hipMemcpyDeviceToHost));
     }
   }
+  lap("gap runs + consensus (device)");
   // m_make.ml:48-62: both files are created even when the MAF holds no block
   std::string dir(out_dir);
   FILE *fp = fopen((dir + "/profiles").c_str(), "wb");
@@ -311,27 +336,48 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
     return fail(PM_E_IO, "cannot create output files in " + dir + " (the directory must exist)");
   }
   std::string buf;
+  buf.reserve((size_t)2 << 20);
+  auto put = [&buf](long long v) { // decimal, appended in place (a million numbers: no temporaries)
+    char tmp[24];
+    int k = 0;
+    unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+    do {
+      tmp[k++] = (char)('0' + u % 10);
+      u /= 10;
+    } while(u);
+    if(v < 0) {
+      tmp[k++] = '-';
+    }
+    while(k) {
+      buf.push_back(tmp[--k]);
+    }
+  };
   char major[1024];
+  int major_block = -1;
+  size_t major_len = 0;
   for(int r = 0; r < n_rows; ++r) { // m_profile.ml:122-135
-    snprintf(major, sizeof major, "%s.%s_%04d", basename, basename, rows[r].block); // m_profile_stream.ml:65
-    buf += major;
+    if(rows[r].block != major_block) {
+      major_block = rows[r].block;
+      major_len = (size_t)snprintf(major, sizeof major, "%s.%s_%04d", basename, basename, rows[r].block); // m_profile_stream.ml:65
+    }
+    buf.append(major, major_len);
     buf += ' ';
-    buf += std::to_string(rows[r].minor);
+    put(rows[r].minor);
     buf += ' ';
     buf += rows[r].seq_name;
     buf += ' ';
-    buf += std::to_string(rows[r].start);
+    put(rows[r].start);
     buf += ' ';
-    buf += std::to_string(rows[r].end);
+    put(rows[r].end);
     buf += ' ';
-    buf += std::to_string(row_off[(size_t)r + 1] - row_off[r]);
+    put(row_off[(size_t)r + 1] - row_off[r]);
     buf += ' ';
-    buf += std::to_string(rows[r].src_size);
+    put(rows[r].src_size);
     buf += '\n';
     for(i64 g = gap_off[r]; g < gap_off[(size_t)r + 1]; ++g) {
-      buf += std::to_string(gap_start[(size_t)g]);
+      put(gap_start[(size_t)g]);
       buf += ' ';
-      buf += std::to_string(gap_end[(size_t)g]);
+      put(gap_end[(size_t)g]);
       buf += '\n';
     }
     buf += "0\n";
@@ -361,6 +407,7 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
   if(fclose(ff) != 0 || !wrote || text_bytes < 0) {
     return fail(PM_E_IO, "cannot write the output files in " + dir);
   }
+  lap("profiles + fasta formatted, written");
   // the same rows as flat arrays: what parse_profiles would read back from the file just written
   Side side;
   side.gap_off.assign(gap_off.begin(), gap_off.end());
@@ -375,6 +422,7 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
     side.length.push_back(row_off[(size_t)r + 1] - row_off[r]);
   }
   PM_TRY(write_side_soa(dir, side, text_bytes));
+  lap("side file written");
   if(side_out) {
     *side_out = std::move(side);
   }
@@ -410,6 +458,20 @@ extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const 
     }
     paths.push_back(delta_paths[k]);
   }
+  const bool timing = getenv("PM_TIMING") != nullptr;
+  auto wall = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+  };
+  double lap_t = wall();
+  auto lap = [&](const char *what) {
+    if(timing) {
+      const double t = wall();
+      fprintf(stderr, "[pm] stage: %-40s %.4f s\n", what, t - lap_t);
+      lap_t = t;
+    }
+  };
   Workload w;
   int rc_l = PM_OK, rc_r = PM_OK;
   std::string msg_l, msg_r;
@@ -435,16 +497,20 @@ extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const 
   if(rc_r) {
     return fail(rc_r, msg_r);
   }
+  lap("two makes beside the delta files");
   index_and_enumerate(w);
+  lap("rows indexed, units listed");
   FILE *f = fopen(out_delta, "wb");
   if(!f) {
     return fail(PM_E_IO, std::string("cannot open ") + out_delta);
   }
   fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_dir, right_dir); // m_translate_main.cc:35-39
   int rc = run_workload(w, f, device);
+  lap("translate job (device) and its text out");
   if(fclose(f) != 0 && !rc) {
     rc = fail(PM_E_IO, "close failed");
   }
+  lap("output closed");
   if(!rc && w.parse_rc) {
     rc = fail(w.parse_rc, w.parse_msg);
   }

@@ -872,6 +872,20 @@ static void staging_release(const TextStaging &st) {
   std::lock_guard<std::mutex> hold(g_staging_lock);
   g_staging_free.push_back(st);
 }
+void text_staging_trim() {
+  std::vector<TextStaging> all;
+  {
+    std::lock_guard<std::mutex> hold(g_staging_lock);
+    all.swap(g_staging_free);
+  }
+  for(size_t k = 0; k < all.size(); ++k) {
+    for(int b = 0; b < TextStaging::n_buf; ++b) {
+      if(all[k].p[b]) {
+        (void)hipHostFree(all[k].p[b]);
+      }
+    }
+  }
+}
 // start-up helper: a set allocated ahead of its use (pinning 32 MB takes a few milliseconds)
 void warm_text_staging() {
   TextStaging st;
