@@ -278,14 +278,17 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
   std::string cons((size_t)cons_off[n_blocks], '\0');
   if(n > 0) {
     lap("(nothing per byte on the host)");
-    DevBuf d_text, d_roff0, d_col, d_start, d_stop, d_sscan, d_escan, d_tmp, d_gs, d_ge, d_goff;
-    PM_TRY(d_text.upload(text.data(), (size_t)n, nullptr));
+    // the per-byte buffers come from the pool of kept device buffers (every one of them is written in full before it is read)
+    DevBuf d_roff0, d_tmp, d_gs, d_ge, d_goff;
+    PooledBuf d_text, d_col, d_start, d_stop, d_sscan, d_escan;
+    PM_TRY(d_text.alloc((size_t)n, device));
+    PM_HIP(hipMemcpy(d_text.p, text.data(), (size_t)n, hipMemcpyHostToDevice));
     PM_TRY(d_roff0.upload(row_off.data(), ((size_t)n_rows + 1) * 8, nullptr));
-    PM_TRY(d_col.alloc((size_t)n * 4));
-    PM_TRY(d_start.alloc((size_t)n * 4));
-    PM_TRY(d_stop.alloc((size_t)n * 4));
-    PM_TRY(d_sscan.alloc((size_t)n * 4));
-    PM_TRY(d_escan.alloc((size_t)n * 4));
+    PM_TRY(d_col.alloc((size_t)n * 4, device));
+    PM_TRY(d_start.alloc((size_t)n * 4, device));
+    PM_TRY(d_stop.alloc((size_t)n * 4, device));
+    PM_TRY(d_sscan.alloc((size_t)n * 4, device));
+    PM_TRY(d_escan.alloc((size_t)n * 4, device));
     PM_TRY(d_goff.alloc(((size_t)n_rows + 1) * 8));
     unsigned blocks = (unsigned)((n + 255) / 256);
     gap_flags_kernel<<<blocks, 256>>>(n, (const unsigned char *)d_text.p, (const i64 *)d_roff0.p, n_rows, (int *)d_start.p, (int *)d_stop.p,
