@@ -210,3 +210,30 @@ def test_maf_blocks_over_a_device_list(oracle_build, tmp_path):
     subprocess.run([os.path.join(ROOT, "bin", "mugsy_profiles"), "align", "-left_maf", pa, "-right_maf", pb, "-out_maf", cli, "-rows", "2",
                     "-devices", "0,0"], check=True)
     assert open(cli, "rb").read() == open(one, "rb").read()
+
+
+@pytest.mark.gpu
+def test_output_that_cannot_be_seeked_and_released_caches(tmp_path):
+    """The job's text normally goes to the output file piece by piece through the descriptor, each piece at its own place; a sink that
+    cannot seek (a named pipe) gets the pieces in order instead -- same bytes.  pm_release_caches() drops the kept staging and
+    device buffers, and the next call builds them again."""
+    import threading
+    from paramugsy_amd.translate import translate
+    w = synth.make_workload(str(tmp_path / "job"), 94, n_left=3, n_right=3, genome_len=60000, n_blocks=40, n_deltas=5,
+                            entries_per_delta=150, mean_len=900)
+    plain = str(tmp_path / "plain.delta")
+    translate(w.left_dir, w.right_dir, w.delta_paths, plain)
+    want = open(plain, "rb").read()
+    fifo = str(tmp_path / "out.fifo")
+    os.mkfifo(fifo)
+    got = []
+    reader = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    reader.start()
+    translate(w.left_dir, w.right_dir, w.delta_paths, fifo)
+    reader.join(timeout=60)
+    assert got and got[0] == want and len(want) > 20000
+    assert capi.lib().pm_release_caches() == capi.PM_OK
+    again = str(tmp_path / "again.delta")
+    translate(w.left_dir, w.right_dir, w.delta_paths, again)
+    assert open(again, "rb").read() == want
+    assert capi.lib().pm_release_caches() == capi.PM_OK
