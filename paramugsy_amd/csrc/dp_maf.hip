@@ -972,6 +972,7 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
 }
 
 extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, int device) {
+  return pm::guarded("pm_dp_align_maf", [&]() -> int {
   if(!maf_a || !maf_b || !params || !out_maf) {
     return fail(PM_E_INVALID, "pm_dp_align_maf: null argument");
   }
@@ -1056,12 +1057,14 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
   }
   lap("write");
   return PM_OK;
+  });
 }
 
 extern "C" int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a, const uint8_t *text_b,
                                   const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs,
                                   const pm_dp_params_t *params, int32_t *scores, int32_t *merged_columns, uint8_t *out_text, int64_t out_capacity,
                                   int64_t *out_off, int device) {
+  return pm::guarded("pm_dp_align_blocks", [&]() -> int {
   if(!row_off_a || !row_off_b || !block_row_a || !block_row_b || !params || !scores || !merged_columns || !out_off || n_pairs < 0 ||
      (!out_text && out_capacity > 0)) {
     return fail(PM_E_INVALID, "pm_dp_align_blocks: null argument");
@@ -1085,6 +1088,7 @@ extern "C" int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_
     memcpy(out_text, merged.data(), (size_t)off[(size_t)n_pairs]);
   }
   return PM_OK;
+  });
 }
 
 // ------------------------------------------------------------------ several devices (multi.hpp)
@@ -1122,6 +1126,7 @@ extern "C" int pm_dp_align_blocks_multi(const uint8_t *text_a, const int64_t *ro
                                         const uint8_t *text_b, const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b,
                                         int64_t n_pairs, const pm_dp_params_t *params, const int *devices, int n_devices, int32_t *scores,
                                         int32_t *merged_columns, uint8_t *out_text, int64_t out_capacity, int64_t *out_off) {
+  return pm::guarded("pm_dp_align_blocks_multi", [&]() -> int {
   if(!row_off_a || !row_off_b || !block_row_a || !block_row_b || !params || !scores || !merged_columns || !out_off || n_pairs < 0 ||
      (!out_text && out_capacity > 0)) {
     return fail(PM_E_INVALID, "pm_dp_align_blocks_multi: null argument");
@@ -1158,10 +1163,12 @@ extern "C" int pm_dp_align_blocks_multi(const uint8_t *text_a, const int64_t *ro
     }
   }
   return PM_OK;
+  });
 }
 
 extern "C" int pm_dp_align_maf_multi(const char *maf_a, const char *maf_b, const pm_dp_params_t *params, const char *out_maf, const int *devices,
                                      int n_devices) {
+  return pm::guarded("pm_dp_align_maf_multi", [&]() -> int {
   if(!maf_a || !maf_b || !params || !out_maf) {
     return fail(PM_E_INVALID, "pm_dp_align_maf_multi: null argument");
   }
@@ -1189,4 +1196,5 @@ extern "C" int pm_dp_align_maf_multi(const char *maf_a, const char *maf_b, const
     return fail(PM_E_IO, std::string("cannot write ") + out_maf);
   }
   return PM_OK;
+  });
 }

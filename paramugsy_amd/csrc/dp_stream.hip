@@ -235,6 +235,7 @@ int pm_dp_stream_align(pm_dp_stream_t *s, const uint8_t *cols_a, const int64_t *
 int pm_dp_stream_align_text(pm_dp_stream_t *s, const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a,
                             const uint8_t *text_b, const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n_pairs,
                             int32_t *scores, uint8_t *ops, int32_t *n_ops) {
+  return guarded("pm_dp_stream_align_text", [&]() -> int {
   if(!s || n_pairs < 0 || !row_off_a || !row_off_b || !block_row_a || !block_row_b || !scores) {
     return fail(PM_E_INVALID, "pm_dp_stream_align_text: null argument");
   }
@@ -289,6 +290,7 @@ int pm_dp_stream_align_text(pm_dp_stream_t *s, const uint8_t *text_a, const int6
         true, true);
   };
   return stream_align_core(s, load, n_pairs, scores, ops, n_ops);
+  });
 }
 
 void pm_dp_stream_destroy(pm_dp_stream_t *s) {
@@ -305,6 +307,7 @@ void pm_dp_stream_destroy(pm_dp_stream_t *s) {
 // is the layout itself.  Workers that share a device (the same index named twice) share its workspace budget.
 int pm_dp_align_multi(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
                       const pm_dp_params_t *params, const int *devices, int n_devices, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
+  return guarded("pm_dp_align_multi", [&]() -> int {
   if(n_pairs < 0 || !off_a || !off_b || !params || !scores || (n_pairs > 0 && (!cols_a || !cols_b))) {
     return fail(PM_E_INVALID, "pm_dp_align_multi: null argument");
   }
@@ -344,6 +347,7 @@ int pm_dp_align_multi(const uint8_t *cols_a, const int64_t *off_a, const uint8_t
     std::string msg = rc ? pm_last_error() : "";
     pm_dp_stream_destroy(st);
     return rc ? fail(rc, msg) : (int)PM_OK;
+  });
   });
 }
 

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <exception>
+#include <new>
 #include <string>
 
 #include "../../include/paramugsy_amd.h"
@@ -30,6 +32,21 @@ int use_device(int device);
       return rc_;     \
     }                 \
   } while(0)
+
+// An extern "C" entry point's body run so that no C++ exception (std::bad_alloc from a table sized by the input, a std::system_error
+// from a thread that cannot be started) crosses the C boundary: it becomes a return code and a message.
+template <typename F>
+int guarded(const char *who, F body) {
+  try {
+    return body();
+  }
+  catch(const std::bad_alloc &) {
+    return fail(PM_E_INVALID, std::string(who) + ": out of host memory");
+  }
+  catch(const std::exception &e) {
+    return fail(PM_E_INVALID, std::string(who) + ": " + e.what());
+  }
+}
 
 // Owning device allocation.
 struct DevBuf {

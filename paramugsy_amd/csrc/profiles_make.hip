@@ -437,10 +437,12 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
 using namespace pm;
 
 extern "C" int pm_profiles_make(const char *in_maf, const char *out_dir, const char *basename, int device) {
+  return pm::guarded("pm_profiles_make", [&]() -> int {
   if(!in_maf || !out_dir || !basename) {
     return fail(PM_E_INVALID, "pm_profiles_make: null argument");
   }
   return make_profiles(in_maf, out_dir, basename, device, nullptr);
+  });
 }
 
 // make(left) + make(right) + translate in one process and one HIP context (lib/base/mugsy_profiles_task.ml:40-58 runs them as
@@ -449,6 +451,7 @@ extern "C" int pm_profiles_make(const char *in_maf, const char *out_dir, const c
 extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const char *left_basename, const char *right_maf,
                               const char *right_dir, const char *right_basename, const char *const *delta_paths, int n_paths,
                               const char *out_delta, int device) {
+  return pm::guarded("pm_stage_files", [&]() -> int {
   if(!left_maf || !left_dir || !left_basename || !right_maf || !right_dir || !right_basename || !out_delta || n_paths < 0 ||
      (n_paths > 0 && !delta_paths)) {
     return fail(PM_E_INVALID, "pm_stage_files: null argument");
@@ -518,4 +521,5 @@ extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const 
     rc = fail(w.parse_rc, w.parse_msg);
   }
   return rc;
+  });
 }

@@ -906,7 +906,13 @@ int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool tim
   }
   TextStaging stage;
   const double t0 = wall_now();
-  PM_TRY(staging_acquire(stage));
+  {
+    const int rc_stage = staging_acquire(stage);
+    if(rc_stage) {
+      copied(); // the caller's clean-up hangs on this call whatever happens
+      return rc_stage;
+    }
+  }
   const int64_t piece = TextStaging::piece;
   const int n_buf = TextStaging::n_buf;
   const int64_t n_pieces = (n_bytes + piece - 1) / piece;
@@ -1058,7 +1064,12 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
     else {
       reap();
     }
-    reaper.join();
+    if(reaper.joinable()) {
+      reaper.join();
+    }
+    else {
+      pm_job_destroy(job);
+    }
     if(rc) {
       return rc;
     }
@@ -1206,6 +1217,7 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
 
 extern "C" int pm_translate_files(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                                   const char *out_path, int device) {
+  return pm::guarded("pm_translate_files", [&]() -> int {
   if(!left_dir || !right_dir || !out_path || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
     return pm::fail(PM_E_INVALID, "pm_translate_files: null argument");
   }
@@ -1228,10 +1240,12 @@ extern "C" int pm_translate_files(const char *left_dir, const char *right_dir, c
     rc = pm::fail(PM_E_IO, "close failed");
   }
   return rc;
+  });
 }
 
 extern "C" int pm_translate_files_multi(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                                         const char *out_path, const int *devices, int n_devices) {
+  return pm::guarded("pm_translate_files_multi", [&]() -> int {
   if(!left_dir || !right_dir || !out_path || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
     return pm::fail(PM_E_INVALID, "pm_translate_files_multi: null argument");
   }
@@ -1253,11 +1267,13 @@ extern "C" int pm_translate_files_multi(const char *left_dir, const char *right_
     rc = pm::fail(PM_E_IO, "close failed");
   }
   return rc;
+  });
 }
 
 // Host only: the outputs of m_translate runs over consecutive slices of one delta-file list (each a complete file: the two header
 // lines of m_translate_main.cc:35-39, then the entries) joined into what one run over the whole list prints.
 extern "C" int pm_delta_join_files(const char *const *part_paths, int n_parts, const char *out_path) {
+  return pm::guarded("pm_delta_join_files", [&]() -> int {
   if(n_parts < 0 || (n_parts > 0 && !part_paths) || !out_path) {
     return pm::fail(PM_E_INVALID, "pm_delta_join_files: null argument");
   }
@@ -1293,6 +1309,7 @@ extern "C" int pm_delta_join_files(const char *const *part_paths, int n_parts, c
     rc = pm::fail(PM_E_IO, "close failed");
   }
   return rc;
+  });
 }
 
 extern "C" int pm_partition(int64_t n_items, int n_parts, int part, int64_t *lo, int64_t *hi) {
@@ -1309,6 +1326,7 @@ struct pm_workload {
 
 extern "C" int pm_workload_load(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                                 pm_workload_t **out) {
+  return pm::guarded("pm_workload_load", [&]() -> int {
   if(!left_dir || !right_dir || !out || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
     return pm::fail(PM_E_INVALID, "pm_workload_load: null argument");
   }
@@ -1331,6 +1349,7 @@ extern "C" int pm_workload_load(const char *left_dir, const char *right_dir, con
     return pm::fail(h->w.parse_rc, h->w.parse_msg); // handle stays valid: the entries read before the failure are in it
   }
   return PM_OK;
+  });
 }
 
 extern "C" int pm_workload_tables(pm_workload_t *h, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units) {

@@ -1188,6 +1188,7 @@ static int upload_names(pm_job *j, int side, const char *const *names, i64 n) {
 
 int pm_job_text(pm_job_t *j, const char *const *left_major, const char *const *right_major, int64_t *n_bytes, int64_t *failed_unit,
                 int32_t *failed_status) {
+  return guarded("pm_job_text", [&]() -> int {
   if(!j || !n_bytes || (j->left.n > 0 && !left_major) || (j->right.n > 0 && !right_major)) {
     return fail(PM_E_INVALID, "pm_job_text: null argument");
   }
@@ -1265,6 +1266,7 @@ int pm_job_text(pm_job_t *j, const char *const *left_major, const char *const *r
     }
   }
   return PM_OK;
+  });
 }
 
 int pm_job_text_fetch_range(pm_job_t *j, char *out, int64_t first, int64_t n) {
