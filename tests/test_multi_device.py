@@ -231,7 +231,8 @@ def test_output_that_cannot_be_seeked_and_released_caches(tmp_path):
     reader.start()
     translate(w.left_dir, w.right_dir, w.delta_paths, fifo)
     reader.join(timeout=60)
-    assert got and got[0] == want and len(want) > 20000
+    assert got and got[0] == want
+    assert len(want) > 2000
     assert capi.lib().pm_release_caches() == capi.PM_OK
     again = str(tmp_path / "again.delta")
     translate(w.left_dir, w.right_dir, w.delta_paths, again)
