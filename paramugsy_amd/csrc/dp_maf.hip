@@ -8,8 +8,10 @@
 //   emit   two blocks + the DP's path -> the merged block: every row's text expanded along the path with '-' where the
 //          path skips its side, as lib/profiles/m_untranslate.ml:38-52 (expand_text) re-inserts gap columns along a
 //          coordinate walk.
-// Both are byte kernels: one thread per block column (pack) or per output byte (emit), consecutive lanes on consecutive
-// bytes of a row; the path's running column positions come from one device scan over all ops.
+// Both are byte kernels: one thread per block column (pack), one per (pair, path position) writing that column's byte of every
+// row of the merged block (emit), consecutive lanes on consecutive bytes of a row; the path's running column positions come from
+// one device scan over all ops.  The file entries (pm_dp_align_maf*) map the input files, send their bytes as they are while the
+// lines are indexed on the host, and assemble the bytes of the OUTPUT FILE on the device.
 // Symbol policy (stated, since nothing upstream defines it): case-insensitive; A, C, G, T count in bytes 0-3, '-' in byte 4,
 // anything else (N, IUPAC codes, '.') in byte 5, which the DP does not score: such a row is neutral in that column.
 #include <hip/hip_runtime.h>
@@ -86,55 +88,8 @@ __global__ void dp_op_flags_kernel(i64 n, const unsigned char *__restrict__ ops,
   fb[g] = op != 2;
 }
 
-// One thread per output byte: pair p, row r of its (rows(A) + rows(B)) rows, path position k.
-__global__ void dp_emit_kernel(i64 n_out, i64 n_pairs, const i64 *__restrict__ out_off, const i64 *__restrict__ ops_off,
-                               const int *__restrict__ n_ops, const unsigned char *__restrict__ ops, const int *__restrict__ pos_a,
-                               const int *__restrict__ pos_b, const i64 *__restrict__ block_row_a, const i64 *__restrict__ row_off_a,
-                               const unsigned char *__restrict__ text_a, const i64 *__restrict__ block_row_b,
-                               const i64 *__restrict__ row_off_b, const unsigned char *__restrict__ text_b, unsigned char *__restrict__ out,
-                               int *bad) {
-  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if(g >= n_out) {
-    return;
-  }
-  const i64 p = owner_of(out_off, n_pairs, g);
-  const i64 len = n_ops[p];
-  const i64 r = (g - out_off[p]) / len, k = (g - out_off[p]) % len;
-  const i64 o = ops_off[p] + k;
-  const unsigned char op = ops[o];
-  if(op > 2) {
-    atomicOr(bad, 1);
-  }
-  const i64 ra = block_row_a[p + 1] - block_row_a[p];
-  unsigned char ch = '-';
-  if(r < ra) {
-    if(op != 1) {
-      const i64 row = block_row_a[p] + r;
-      const i64 c = pos_a[o] - pos_a[ops_off[p]];
-      if(c >= row_off_a[row + 1] - row_off_a[row]) {
-        atomicOr(bad, 2);
-      }
-      else {
-        ch = text_a[row_off_a[row] + c];
-      }
-    }
-  }
-  else {
-    if(op != 2) {
-      const i64 row = block_row_b[p] + (r - ra);
-      const i64 c = pos_b[o] - pos_b[ops_off[p]];
-      if(c >= row_off_b[row + 1] - row_off_b[row]) {
-        atomicOr(bad, 2);
-      }
-      else {
-        ch = text_b[row_off_b[row] + c];
-      }
-    }
-  }
-  out[g] = ch;
-}
-
-// The merged blocks straight into the bytes of the MAF file they are written to.  One thread per (pair, path position): it reads
+// The merged blocks straight into the bytes they are delivered as: the MAF file they are written to (pm_dp_align_maf), or the blocks'
+// lines back to back (pm_dp_emit_maf, pm_dp_align_blocks).  One thread per (pair, path position): it reads
 // its op and the two column positions once and writes that column's byte of EVERY row of the merged block -- rows(A) + rows(B)
 // stores, each coalesced with the neighbouring threads' (consecutive positions of one output line).  line_text[q] = where the text
 // of output line q starts in the file image; pair p's lines are first_line[p] .. (A's rows first).
@@ -171,6 +126,25 @@ __global__ void dp_emit_file_kernel(i64 n_pairs, const i64 *__restrict__ ops_off
           out[line_text[q0 + ra + r] + k] = op != 2 ? (char)text_b[row_off_b[rb0 + r] + cb] : '-';
         }
       }
+    }
+  }
+}
+
+// Where the lines of the merged blocks go when the output is the blocks themselves (pm_dp_emit_maf, pm_dp_align_blocks: pair p's
+// rows(A) + rows(B) lines of n_ops[p] bytes back to back at out_off[p]): pair p's first line is line block_row_a[p] + block_row_b[p].
+__global__ void dp_line_table_kernel(i64 n_pairs, const i64 *__restrict__ block_row_a, const i64 *__restrict__ block_row_b,
+                                     const i64 *__restrict__ out_off, const int *__restrict__ n_ops, i64 *__restrict__ first_line,
+                                     i64 *__restrict__ line_text) {
+  const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(p > n_pairs) {
+    return;
+  }
+  const i64 q0 = block_row_a[p] + block_row_b[p];
+  first_line[p] = q0;
+  if(p < n_pairs) {
+    const i64 rows = block_row_a[p + 1] - block_row_a[p] + block_row_b[p + 1] - block_row_b[p];
+    for(i64 r = 0; r < rows; ++r) {
+      line_text[q0 + r] = out_off[p] + r * (i64)n_ops[p];
     }
   }
 }
@@ -496,15 +470,20 @@ struct MafSideDev {
 
 // The merged blocks of n_pairs pairs from texts, tables and paths that are all in device memory (d_ops: ops_end bytes, pair p's
 // path at d_ops_off[p], d_n_ops[p] long; d_out_off: where each pair's text goes) into d_out (n_out bytes, allocated here).
-static int emit_device(const MafSideDev &A, const MafSideDev &B, i64 n_pairs, const unsigned char *d_ops, i64 ops_end, const i64 *d_ops_off,
-                       const int *d_n_ops, const i64 *d_out_off, i64 n_out, DevBuf &d_out, const char *who) {
-  DevBuf d_fa, d_fb, d_pa, d_pb, d_bad, d_tmp;
-  PM_TRY(d_fa.alloc((size_t)ops_end * 4));
-  PM_TRY(d_fb.alloc((size_t)ops_end * 4));
-  PM_TRY(d_pa.alloc((size_t)ops_end * 4));
-  PM_TRY(d_pb.alloc((size_t)ops_end * 4));
+static int emit_device(const MafSideDev &A, const MafSideDev &B, i64 n_pairs, i64 n_lines, i64 max_len, const unsigned char *d_ops, i64 ops_end,
+                       const i64 *d_ops_off, const int *d_n_ops, const i64 *d_out_off, i64 n_out, DevBuf &d_out, const char *who) {
+  int device = 0;
+  PM_HIP(hipGetDevice(&device));
+  PooledBuf d_fa, d_fb, d_pa, d_pb;
+  DevBuf d_bad, d_tmp, d_first_line, d_line_text;
+  PM_TRY(d_fa.alloc((size_t)ops_end * 4 + 4, device));
+  PM_TRY(d_fb.alloc((size_t)ops_end * 4 + 4, device));
+  PM_TRY(d_pa.alloc((size_t)ops_end * 4 + 4, device));
+  PM_TRY(d_pb.alloc((size_t)ops_end * 4 + 4, device));
   PM_TRY(d_out.alloc((size_t)n_out));
   PM_TRY(d_bad.alloc(4));
+  PM_TRY(d_first_line.alloc((size_t)(n_pairs + 1) * 8));
+  PM_TRY(d_line_text.alloc((size_t)(n_lines + 1) * 8));
   PM_HIP(hipMemset(d_bad.p, 0, 4));
   dp_op_flags_kernel<<<(unsigned)((ops_end + 255) / 256), 256>>>(ops_end, d_ops, (int *)d_fa.p, (int *)d_fb.p);
   PM_HIP(hipGetLastError());
@@ -513,10 +492,16 @@ static int emit_device(const MafSideDev &A, const MafSideDev &B, i64 n_pairs, co
   PM_TRY(d_tmp.alloc(tmp_bytes));
   PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fa.p, (int *)d_pa.p, 0, (size_t)ops_end, rocprim::plus<int>()));
   PM_HIP(rocprim::exclusive_scan(d_tmp.p, tmp_bytes, (int *)d_fb.p, (int *)d_pb.p, 0, (size_t)ops_end, rocprim::plus<int>()));
-  dp_emit_kernel<<<(unsigned)((n_out + 255) / 256), 256>>>(n_out, n_pairs, d_out_off, d_ops_off, d_n_ops, d_ops, (const int *)d_pa.p,
-                                                           (const int *)d_pb.p, (const i64 *)A.block_row.p, (const i64 *)A.row_off.p,
-                                                           (const unsigned char *)A.text.p, (const i64 *)B.block_row.p, (const i64 *)B.row_off.p,
-                                                           (const unsigned char *)B.text.p, (unsigned char *)d_out.p, (int *)d_bad.p);
+  dp_line_table_kernel<<<(unsigned)((n_pairs + 256) / 256), 256>>>(n_pairs, (const i64 *)A.block_row.p, (const i64 *)B.block_row.p, d_out_off,
+                                                                   d_n_ops, (i64 *)d_first_line.p, (i64 *)d_line_text.p);
+  PM_HIP(hipGetLastError());
+  // one thread per (pair, path position): every row's byte of that column (the kernel of the file path, with the lines back to back)
+  const unsigned gx = (unsigned)std::min<i64>((std::max<i64>(max_len, 1) + 255) / 256, 1024), gy = (unsigned)std::min<i64>(std::max<i64>(n_pairs, 1), 65535);
+  dp_emit_file_kernel<<<dim3(gx, gy), 256>>>(n_pairs, d_ops_off, d_n_ops, d_ops, (const int *)d_pa.p, (const int *)d_pb.p, (const i64 *)A.block_row.p,
+                                             (const i64 *)A.row_off.p, (const unsigned char *)A.text.p, (const i64 *)B.block_row.p,
+                                             (const i64 *)B.row_off.p, (const unsigned char *)B.text.p, (const i64 *)A.col_off.p,
+                                             (const i64 *)B.col_off.p, (const i64 *)d_first_line.p, (const i64 *)d_line_text.p, (char *)d_out.p,
+                                             (int *)d_bad.p);
   PM_HIP(hipGetLastError());
   int bad = 0;
   PM_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
@@ -603,16 +588,23 @@ int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_ro
     }
   }
   MafSideDev A, B;
-  std::vector<int64_t> no_cols_a((size_t)n_pairs + 1, 0), no_cols_b((size_t)n_pairs + 1, 0); // the emit side does not need the column offsets
-  PM_TRY(A.upload(text_a, row_off_a, n_rows_a, block_row_a, n_pairs, no_cols_a.data()));
-  PM_TRY(B.upload(text_b, row_off_b, n_rows_b, block_row_b, n_pairs, no_cols_b.data()));
+  std::vector<int64_t> cols_a((size_t)n_pairs + 1, 0), cols_b((size_t)n_pairs + 1, 0); // a block has as many columns as its first row has bytes
+  int64_t max_len = 1;
+  for(int64_t p = 0; p < n_pairs; ++p) {
+    const int64_t ra = block_row_a[p], rb = block_row_b[p];
+    cols_a[(size_t)p + 1] = cols_a[(size_t)p] + (ra < block_row_a[p + 1] ? row_off_a[ra + 1] - row_off_a[ra] : 0);
+    cols_b[(size_t)p + 1] = cols_b[(size_t)p] + (rb < block_row_b[p + 1] ? row_off_b[rb + 1] - row_off_b[rb] : 0);
+    max_len = std::max<int64_t>(max_len, n_ops[p]);
+  }
+  PM_TRY(A.upload(text_a, row_off_a, n_rows_a, block_row_a, n_pairs, cols_a.data()));
+  PM_TRY(B.upload(text_b, row_off_b, n_rows_b, block_row_b, n_pairs, cols_b.data()));
   DevBuf d_ops, d_ops_off, d_n_ops, d_out_off, d_out;
   PM_TRY(d_ops.upload(ops, (size_t)ops_end, nullptr));
   PM_TRY(d_ops_off.upload(ops_off, (size_t)n_pairs * 8, nullptr));
   PM_TRY(d_n_ops.upload(n_ops, (size_t)n_pairs * 4, nullptr));
   PM_TRY(d_out_off.upload(out_off, (size_t)(n_pairs + 1) * 8, nullptr));
-  PM_TRY(emit_device(A, B, n_pairs, (const unsigned char *)d_ops.p, ops_end, (const i64 *)d_ops_off.p, (const int *)d_n_ops.p,
-                     (const i64 *)d_out_off.p, n_out, d_out, "pm_dp_emit_maf"));
+  PM_TRY(emit_device(A, B, n_pairs, n_rows_a + n_rows_b, max_len, (const unsigned char *)d_ops.p, ops_end, (const i64 *)d_ops_off.p,
+                     (const int *)d_n_ops.p, (const i64 *)d_out_off.p, n_out, d_out, "pm_dp_emit_maf"));
   PM_HIP(hipMemcpy(out_text, d_out.p, (size_t)n_out, hipMemcpyDeviceToHost));
   return PM_OK;
 }
@@ -757,8 +749,12 @@ static int align_blocks_core(const uint8_t *text_a, const int64_t *row_off_a, in
     PM_TRY(d_ops_off.upload(ops_off.data(), (size_t)n * 8, nullptr));
     PM_TRY(d_n_ops.upload(n_ops.data(), (size_t)n * 4, nullptr));
     PM_TRY(d_out_off.upload(out_off.data(), (size_t)(n + 1) * 8, nullptr));
-    PM_TRY(emit_device(SA, SB, n, (const unsigned char *)batch->ops.p, ops_end, (const i64 *)d_ops_off.p, (const int *)d_n_ops.p,
-                       (const i64 *)d_out_off.p, out_off[(size_t)n], d_out, "pm_dp_align"));
+    int64_t max_len = 1;
+    for(int64_t k = 0; k < n; ++k) {
+      max_len = std::max<int64_t>(max_len, n_ops[(size_t)k]);
+    }
+    PM_TRY(emit_device(SA, SB, n, n_rows_a + n_rows_b, max_len, (const unsigned char *)batch->ops.p, ops_end, (const i64 *)d_ops_off.p,
+                       (const int *)d_n_ops.p, (const i64 *)d_out_off.p, out_off[(size_t)n], d_out, "pm_dp_align"));
     PM_HIP(hipMemcpy(merged.data(), d_out.p, (size_t)out_off[(size_t)n], hipMemcpyDeviceToHost));
   }
   lap("emit (device)");
