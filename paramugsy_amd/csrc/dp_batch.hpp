@@ -75,6 +75,7 @@ namespace pm {
 // The steps pm_dp_batch_create is made of (dp_kernels.hip).  A reusable batch goes reserve once, then load / plan / run per slice.
 int dp_batch_check_params(const pm_dp_params_t *params);
 int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device);
+int dp_clear_pipe_error(pm_dp_batch *h); // synchronous (see dp_kernels.hip)
 // device buffers for up to cap_pairs pairs with cap_a / cap_b columns in all; only grows
 int dp_batch_reserve(pm_dp_batch *h, i64 cap_pairs, i64 cap_a, i64 cap_b);
 // offsets (rebased to 0), columns and the column statistics kernels on `stream`; the statistics land in h->host_stats once the

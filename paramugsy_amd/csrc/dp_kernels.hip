@@ -524,6 +524,16 @@ int dp_batch_check_params(const pm_dp_params_t *params) {
   return PM_OK;
 }
 
+// The error word of the fill kernel's bounded waits, cleared so that the clear has LANDED when this returns: the kernels run on
+// the caller's streams, which need not wait for the null stream (hipStreamNonBlocking: pm_dp_stream_*), and a wave that finds the
+// word set -- by a hipMemset that has not run yet over whatever the allocation held before -- skips its waits.  A blocking copy from
+// host memory is complete on return; hipMemset is not.
+int dp_clear_pipe_error(pm_dp_batch *h) {
+  const int zero = 0;
+  PM_HIP(hipMemcpy(h->pipe_error.p, &zero, 4, hipMemcpyHostToDevice));
+  return PM_OK;
+}
+
 int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device) {
   h->device = device;
   if(const char *e = getenv("PM_DP_WAVES")) {
@@ -569,7 +579,7 @@ int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budge
   }
   h->tb_budget_bytes = tb_budget_bytes;
   PM_TRY(h->pipe_error.alloc(4));
-  PM_HIP(hipMemset(h->pipe_error.p, 0, 4));
+  PM_TRY(dp_clear_pipe_error(h));
   PM_TRY(h->stats.alloc(32));
   return PM_OK;
 }
@@ -1400,7 +1410,7 @@ int pm_dp_batch_fetch(pm_dp_batch_t *h, int32_t *scores, uint8_t *ops, int32_t *
     int perr = 0;
     PM_HIP(hipMemcpy(&perr, h->pipe_error.p, 4, hipMemcpyDeviceToHost));
     if(perr) {
-      (void)hipMemset(h->pipe_error.p, 0, 4); // reported: the batch can be run again
+      (void)dp_clear_pipe_error(h); // reported: the batch can be run again
       return fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
     }
   }

@@ -204,7 +204,7 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
   drain();
   lap("drained");
   if(!rc && s->host_words[8]) {
-    (void)hipMemset(b->pipe_error.p, 0, 4); // reported: the stream's batch is reused by the next call
+    (void)dp_clear_pipe_error(b); // reported: the stream's batch is reused by the next call
     s->host_words[8] = 0;
     rc = fail(PM_E_HIP, "dp_fill_kernel: a stripe timed out waiting for its left neighbour (results invalid)");
   }

@@ -96,6 +96,9 @@ while time.time() < t_end:
     # texts; the device-list entry with two to four workers on the one GPU
     draw = rng.random()
     engine = "batch" if draw >= 0.45 or inputs.n_pairs == 0 else ("stream" if draw < 0.2 else ("stream_text" if draw < 0.33 else "multi"))
+    if os.environ.get("PM_FUZZ_ENGINE") and inputs.n_pairs > 0:  # one engine only (hunting)
+        engine = os.environ["PM_FUZZ_ENGINE"]
+    n_workers = int(rng.integers(2, 5))
     if engine == "stream_text" and rows > 255:
         engine = "stream"
     streamed = engine != "batch"
@@ -113,7 +116,7 @@ while time.time() < t_end:
             paths = dp.paths_of(inputs, ops, n_ops)
             v = {"checkpoints": "?", "cols_per_lane": "?"}
         elif engine == "multi":
-            scores, ops, n_ops = dp.align_multi(inputs, p, [0] * int(rng.integers(2, 5)))
+            scores, ops, n_ops = dp.align_multi(inputs, p, [0] * n_workers)
             paths = dp.paths_of(inputs, ops, n_ops)
             v = {"checkpoints": "?", "cols_per_lane": "?"}
         else:
@@ -135,8 +138,17 @@ while time.time() < t_end:
           "OK" if ok else "MISMATCH", flush=True)
     if not ok:
         bad = [k for k in range(len(la)) if scores[k] != o_scores[k] or not np.array_equal(paths[k], o_paths[k])]
-        print("  first bad pairs", bad[:5], "la/lb", [(la[k], lb[k]) for k in bad[:5]], flush=True)
+        print("  first bad pairs", bad[:5], "la/lb", [(la[k], lb[k]) for k in bad[:5]], "workers", n_workers if engine == "multi" else "-", flush=True)
+        for k in bad[:3]:
+            diff = [i for i in range(min(len(paths[k]), len(o_paths[k]))) if paths[k][i] != o_paths[k][i]]
+            print("   pair", k, "score", int(scores[k]), "oracle", int(o_scores[k]), "path length", len(paths[k]), "oracle", len(o_paths[k]),
+                  "first differing op", diff[:1], "ops differing", len(diff), flush=True)
+        if os.environ.get("PM_FUZZ_KEEP_GOING"):
+            seed += 1
+            continue
         sys.exit(1)
     cases += 1
+    if os.environ.get("PM_FUZZ_SAME_SEED"):  # the same case again and again (hunting something that does not fail every time)
+        continue
     seed += 1
 print("cases", cases, "all equal the oracle")
