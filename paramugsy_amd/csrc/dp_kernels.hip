@@ -95,7 +95,9 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   constexpr bool TRACE = MODE == DP_MODE_BITS;
   constexpr bool CKPT = MODE == DP_MODE_CKPT;
   constexpr int TBW = C / 8;
-  __shared__ int4 ring_all[NW][128];
+  // A's expanded rows, 128 rows deep, every row written at two places 128 apart: the 127 rows a 64-step block reads (64 lanes one row
+  // apart, 64 steps) then lie at consecutive places whatever the block, and a lane's read address only advances, 16 bytes a step
+  __shared__ int4 ring_all[NW][256];
   __shared__ int progress[NW]; // per wave: rows of boundary published so far, cumulated over the wave's stripes
   constexpr int TBS = TRACE ? 64 * TBW : 1;
   __shared__ unsigned tbstage_all[NW][TRACE ? 4 : 1][TBS]; // the decisions of the current tile (4 steps), per wave
@@ -130,7 +132,6 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   const int n_stripes = (lb + W - 1) / W;
   const int steps = la + 63;
   const int tiles = (steps + 3) / 4;
-  const int la16 = la * 16;
   int result = 0;
   if(la == 0 || lb == 0) { // one profile empty: a single gap run
     int n = la + lb;
@@ -179,6 +180,7 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         // (nGap, 1) sits next to x, so that the int8 path reads 8 bytes per row
         const int4 v = r < la ? dp_expand_row<DOT4>(A[r]) : make_int4(0, 0, 0, 0);
         ring[r & 127] = v;
+        ring[(r & 127) + 128] = v;
         if(NW > 1 && s > 0) {
           // rows [t0, t0+63] of the left stripe's boundary must have been published by its wave
           const int need = ((s - 1) / team) * la + min(t0 + 64, la);
@@ -244,8 +246,11 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       const int t1 = min(t0 + 64, steps);
-      int ii16 = (t0 - lane) * 16; // 16 x this lane's row of A (0-based): the byte offset of the row in the LDS ring
-      for(int t = t0; t < t1; ++t, ii16 += 16) {
+      int ii16 = (t0 - lane) * 16; // 16 x this lane's row of A (0-based)
+      // where this lane's row of step t0 lies in the doubled ring: place (rbase & 127) + (row - rbase) with rbase = t0 - 64, the oldest
+      // row the block can read: between 1 and 191 for the rows of the block
+      int raddr = (((t0 - 64) & 127) + 64 - lane) * 16;
+      for(int t = t0; t < t1; ++t, ii16 += 16, raddr += 16) {
       // what the column left of the stripe hands to lane 0 for row t
       int b_ho, b_e;
       if(NW == 1 && s == 0) {
@@ -264,8 +269,12 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
                    : "+v"(e)
                    : "s"(b_e));
       const int tq = t & 3;
-      if((unsigned)ii16 < (unsigned)la16) {
-        const int4 a = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(ring) + (ii16 & 0x7f0));
+      // the lanes that are on a row of A at this step, 0 <= t - lane < la, are lanes max(0, t - la + 1) .. min(63, t): the mask is built
+      // on the scalar unit and becomes EXEC as it is (no per-lane compare: v_cmp is a half-rate VALU instruction, once a step)
+      const int lane_lo = max(0, t - la + 1), lane_hi = min(63, t);
+      const unsigned long long on_a_row = (~0ull >> (63 - (lane_hi - lane_lo))) << lane_lo;
+      if(__builtin_amdgcn_inverse_ballot_w64(on_a_row)) {
+        const int4 a = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(ring) + raddr);
         unsigned accw[TBW];
 #pragma unroll
         for(int k = 0; k < TBW; ++k) {
