@@ -13,8 +13,8 @@
 //     values a row hands to the next lane (H-gap_open and E of the lane's last column) move with one
 //     v_mov_b32_dpp wave_shr:1 each;
 //   * A's packed columns are loaded 64 at a time (one coalesced 512-byte load per 64 steps), expanded to
-//     int8/int16 lanes and staged in a 128-row LDS ring; each lane reads its row with one ds_read_b64 (b96 with
-//     int16 weights);
+//     int8/int16 lanes and staged in a 128-row LDS ring (every row at two places 128 apart, so that a block's reads are
+//     consecutive); each lane reads its row with one ds_read_b64 (b96 with int16 weights);
 //   * the column score is sum-of-pairs = v_dot4_i32_i8 + v_dot2_i32_i16 (or 3 x v_dot2_i32_i16) accumulating onto
 //     the diagonal (the last half lane of the gap-row dot carries gap_open so that the stored H-gap_open needs no
 //     correction);
