@@ -167,6 +167,12 @@ typedef struct pm_workload pm_workload_t;
 int pm_workload_load(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                      pm_workload_t **out);
 int pm_workload_tables(pm_workload_t *w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units);
+/* A job over a loaded workload whose unit list is made ON THE DEVICE (the loops of _translate_delta, m_translate.cc:666-707: per
+ * entry a binary search and an overlap scan in each side's sorted rows, a scan over the per-entry counts, one thread per unit):
+ * the same list, in the same order, as pm_workload_tables hands out -- which is what the file-level entries below run on.
+ * pm_job_units reports the job's unit count and copies the list out (any pointer may be NULL). */
+int pm_job_create_from_workload(pm_workload_t *w, int device, pm_job_t **out);
+int pm_job_units(pm_job_t *job, int64_t *n_units, int32_t *delta, int32_t *left, int32_t *right);
 /* side 0 = left, 1 = right; pointers stay valid until pm_workload_destroy */
 int pm_workload_row_name(pm_workload_t *w, int side, int64_t row, const char **major_name, const char **seq_name);
 void pm_workload_destroy(pm_workload_t *w);

@@ -53,7 +53,7 @@ EXPORTS = [
     "pm_last_error", "pm_release_caches", "pm_device_count", "pm_device_info",
     "pm_job_create", "pm_job_text", "pm_job_text_fetch", "pm_job_text_fetch_range", "pm_job_run", "pm_job_run_profiled", "pm_job_sizes", "pm_job_fetch", "pm_job_algorithmic_bytes", "pm_job_kernel_bytes", "pm_job_coordinate_bits", "pm_job_destroy",
     "pm_rows_profile_idx_of_seq_idx_batch", "pm_rows_seq_idx_of_profile_idx_batch",
-    "pm_workload_load", "pm_workload_tables", "pm_workload_row_name", "pm_workload_destroy",
+    "pm_workload_load", "pm_workload_tables", "pm_workload_row_name", "pm_workload_destroy", "pm_job_create_from_workload", "pm_job_units",
     "pm_translate_files", "pm_sort_delta", "pm_maf_analyzer", "pm_profiles_make", "pm_stage_files", "pm_untranslate",
     "pm_dp_batch_create", "pm_dp_batch_run", "pm_dp_batch_run_profiled", "pm_dp_batch_fetch", "pm_dp_batch_info", "pm_dp_batch_chunks", "pm_dp_batch_variant", "pm_dp_batch_path_mode", "pm_dp_batch_destroy",
     "pm_dp_host_alloc", "pm_dp_host_free", "pm_dp_stream_create", "pm_dp_stream_align", "pm_dp_stream_align_text", "pm_dp_stream_destroy",
@@ -100,6 +100,8 @@ def lib() -> C.CDLL:
         l.pm_workload_tables.argtypes = [C.c_void_p, C.POINTER(PmRows), C.POINTER(PmRows), C.POINTER(PmDeltas), C.POINTER(PmUnits)]
         l.pm_workload_row_name.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
         l.pm_workload_destroy.argtypes = [C.c_void_p]
+        l.pm_job_create_from_workload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        l.pm_job_units.argtypes = [C.c_void_p, _i64p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_workload_destroy.restype = None
         l.pm_translate_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_int]
         l.pm_sort_delta.argtypes = [C.c_char_p, C.c_char_p, C.c_int]

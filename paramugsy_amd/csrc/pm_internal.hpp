@@ -141,4 +141,16 @@ struct PooledBuf {
 void text_staging_trim();
 void dp_batch_cache_trim();
 
+// What the device needs to list a job's work units itself (translate_job.hip): per side (0 left, 1 right) the rows of every sequence
+// sorted by forward start, and per delta entry the index of its sequence on that side (-1: the side has no such sequence).
+struct EnumInput {
+  int64_t n_seq[2];
+  const int64_t *seq_off[2]; // [n_seq + 1]
+  const int32_t *seq_rows[2];
+  const int32_t *entry_seq[2]; // [entries]
+};
+int job_create_enumerating(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const EnumInput *en, int device,
+                           pm_job_t **out);
+int job_unit_at(pm_job_t *job, int64_t unit, int32_t out[3]); // a unit's delta entry, left row, right row
+
 } // namespace pm

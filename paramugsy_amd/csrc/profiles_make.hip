@@ -504,8 +504,8 @@ extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const 
     return fail(rc_r, msg_r);
   }
   lap("two makes beside the delta files");
-  index_and_enumerate(w);
-  lap("rows indexed, units listed");
+  index_sides(w); // the job lists the units on the device
+  lap("rows indexed");
   FILE *f = fopen(out_delta, "wb");
   if(!f) {
     return fail(PM_E_IO, std::string("cannot open ") + out_delta);

@@ -556,6 +556,55 @@ void enumerate_units(const Side &left, const Side &right, const DeltaTable &t, s
   });
 }
 
+// The same list made on the device (translate_job.hip: enum_count_kernel / enum_fill_kernel): what it needs from here is the row
+// index flattened (sequences in the index's order, each one's rows as sorted there) and every entry's sequence on either side.
+// Entries under one header share their names, so the look-up is repeated only when the name changes.
+struct EnumTables {
+  std::vector<int64_t> seq_off[2];
+  std::vector<int32_t> seq_rows[2], entry_seq[2];
+  EnumInput view() const {
+    EnumInput en;
+    for(int sd = 0; sd < 2; ++sd) {
+      en.n_seq[sd] = (int64_t)seq_off[sd].size() - 1;
+      en.seq_off[sd] = seq_off[sd].data();
+      en.seq_rows[sd] = seq_rows[sd].data();
+      en.entry_seq[sd] = entry_seq[sd].data();
+    }
+    return en;
+  }
+};
+static void build_enum_tables(const Side &left, const Side &right, const DeltaTable &t, EnumTables &et) {
+  const Side *side[2] = {&left, &right};
+  const std::vector<std::string> *name[2] = {&t.ref_name, &t.qry_name};
+  const size_t n = t.ref_start.size();
+  auto one = [&](int sd) {
+    std::map<std::string, int> id;
+    et.seq_off[sd].assign(1, 0);
+    et.seq_rows[sd].clear();
+    et.seq_rows[sd].reserve(side[sd]->start.size());
+    for(std::map<std::string, std::vector<int> >::const_iterator it = side[sd]->by_seq.begin(); it != side[sd]->by_seq.end(); ++it) {
+      id[it->first] = (int)et.seq_off[sd].size() - 1;
+      et.seq_rows[sd].insert(et.seq_rows[sd].end(), it->second.begin(), it->second.end());
+      et.seq_off[sd].push_back((int64_t)et.seq_rows[sd].size());
+    }
+    et.entry_seq[sd].resize(n);
+    const std::string *last = nullptr;
+    int last_id = -1;
+    for(size_t d = 0; d < n; ++d) {
+      const std::string &nm = (*name[sd])[d];
+      if(!last || nm != *last) {
+        std::map<std::string, int>::const_iterator f = id.find(nm);
+        last_id = f == id.end() ? -1 : f->second;
+        last = &nm;
+      }
+      et.entry_seq[sd][d] = last_id;
+    }
+  };
+  std::thread other(one, 1);
+  one(0);
+  other.join();
+}
+
 // ------------------------------------------------------------------ text out
 
 // A host array whose elements are left uninitialised (plain malloc), for buffers a copy is about to fill.
@@ -640,7 +689,8 @@ static double wall_now() {
   return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
-int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w) {
+int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w,
+                  bool list_units) {
   const bool timing = getenv("PM_TIMING") != nullptr;
   const double t0 = wall_now();
   PM_TRY(load_side(left_dir, w.left));
@@ -648,9 +698,15 @@ int load_workload(const std::string &left_dir, const std::string &right_dir, con
   const double t1 = wall_now();
   parse_deltas(delta_paths, w);
   const double t2 = wall_now();
-  index_and_enumerate(w);
+  if(list_units) {
+    index_and_enumerate(w);
+  }
+  else {
+    index_sides(w); // the units are listed on the device, by the job
+  }
   if(timing) {
-    fprintf(stderr, "[pm]   sides: %.4f s; delta files: %.4f s; index + enumerate: %.4f s\n", t1 - t0, t2 - t1, wall_now() - t2);
+    fprintf(stderr, "[pm]   sides: %.4f s; delta files: %.4f s; %s: %.4f s\n", t1 - t0, t2 - t1, list_units ? "index + enumerate" : "index",
+            wall_now() - t2);
   }
   return PM_OK;
 }
@@ -659,7 +715,7 @@ int load_workload(const std::string &left_dir, const std::string &right_dir, con
 // memory by the make stage: pm_stage_files).
 int load_deltas(const std::vector<std::string> &delta_paths, Workload &w) {
   parse_deltas(delta_paths, w);
-  index_and_enumerate(w);
+  index_sides(w);
   return PM_OK;
 }
 
@@ -763,10 +819,18 @@ void parse_deltas(const std::vector<std::string> &delta_paths, Workload &w) {
 
 // The per-sequence row index of both sides and the unit list of every parsed entry (m_translate.cc:666-707), in entry order.
 void index_and_enumerate(Workload &w) {
-  build_side_index(w.left);
-  build_side_index(w.right);
-  w.units = UnitList();
+  index_sides(w);
   enumerate_units(w.left, w.right, w.table, 0, w.units);
+  w.units_listed = true;
+}
+
+// Only the index: the job lists the units itself (run_workload with w.units_listed false).
+void index_sides(Workload &w) {
+  std::thread other([&]() { build_side_index(w.right); });
+  build_side_index(w.left);
+  other.join();
+  w.units = UnitList();
+  w.units_listed = false;
 }
 
 void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units) {
@@ -820,7 +884,7 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
     init_s = wall_now() - i0;
   });
   Workload w;
-  int load_rc = load_workload(left_dir, right_dir, delta_paths, w);
+  int load_rc = load_workload(left_dir, right_dir, delta_paths, w, false);
   std::string load_msg = load_rc ? pm_last_error() : "";
   init.join();
   if(init_rc) {
@@ -831,7 +895,7 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   }
   double t1 = now();
   if(timing) {
-    fprintf(stderr, "[pm] parse + enumerate: %.3f s (%zu units); HIP runtime start-up beside it: %.3f s\n", t1 - t0, w.units.delta.size(), init_s);
+    fprintf(stderr, "[pm] parse + index: %.3f s; HIP runtime start-up beside it: %.3f s\n", t1 - t0, init_s);
   }
   return run_workload(w, out, device);
 }
@@ -1011,10 +1075,10 @@ int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool tim
 
 // The device part of a translate job and the text of its output: upload + prepare + sizing, one pass, fetch, format + write.
 int run_workload(Workload &w, FILE *out, int device) {
-  return run_tables(w.left, w.right, w.table, w.units, w.parse_rc, w.parse_msg, OutSink(out), device);
+  return run_tables(w.left, w.right, w.table, w.units_listed ? &w.units : nullptr, w.parse_rc, w.parse_msg, OutSink(out), device);
 }
 
-int run_tables(const Side &left, const Side &right, const DeltaTable &table, const UnitList &units, int parse_rc, const std::string &parse_msg,
+int run_tables(const Side &left, const Side &right, const DeltaTable &table, const UnitList *units, int parse_rc, const std::string &parse_msg,
                OutSink out, int device) {
   const bool timing = getenv("PM_TIMING") != nullptr;
   auto now = []() {
@@ -1023,16 +1087,32 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
     return ts.tv_sec + ts.tv_nsec * 1e-9;
   };
   double t1 = now();
-  if(!units.delta.empty()) {
+  pm_job_t *job = nullptr;
+  if(units ? !units->delta.empty() : !table.ref_start.empty()) {
     pm_rows_t lv = rows_view(left), rv = rows_view(right);
     pm_deltas_t dv = deltas_view(table);
-    pm_units_t uv;
-    uv.n = (int64_t)units.delta.size();
-    uv.delta = units.delta.data();
-    uv.left = units.left.data();
-    uv.right = units.right.data();
-    pm_job_t *job = nullptr;
-    PM_TRY(pm_job_create(&lv, &rv, &dv, &uv, device, &job));
+    if(units) {
+      pm_units_t uv;
+      uv.n = (int64_t)units->delta.size();
+      uv.delta = units->delta.data();
+      uv.left = units->left.data();
+      uv.right = units->right.data();
+      PM_TRY(pm_job_create(&lv, &rv, &dv, &uv, device, &job));
+    }
+    else { // the unit list is made on the device from the sides' row index (left.by_seq, right.by_seq)
+      EnumTables et;
+      build_enum_tables(left, right, table, et);
+      const EnumInput en = et.view();
+      PM_TRY(job_create_enumerating(&lv, &rv, &dv, &en, device, &job));
+      int64_t n_units = 0;
+      (void)pm_job_units(job, &n_units, nullptr, nullptr, nullptr);
+      if(n_units == 0) {
+        pm_job_destroy(job);
+        job = nullptr;
+      }
+    }
+  }
+  if(job) {
     double t2 = now();
     int rc = pm_job_run(job, nullptr);
     int64_t ne = 0, no = 0;
@@ -1053,6 +1133,10 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
     int32_t failed_status = 0;
     if(!rc) {
       rc = pm_job_text(job, ln.data(), rn.data(), &n_bytes, &failed, &failed_status);
+    }
+    int32_t failed_at[3] = {-1, -1, -1}; // the failing unit's entry and rows, for the message
+    if(!rc && failed >= 0) {
+      rc = job_unit_at(job, failed, failed_at);
     }
     double t4 = now();
     // the job's forty device buffers are freed (milliseconds of hipFree) while the last pieces of the text are written
@@ -1080,7 +1164,7 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
     if(failed >= 0) { // the reference died inside this unit: what it had printed is on the stream
       char msg[160];
       snprintf(msg, sizeof msg, "work unit %lld (delta entry %d, left row %d, right row %d) failed with status %d", (long long)failed,
-               units.delta[(size_t)failed], units.left[(size_t)failed], units.right[(size_t)failed], (int)failed_status);
+               failed_at[0], failed_at[1], failed_at[2], (int)failed_status);
       return fail(failed_status == PM_ST_MALFORMED_INPUT ? PM_E_MALFORMED : PM_E_UNIT, msg);
     }
   }
@@ -1197,8 +1281,7 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
         partition((int64_t)delta_paths.size(), n_devices, w, lo, hi);
         Workload mine; // its sides stay empty: the shared ones are used
         parse_deltas(std::vector<std::string>(delta_paths.begin() + lo, delta_paths.begin() + hi), mine);
-        enumerate_units(left, right, mine.table, 0, mine.units);
-        return run_tables(left, right, mine.table, mine.units, mine.parse_rc, mine.parse_msg, OutSink(&text[(size_t)w]), device);
+        return run_tables(left, right, mine.table, nullptr, mine.parse_rc, mine.parse_msg, OutSink(&text[(size_t)w]), device);
       },
       &rcs);
   std::string msg = rc ? pm_last_error() : "";
@@ -1339,7 +1422,7 @@ extern "C" int pm_workload_load(const char *left_dir, const char *right_dir, con
     paths.push_back(delta_paths[k]);
   }
   pm_workload *h = new pm_workload();
-  int rc = pm::load_workload(left_dir, right_dir, paths, h->w);
+  int rc = pm::load_workload(left_dir, right_dir, paths, h->w, true);
   if(rc) {
     delete h;
     return rc;
@@ -1375,6 +1458,21 @@ extern "C" int pm_workload_row_name(pm_workload_t *h, int side, int64_t row, con
     *seq_name = s.seq_name[(size_t)row].c_str();
   }
   return PM_OK;
+}
+
+extern "C" int pm_job_create_from_workload(pm_workload_t *h, int device, pm_job_t **out) {
+  return pm::guarded("pm_job_create_from_workload", [&]() -> int {
+    if(!h || !out) {
+      return pm::fail(PM_E_INVALID, "pm_job_create_from_workload: null argument");
+    }
+    *out = nullptr;
+    pm_rows_t lv = pm::rows_view(h->w.left), rv = pm::rows_view(h->w.right);
+    pm_deltas_t dv = pm::deltas_view(h->w.table);
+    pm::EnumTables et;
+    pm::build_enum_tables(h->w.left, h->w.right, h->w.table, et);
+    const pm::EnumInput en = et.view();
+    return pm::job_create_enumerating(&lv, &rv, &dv, &en, device, out);
+  });
 }
 
 extern "C" void pm_workload_destroy(pm_workload_t *h) { delete h; }

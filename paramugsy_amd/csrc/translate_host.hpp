@@ -39,6 +39,7 @@ struct Workload {
   Side left, right;
   DeltaTable table;
   UnitList units;
+  bool units_listed = false; // false: the job lists them on the device (index_sides), units stays empty
   int parse_rc = 0;
   std::string parse_msg;
 };
@@ -69,13 +70,16 @@ int write_side_soa(const std::string &dir, const Side &side, long long profiles_
 int load_deltas(const std::vector<std::string> &delta_paths, Workload &w);
 void parse_deltas(const std::vector<std::string> &delta_paths, Workload &w);
 void index_and_enumerate(Workload &w);
+void index_sides(Workload &w);
 int run_workload(Workload &w, FILE *out, int device);
 // The device part of a translate job over tables that are in place (the two sides may be shared, read-only, by several callers):
-// upload + prepare + sizing, one pass, fetch, format.  parse_rc / parse_msg: a delta-file parse failure to report after the
+// upload + prepare + sizing, one pass, fetch, format.  units: the unit list, or null for the job to list the units on the device from
+// the sides' row index (build_side_index must have run on both).  parse_rc / parse_msg: a delta-file parse failure to report after the
 // output of the entries read before it.
-int run_tables(const Side &left, const Side &right, const DeltaTable &table, const UnitList &units, int parse_rc, const std::string &parse_msg,
+int run_tables(const Side &left, const Side &right, const DeltaTable &table, const UnitList *units, int parse_rc, const std::string &parse_msg,
                OutSink out, int device);
-int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w);
+int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w,
+                  bool list_units = true);
 void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units);
 // Bytes in device memory to a sink through pinned staging pieces, the writing beside the copying; `copied` runs once the last byte
 // has left the device.  The calling thread's current device must be the buffer's.

@@ -347,6 +347,99 @@ int warm_translate_kernels() {
   return PM_OK;
 }
 
+// ------------------------------------------------------------------ the unit list, on the device
+// The loops of _translate_delta (m_translate.cc:666-707): for every delta entry, the rows of its reference sequence on the left side
+// and of its query sequence on the right side that overlap it, every (left, right) pair of them a work unit, in entry order, left
+// rows outer.  Per side the host hands over the rows of every sequence sorted by forward start (_profile_map_of_dir, :188-207) as
+// one array with offsets per sequence; the first candidate is std::lower_bound with "the row ends before the entry starts"
+// (:175-178,682-695) -- restated here as the SAME halving search libstdc++ runs, so that the result is the reference's whatever the
+// rows' order makes of the predicate -- and the candidates run on while they overlap the entry (m_range.hh:80-94).
+struct EnumSideD {
+  const i64 *seq_off;  // [sequences + 1] into seq_rows
+  const int *seq_rows; // the side's rows, sequence by sequence, sorted by forward start
+  const i64 *start, *end; // the rows' p_range (as uploaded)
+};
+
+__device__ __forceinline__ void enum_span(const EnumSideD &sd, int seq, i64 es, i64 ee, int &first, int &count) {
+  first = 0;
+  count = 0;
+  if(seq < 0) {
+    return;
+  }
+  const int *rows = sd.seq_rows + sd.seq_off[seq];
+  const i64 n = sd.seq_off[seq + 1] - sd.seq_off[seq];
+  const i64 key = es < ee ? es : ee;
+  i64 lo = 0, len = n; // std::lower_bound(rows, rows + n, key, [](row, v) { return max(start, end) < v; })
+  while(len > 0) {
+    const i64 half = len >> 1;
+    const int r = rows[lo + half];
+    const i64 hi_end = sd.start[r] > sd.end[r] ? sd.start[r] : sd.end[r];
+    if(hi_end < key) {
+      lo = lo + half + 1;
+      len = len - half - 1;
+    }
+    else {
+      len = half;
+    }
+  }
+  const i64 e_lo = key, e_hi = es < ee ? ee : es;
+  i64 k = lo;
+  for(; k < n; ++k) { // while the row overlaps the entry: max of the starts <= min of the ends
+    const int r = rows[k];
+    const i64 r_lo = sd.start[r] < sd.end[r] ? sd.start[r] : sd.end[r], r_hi = sd.start[r] < sd.end[r] ? sd.end[r] : sd.start[r];
+    const i64 s = r_lo > e_lo ? r_lo : e_lo, e = r_hi < e_hi ? r_hi : e_hi;
+    if(e - s < 0) {
+      break;
+    }
+  }
+  first = (int)lo;
+  count = (int)(k - lo);
+}
+
+__global__ void enum_count_kernel(i64 n_entries, EnumSideD left, EnumSideD right, const int *ref_seq, const int *qry_seq, const i64 *ref_s,
+                                  const i64 *ref_e, const i64 *qry_s, const i64 *qry_e, int4 *span, i64 *count) {
+  const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(d > n_entries) {
+    return;
+  }
+  if(d == n_entries) {
+    count[d] = 0;
+    return;
+  }
+  int l0, nl, r0, nr;
+  enum_span(left, ref_seq[d], ref_s[d], ref_e[d], l0, nl);
+  enum_span(right, qry_seq[d], qry_s[d], qry_e[d], r0, nr);
+  if(ref_seq[d] < 0 || qry_seq[d] < 0) {
+    nl = nr = 0;
+  }
+  span[d] = make_int4(l0, nl, r0, nr);
+  count[d] = (i64)nl * nr;
+}
+
+__global__ void enum_fill_kernel(i64 n_units, i64 n_entries, EnumSideD left, EnumSideD right, const int *ref_seq, const int *qry_seq,
+                                 const int4 *span, const i64 *unit_off, int *u_delta, int *u_left, int *u_right) {
+  const i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(u >= n_units) {
+    return;
+  }
+  i64 lo = 0, hi = n_entries; // the entry that owns unit u: the last d with unit_off[d] <= u
+  while(hi - lo > 1) {
+    const i64 mid = (lo + hi) >> 1;
+    if(unit_off[mid] <= u) {
+      lo = mid;
+    }
+    else {
+      hi = mid;
+    }
+  }
+  const int4 sp = span[lo];
+  const i64 local = u - unit_off[lo];
+  const i64 l = local / sp.w, r = local % sp.w; // left rows outer, right rows inner
+  u_delta[u] = (int)lo;
+  u_left[u] = left.seq_rows[left.seq_off[ref_seq[lo]] + sp.x + l];
+  u_right[u] = right.seq_rows[right.seq_off[qry_seq[lo]] + sp.z + r];
+}
+
 // ------------------------------------------------------------------ the writer's text, on the device
 // M_delta_stream_writer::write (m_delta_stream_writer.hh:55-82) for every entry of a job's result, in unit order: a `>` header
 // line when the (left major name, right major name) pair differs from the pair of the last entry printed, the entry line
@@ -834,12 +927,19 @@ const char *job_text_device(pm_job_t *j) { return (const char *)j->t_text.p; }
 
 extern "C" {
 
-int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units, int device,
-                  pm_job_t **out) {
+} // extern "C"
+
+// pm_job_create, with the unit list either given (units) or made on the device from the sides' per-sequence row lists (en).
+static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+                           const pm::EnumInput *en, int device, pm_job_t **out) {
   if(!out) {
     return fail(PM_E_INVALID, "pm_job_create: null out");
   }
   *out = nullptr;
+  const pm_units_t no_units = {0, nullptr, nullptr, nullptr};
+  if(en) {
+    units = &no_units;
+  }
   if(!units || units->n < 0 || (units->n > 0 && (!units->delta || !units->left || !units->right))) {
     return fail(PM_E_INVALID, "pm_job_create: bad units");
   }
@@ -896,9 +996,61 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   JTRY(upload_deltas(deltas, j->deltas, stream, (unsigned long long *)j->maxabs.p));
   lap("rows + deltas up, prepared");
   i64 U = j->n_units = units->n;
-  JTRY(j->u_delta.upload(units->delta, (size_t)U * 4, stream));
-  JTRY(j->u_left.upload(units->left, (size_t)U * 4, stream));
-  JTRY(j->u_right.upload(units->right, (size_t)U * 4, stream));
+  if(en) {
+    // the unit list on the device: spans and counts per entry, a scan, then one thread per unit
+    const i64 D = deltas->n;
+    DevBuf d_seq_off[2], d_seq_rows[2], d_eseq[2], d_span, d_count, d_uoff, d_tmp;
+    for(int sd = 0; sd < 2; ++sd) {
+      JTRY(d_seq_off[sd].upload(en->seq_off[sd], (size_t)(en->n_seq[sd] + 1) * 8, stream));
+      JTRY(d_seq_rows[sd].upload(en->seq_rows[sd], (size_t)en->seq_off[sd][en->n_seq[sd]] * 4, stream));
+      JTRY(d_eseq[sd].upload(en->entry_seq[sd], (size_t)D * 4, stream));
+    }
+    JTRY(d_span.alloc((size_t)(D + 1) * 16));
+    JTRY(d_count.alloc((size_t)(D + 1) * 8));
+    JTRY(d_uoff.alloc((size_t)(D + 1) * 8));
+    EnumSideD L = {(const i64 *)d_seq_off[0].p, (const int *)d_seq_rows[0].p, (const i64 *)j->left.raw_s.p, (const i64 *)j->left.raw_e.p};
+    EnumSideD R = {(const i64 *)d_seq_off[1].p, (const int *)d_seq_rows[1].p, (const i64 *)j->right.raw_s.p, (const i64 *)j->right.raw_e.p};
+    enum_count_kernel<<<(unsigned)((D + 256) / 256), 256, 0, stream>>>(D, L, R, (const int *)d_eseq[0].p, (const int *)d_eseq[1].p,
+                                                                       (const i64 *)j->deltas.raw[0].p, (const i64 *)j->deltas.raw[1].p,
+                                                                       (const i64 *)j->deltas.raw[2].p, (const i64 *)j->deltas.raw[3].p,
+                                                                       (int4 *)d_span.p, (i64 *)d_count.p);
+    size_t tmp_b = 0;
+    if(hipGetLastError() != hipSuccess ||
+       rocprim::exclusive_scan(nullptr, tmp_b, (i64 *)d_count.p, (i64 *)d_uoff.p, (i64)0, (size_t)(D + 1), rocprim::plus<i64>(), stream) != hipSuccess) {
+      pm_job_destroy(j);
+      return fail(PM_E_HIP, "unit enumeration failed");
+    }
+    JTRY(d_tmp.alloc(tmp_b ? tmp_b : 8));
+    i64 total = 0;
+    if(rocprim::exclusive_scan(d_tmp.p, tmp_b, (i64 *)d_count.p, (i64 *)d_uoff.p, (i64)0, (size_t)(D + 1), rocprim::plus<i64>(), stream) != hipSuccess ||
+       hipMemcpyAsync(&total, (i64 *)d_uoff.p + D, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+      pm_job_destroy(j);
+      return fail(PM_E_HIP, "unit enumeration failed");
+    }
+    if(total < 0 || total >= ((i64)1 << 31)) {
+      pm_job_destroy(j);
+      return fail(PM_E_INVALID, "pm_job_create: more than 2^31 work units in one job");
+    }
+    U = j->n_units = total;
+    JTRY(j->u_delta.alloc((size_t)U * 4));
+    JTRY(j->u_left.alloc((size_t)U * 4));
+    JTRY(j->u_right.alloc((size_t)U * 4));
+    if(U > 0) {
+      enum_fill_kernel<<<(unsigned)((U + 255) / 256), 256, 0, stream>>>(U, D, L, R, (const int *)d_eseq[0].p, (const int *)d_eseq[1].p,
+                                                                        (const int4 *)d_span.p, (const i64 *)d_uoff.p, (int *)j->u_delta.p,
+                                                                        (int *)j->u_left.p, (int *)j->u_right.p);
+      if(hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { // the scratch tables die with this scope
+        pm_job_destroy(j);
+        return fail(PM_E_HIP, "unit enumeration failed");
+      }
+    }
+    lap("units listed on the device");
+  }
+  else {
+    JTRY(j->u_delta.upload(units->delta, (size_t)U * 4, stream));
+    JTRY(j->u_left.upload(units->left, (size_t)U * 4, stream));
+    JTRY(j->u_right.upload(units->right, (size_t)U * 4, stream));
+  }
   JTRY(j->status.alloc((size_t)U * 4));
   JTRY(j->cnt_ent.alloc((size_t)(U + 1) * 8));
   JTRY(j->cnt_off.alloc((size_t)(U + 1) * 8));
@@ -1046,6 +1198,54 @@ int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas
   lap("states + output buffers");
 #undef JTRY
   *out = j;
+  return PM_OK;
+}
+
+namespace pm {
+int job_create_enumerating(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const EnumInput *en, int device,
+                           pm_job_t **out) {
+  return job_create_impl(left, right, deltas, nullptr, en, device, out);
+}
+int job_unit_at(pm_job_t *j, int64_t unit, int32_t out[3]) {
+  if(!j || unit < 0 || unit >= j->n_units) {
+    return fail(PM_E_INVALID, "job_unit_at: no such unit");
+  }
+  PM_TRY(use_device(j->device));
+  PM_HIP(hipMemcpy(&out[0], (const int *)j->u_delta.p + unit, 4, hipMemcpyDeviceToHost));
+  PM_HIP(hipMemcpy(&out[1], (const int *)j->u_left.p + unit, 4, hipMemcpyDeviceToHost));
+  PM_HIP(hipMemcpy(&out[2], (const int *)j->u_right.p + unit, 4, hipMemcpyDeviceToHost));
+  return PM_OK;
+}
+} // namespace pm
+
+extern "C" {
+
+int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units, int device,
+                  pm_job_t **out) {
+  return job_create_impl(left, right, deltas, units, nullptr, device, out);
+}
+
+/* the job's unit list (made on the device when the job came from pm_job_create_from_workload) */
+int pm_job_units(pm_job_t *j, int64_t *n_units, int32_t *delta, int32_t *left, int32_t *right) {
+  if(!j) {
+    return fail(PM_E_INVALID, "pm_job_units: null job");
+  }
+  PM_TRY(use_device(j->device));
+  if(n_units) {
+    *n_units = j->n_units;
+  }
+  const size_t bytes = (size_t)j->n_units * 4;
+  if(bytes > 0) {
+    if(delta) {
+      PM_HIP(hipMemcpy(delta, j->u_delta.p, bytes, hipMemcpyDeviceToHost));
+    }
+    if(left) {
+      PM_HIP(hipMemcpy(left, j->u_left.p, bytes, hipMemcpyDeviceToHost));
+    }
+    if(right) {
+      PM_HIP(hipMemcpy(right, j->u_right.p, bytes, hipMemcpyDeviceToHost));
+    }
+  }
   return PM_OK;
 }
 

@@ -86,8 +86,10 @@ def _gapped_text(rng: np.random.Generator, columns: int, gap_rate: float, mean_g
 def gen_side(rng: np.random.Generator, genomes: Sequence[str], genome_len: int, n_blocks: int,
              mean_cols: int = 400, gap_rate: float = 0.01, mean_gap: float = 3.0,
              row_prob: float = 0.8, rev_prob: float = 0.2, edge_gap_prob: float = 0.15,
-             spacing: int = 40) -> List[Block]:
-    """A side: `n_blocks` blocks; per genome the covered intervals are disjoint and ascending."""
+             spacing: int = 40, overlap_prob: float = 0.0) -> List[Block]:
+    """A side: `n_blocks` blocks; per genome the covered intervals are disjoint and ascending -- unless overlap_prob > 0: then a
+    row starts, with that probability, somewhere inside the stretch the genome's earlier rows cover (rows that overlap, nest and
+    come out of file order once sorted by start: what the per-sequence row index and its binary search have to cope with)."""
     cursor = {g: 1 + int(rng.integers(0, spacing)) for g in genomes}
     blocks: List[Block] = []
     for _ in range(n_blocks):
@@ -99,9 +101,11 @@ def gen_side(rng: np.random.Generator, genomes: Sequence[str], genome_len: int, 
             text = _gapped_text(rng, columns, gap_rate, mean_gap, edge_gap_prob)
             size = columns - text.count(b"-")
             start = cursor[g] + int(rng.integers(0, spacing))
+            if overlap_prob > 0 and rng.random() < overlap_prob:
+                start = int(rng.integers(1, max(2, cursor[g])))
             if start + size - 1 > genome_len:
                 continue
-            cursor[g] = start + size
+            cursor[g] = max(cursor[g], start + size)
             blk.rows.append(Row(g, start, size, bool(rng.random() >= rev_prob), genome_len, text))
         if blk.rows:
             blocks.append(blk)
@@ -233,7 +237,7 @@ def make_workload(root: str, seed: int, n_left: int = 3, n_right: int = 3, genom
                   n_blocks: int = 60, n_deltas: int = 2, entries_per_delta: int = 40, **kw) -> Workload:
     """Write a complete m_translate job under `root` and return its paths."""
     rng = np.random.default_rng(seed)
-    side_kw = {k: kw[k] for k in ("mean_cols", "gap_rate", "mean_gap", "row_prob", "rev_prob", "edge_gap_prob", "spacing") if k in kw}
+    side_kw = {k: kw[k] for k in ("mean_cols", "gap_rate", "mean_gap", "row_prob", "rev_prob", "edge_gap_prob", "spacing", "overlap_prob") if k in kw}
     delta_kw = {k: kw[k] for k in ("mean_len", "indel_rate", "mean_indel", "adjacent_prob", "group") if k in kw}
     if "delta_rev_prob" in kw:
         delta_kw["rev_prob"] = kw["delta_rev_prob"]

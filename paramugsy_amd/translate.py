@@ -105,6 +105,25 @@ class TranslateJob:
         self._h = h
         self.n_units = tables.n_units
 
+    @classmethod
+    def from_workload(cls, workload: "Workload", device: int = 0) -> "TranslateJob":
+        """The job of a loaded workload with its unit list made on the device (pm_job_create_from_workload)."""
+        h = C.c_void_p()
+        capi.check(capi.lib().pm_job_create_from_workload(workload._h, device, C.byref(h)))
+        job = cls.__new__(cls)
+        job._h = h
+        n = C.c_int64()
+        capi.check(capi.lib().pm_job_units(h, C.byref(n), None, None, None))
+        job.n_units = n.value
+        return job
+
+    def units(self) -> Dict[str, np.ndarray]:
+        """The job's unit list as it stands on the device."""
+        out = {k: np.empty(self.n_units, np.int32) for k in ("delta", "left", "right")}
+        n = C.c_int64()
+        capi.check(capi.lib().pm_job_units(self._h, C.byref(n), out["delta"].ctypes.data, out["left"].ctypes.data, out["right"].ctypes.data))
+        return out
+
     def run(self, stream: int = 0) -> None:
         """One pass of the hot path (count, scan, emit), asynchronous on `stream` (a hipStream_t value)."""
         capi.check(capi.lib().pm_job_run(self._h, C.c_void_p(stream)))

@@ -209,6 +209,50 @@ def test_gaps_out_of_the_writers_order_are_merged_as_the_writer_does(seed, mode,
         job.close()
 
 
+@pytest.mark.parametrize("mode,overlap", [(m, 0.0) for m in sorted(MODES)] + [("typical", 0.3), ("tiny_blocks", 0.8), ("reverse", 0.05)])
+def test_unit_list_made_on_the_device_equals_the_hosts_loops(mode, overlap, oracle_build, tmp_path):
+    """pm_job_create_from_workload lists the units on the device (what every file-level entry runs on): the same triples in the same
+    order as the host's restatement of the loops at m_translate.cc:666-707, also when a genome's rows overlap and nest (their ends are
+    then out of order under the index's sort by start, and the binary search has to land where libstdc++'s lands) -- and the job run
+    over them equals the oracle."""
+    import pyoracle
+    kw = dict(MODES[mode])
+    if overlap:
+        kw["overlap_prob"] = overlap
+    w = synth.make_workload(str(tmp_path / "job"), 5150 + len(mode), **kw)
+    wl = Workload.load(w.left_dir, w.right_dir, w.delta_paths)
+    t = wl.tables()
+    job = TranslateJob.from_workload(wl)
+    assert job.n_units == t.n_units > 10
+    got = job.units()
+    for k in ("delta", "left", "right"):
+        assert np.array_equal(got[k], t.units[k]), k
+    if overlap:  # some entry does see several rows of one genome
+        assert (np.bincount(t.units["delta"]) > 1).any()
+    job.run()
+    assert_same_result(job.fetch(), pyoracle.translate_units(t.left, t.right, t.deltas, t.units))
+    job.close()
+
+
+def test_unit_list_on_the_device_with_sequences_a_side_does_not_have(tmp_path):
+    """Entries whose reference or query sequence has no rows on its side yield no units (m_translate.cc:676-681)."""
+    w = synth.make_workload(str(tmp_path / "job"), 99, n_left=3, n_right=3, row_prob=1.0)
+    # a delta file naming genomes the sides do not hold, between two that they do
+    text = open(w.delta_paths[0]).read()
+    stranger = text.replace(">L0.chr ", ">nobody.chr ").replace(" R1.chr ", " nothing.chr ")
+    extra = str(tmp_path / "job" / "strangers.delta")
+    open(extra, "w").write(stranger)
+    paths = [w.delta_paths[0], extra] + w.delta_paths[1:]
+    wl = Workload.load(w.left_dir, w.right_dir, paths)
+    t = wl.tables()
+    job = TranslateJob.from_workload(wl)
+    got = job.units()
+    assert job.n_units == t.n_units > 0
+    for k in ("delta", "left", "right"):
+        assert np.array_equal(got[k], t.units[k]), k
+    job.close()
+
+
 def test_malformed_gap_lists_are_refused_not_miscomputed(tmp_path):
     w = synth.make_workload(str(tmp_path / "job"), 77)
     t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()

@@ -54,6 +54,9 @@ while time.time() < t_end:
                       mean_len=int(rng.choice([30, 300, 3000])), indel_rate=float(rng.choice([0.001, 0.01, 0.08])), mean_indel=float(rng.choice([1.5, 4.0, 15.0])),
                       adjacent_prob=float(rng.choice([0.0, 0.1, 0.4])), delta_rev_prob=float(rng.choice([0.0, 0.3, 1.0])), group=int(rng.integers(1, 5)))
             mode = "wild"
+        if rng.random() < 0.25:  # rows of a genome that overlap and nest (the row index's binary search then meets ends out of order)
+            kw["overlap_prob"] = float(rng.choice([0.05, 0.3, 0.8]))
+            mode += " overlapping rows"
         w = synth.make_workload(os.path.join(d, "job"), seed, **kw)
         rc = subprocess.run([os.path.join(REF, "m_translate"), w.left_dir, w.right_dir, w.list_path, a], capture_output=True).returncode
         multi = int(rng.integers(2, 5)) if rng.random() < 0.3 else 0  # a third of the jobs over a device list (workers share the GPU)

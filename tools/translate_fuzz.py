@@ -2,7 +2,7 @@
 """Differential fuzz of the translate path on the GPU box: random workloads (the parameter sets of tests/test_translate_gpu.py with
 random perturbations, half of them with the tables made inconsistent so that units fail) through pm_job_* against
 oracle/pm_oracle.cc (which tests/test_oracle_vs_ref.py and the goldens pin to the upstream binary): status per unit, entries and
-offsets must be equal.  python tools/translate_fuzz.py [seconds] [first seed]"""
+offsets must be equal; and the unit list the device makes for the loaded files (pm_job_create_from_workload) against the host's.  python tools/translate_fuzz.py [seconds] [first seed]"""
 import os
 import shutil
 import sys
@@ -36,8 +36,19 @@ while time.time() < t_end:
         kw["entries_per_delta"] = int(rng.integers(5, 200))
     d = os.path.join(tmp, "job")
     shutil.rmtree(d, ignore_errors=True)
+    if seed >= 1000 and np.random.default_rng(seed ^ 0x5EED).random() < 0.25:  # (the seeds below 1000 are pinned by tests as they were)
+        kw["overlap_prob"] = float(np.random.default_rng(seed ^ 0x5EED).choice([0.05, 0.3, 0.8]))
+        mode += " overlapping rows"
     w = synth.make_workload(d, seed, **kw)
-    t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+    wl = Workload.load(w.left_dir, w.right_dir, w.delta_paths)
+    t = wl.tables()
+    # the unit list made on the device (what the file-level entries run on) against the host's loops
+    listed = TranslateJob.from_workload(wl)
+    dev_units = listed.units()
+    listed.close()
+    if any(not np.array_equal(dev_units[k], t.units[k]) for k in ("delta", "left", "right")):
+        print("seed", seed, mode, "the device's unit list differs from the host's: UNIT LIST MISMATCH", flush=True)
+        sys.exit(1)
     corrupt = rng.random() < 0.5
     if corrupt:
         corrupt_tables(t, rng)
