@@ -379,16 +379,39 @@ struct PairCursorT {
 // rows, get there).  Such units are emitted a second time by the FIX pass (`fix` != nullptr): the open segment's gaps
 // are recorded in arrival order in a scratch list and commit() writes the writer's own two-list merge of them -- heads
 // compared by start, ties to the query list -- over what the EMIT pass wrote.
+// What the EMIT pass writes per entry.  Jobs in int64 coordinates write the C ABI's pm_entry_t (48 bytes) and int64 offsets; jobs
+// whose tables fit the int instantiation -- all but pathological ones -- write a 32-byte record and int offsets: a record is then
+// one 32-byte sector of HBM, written whole by its lane, and the job's output is 0.63 of the wide one's bytes.  (Round 2's PMC
+// pass found 239 MB written for 126 MB of output: a 48-byte record at a 48-byte stride touches two sectors, a lone 8-byte offset
+// costs a sector of its own; the lines of ~400 k resident lanes do not wait in the L2 to be completed.)  pm_job_fetch widens.
+struct alignas(32) Entry32 {
+  int ref_start, ref_end, qry_start, qry_end;
+  i64 offset_begin;
+  int n_offsets;
+  int pad;
+};
+static_assert(sizeof(Entry32) == 32, "one HBM sector per record");
+template <typename I>
+struct EntRecT {
+  typedef pm_entry_t type;
+};
+template <>
+struct EntRecT<int> {
+  typedef Entry32 type;
+};
+
 template <bool EMIT, typename I = i64>
 struct Sink {
+  typedef typename EntRecT<I>::type Rec;
+  static constexpr int S = 32 / (int)sizeof(I); // offsets per 32-byte sector
   I n_ent;     // committed entries
   I n_off;     // committed offsets
   I pend;      // offsets of the open segment
   I wpos;      // deltas_of_gaps' running column
   I last_start;
   int last_row;
-  pm_entry_t *ent; // EMIT: this unit's first entry slot
-  i64 *off;      // EMIT: whole offsets array (always int64: the C ABI's type)
+  Rec *ent;      // EMIT: this unit's first entry slot
+  I *off;        // EMIT: whole offsets array
   i64 off_base;  // EMIT: this unit's first offset index
   I off_cap;     // EMIT: this unit's offset count (exact, from the COUNT pass)
   I ent_cap;
@@ -398,13 +421,71 @@ struct Sink {
   I fix_cap;     // FIX pass: gaps the scratch list holds (the unit's offset count + 1).  A gap owns at least one offset of
                  // its segment, so a segment that commits never holds more; one that is later dropped may, and the
                  // gaps past the cap are then simply not recorded (nothing ever reads them)
+  // EMIT: offsets wait in a stage of the lane's own (T = two sectors' worth of slots, `stage_stride` elements apart: LDS, slot-major
+  // across the wavefront) and leave as whole 32-byte sectors: a lone 4- or 8-byte store costs a sector write of its own, since the
+  // lines of some 400 k resident lanes do not wait in the L2 for their neighbours.  Slot = the offset's global index mod T.
+  // [stage_lo, n_off + pend) is what is staged and not yet written, at most T of them.  When the stage is full, everything up to
+  // the last complete sector leaves (its head, if the unit starts inside a sector, as single stores); the rest at the unit's end.
+  static constexpr int T = 2 * S;
+  I *stage;
+  int stage_stride;
+  I stage_lo;
+
+  PM_HD __forceinline__ void stage_write(i64 g_first, i64 g_end) { // the staged offsets with global indices [g_first, g_end)
+    i64 g = g_first;
+    for(; g < g_end && (g & (S - 1)) != 0; ++g) { // up to the first sector boundary
+      off[g] = stage[(int)(g & (T - 1)) * stage_stride];
+    }
+    for(; g + S <= g_end; g += S) { // whole sectors
+      const I *src = stage + (int)(g & (T - 1)) * stage_stride;
+      I *dst = off + g;
+#ifdef __HIP_DEVICE_COMPILE__
+      struct alignas(16) Half {
+        I v[S / 2];
+      };
+      Half lo, hi; // the array starts on a sector (hipMalloc), g is a multiple of S: two 16-byte stores
+#pragma unroll
+      for(int k = 0; k < S / 2; ++k) {
+        lo.v[k] = src[k * stage_stride];
+        hi.v[k] = src[(k + S / 2) * stage_stride];
+      }
+      reinterpret_cast<Half *>(dst)[0] = lo;
+      reinterpret_cast<Half *>(dst)[1] = hi;
+#else
+      for(int k = 0; k < S; ++k) {
+        dst[k] = src[k * stage_stride];
+      }
+#endif
+    }
+    for(; g < g_end; ++g) { // the tail
+      off[g] = stage[(int)(g & (T - 1)) * stage_stride];
+    }
+  }
+  PM_HD __forceinline__ void stash(I at, I v) {
+    if(at < off_cap) { // offsets of a segment that is later dropped may run past the exact slot
+      const i64 g = off_base + at;
+      stage[(int)(g & (T - 1)) * stage_stride] = v;
+      if(at - stage_lo + 1 == T) { // full: T >= 2 S - 1 staged offsets hold at least one complete sector
+        const i64 g_end = (g + 1) & ~(i64)(S - 1);
+        stage_write(off_base + stage_lo, g_end);
+        stage_lo = (I)(g_end - off_base);
+      }
+    }
+  }
+  // after the unit's last commit (or its failure): the committed offsets still staged
+  PM_HD __forceinline__ void finish() {
+    if(EMIT && !fix) {
+      const I end = n_off < off_cap ? n_off : off_cap;
+      if(stage_lo < end) {
+        stage_write(off_base + stage_lo, off_base + end);
+        stage_lo = end;
+      }
+    }
+  }
 
   PM_HD __forceinline__ void put(I v) {
     if(EMIT && !fix) {
-      I at = n_off + pend;
-      if(at < off_cap) { // offsets of a segment that is later dropped may run past the exact slot
-        off[off_base + at] = v;
-      }
+      stash(n_off + pend, v);
     }
     ++pend;
   }
@@ -427,7 +508,7 @@ struct Sink {
       I room = off_cap - at;
       I n = ones < room ? ones : room;
       for(I k = 0; k < n; ++k) {
-        off[off_base + at + k] = sign;
+        stash(at + k, sign);
       }
     }
     pend += ones;
@@ -440,6 +521,9 @@ struct Sink {
     pend = 0;
     wpos = 0;
     fix_n = 0;
+    if(EMIT && stage_lo > n_off) { // a segment that was dropped after it had filled sectors: the next one is staged from n_off again
+      stage_lo = n_off;
+    }
   }
   // FIX pass: deltas_of_gaps over the recorded gaps (m_delta_stream_writer.hh:14-53): two cursors, one per row, each taking
   // its row's gaps in arrival order; the smaller start goes first, ties to the query row
@@ -485,7 +569,7 @@ struct Sink {
     put(0);
     if(EMIT) {
       if(n_ent < ent_cap) {
-        pm_entry_t e;
+        Rec e = Rec();
         e.ref_start = ref.s;
         e.ref_end = ref.e;
         e.qry_start = qry.s;
@@ -868,6 +952,7 @@ PM_HD inline int run_unit(const RowsT<I> &left, const RowsT<I> &right, const Del
     return st;
   }
   st = unit_merge<EMIT>(m);
+  m.sink.finish();
   sink = m.sink;
   return st;
 }

@@ -6,7 +6,8 @@
 //            {ref,qry}_gaps[2][R2 G], {ref,qry}_pre[2][G+n]   (orientation 0 as read, 1 reversed), bad[int n]
 //   units  : delta[int U], left[int U], right[int U]
 //   out    : status[int U], cnt_ent[U+1], cnt_off[U+1] -> exclusive scans ent_off[U+1], off_off[U+1],
-//            entries[pm_entry_t E], offsets[O]
+//            entries[E] + offsets[O]: 32-byte Entry32 records + int offsets for a job on the int tables (pm_job_fetch widens them),
+//            pm_entry_t + int64 else (translate_device.hpp, EntRecT)
 // Kernels: prepare_rows / prepare_deltas (once per job), translate_count, 2x rocprim exclusive_scan,
 // translate_emit.  One lane per unit (the merge is a sequential state machine; the batch supplies the
 // parallelism), 64-lane workgroups so a 100 k-unit batch spreads over all 256 CUs.
@@ -206,7 +207,7 @@ template <bool EMIT, typename I>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                  const int *live_units, const int *live_pos, int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off,
-                 const i64 *off_off, pm_entry_t *entries, i64 *offsets, i64 ent_cap, i64 off_cap, int *overflow, void *states,
+                 const i64 *off_off, typename EntRecT<I>::type *entries, I *offsets, i64 ent_cap, i64 off_cap, int *overflow, void *states,
                  int *narrow_trip, int *slow_flag, const int *slow_units, i64 n_slow, i64 *scratch, const i64 *slow_scratch_off) {
   // slow_flag (COUNT): set for a unit whose gaps arrive out of the writer's merge order (Sink, translate_device.hpp).
   // slow_units (EMIT only; the FIX pass): the launch covers just those units, one lane each, with a scratch list for the open
@@ -252,6 +253,14 @@ translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, cons
   sink.fix = fix;
   sink.fix_n = 0;
   sink.fix_cap = 0;
+  sink.stage = nullptr;
+  sink.stage_stride = 64;
+  sink.stage_lo = 0;
+  if constexpr(EMIT) {
+    // two sectors of offsets per lane, slot-major: lanes that fill the same slot hit 64 different banks
+    __shared__ I stage[Sink<EMIT, I>::T * 64];
+    sink.stage = stage + threadIdx.x;
+  }
   if(EMIT) {
     sink.ent = entries + ent_off[u];
     sink.ent_cap = (I)(ent_off[u + 1] - ent_off[u]);
@@ -269,6 +278,7 @@ translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, cons
     state_load<I>(states, n_live, k, s);
     unit_restore<EMIT>(left, right, ds, d, l, r, s, m);
     (void)unit_merge<EMIT>(m);
+    m.sink.finish();
   }
   else {
     PVT<I> lp, rp, dr, dq;
@@ -300,6 +310,28 @@ translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, cons
       slow_flag[u] = 1;
       slow_flag[n_units] = 1; // "the job has such units"
     }
+  }
+}
+
+// pm_job_fetch of a narrow job: its records and offsets in the C ABI's types
+__global__ void widen_entries_kernel(i64 n, const Entry32 *in, pm_entry_t *out) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k < n) {
+    const Entry32 e = in[k];
+    pm_entry_t w;
+    w.ref_start = e.ref_start;
+    w.ref_end = e.ref_end;
+    w.qry_start = e.qry_start;
+    w.qry_end = e.qry_end;
+    w.offset_begin = e.offset_begin;
+    w.n_offsets = e.n_offsets;
+    out[k] = w;
+  }
+}
+__global__ void widen_offsets_kernel(i64 n, const int *in, i64 *out) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(k < n) {
+    out[k] = in[k];
   }
 }
 
@@ -512,10 +544,10 @@ struct TextNames {
   const i64 *length[2];   // p_length of the rows (the header's two numbers)
 };
 
-template <bool WRITE>
+template <bool WRITE, typename I>
 __global__ void text_entries_kernel(i64 E, i64 U, const i64 *ent_off, const int *u_left, const int *u_right, const int *last_ne,
-                                    const int *first_fail, const pm_entry_t *entries, const i64 *offsets, TextNames names, int *e_unit,
-                                    i64 *len, const i64 *pos, char *text) {
+                                    const int *first_fail, const typename EntRecT<I>::type *entries, const I *offsets, TextNames names,
+                                    int *e_unit, i64 *len, const i64 *pos, char *text) {
   const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= E) {
     return;
@@ -549,7 +581,7 @@ __global__ void text_entries_kernel(i64 E, i64 U, const i64 *ent_off, const int 
     header = p < 0 ? (names.off[0][l + 1] > names.off[0][l] || names.off[1][r + 1] > names.off[1][r])
                    : (names.id[0][u_left[p]] != names.id[0][l] || names.id[1][u_right[p]] != names.id[1][r]);
   }
-  const pm_entry_t en = entries[k];
+  const typename EntRecT<I>::type en = entries[k];
   if(!WRITE) {
     if(u > *first_fail) {
       e_unit[k] = -1;
@@ -798,6 +830,9 @@ struct pm_job {
   // units whose gaps arrive out of the writer's order (Sink): found by the sizing pass, emitted again by the FIX pass
   DevBuf slow_flag, slow_units, slow_scratch_off, slow_scratch;
   i64 n_slow = 0;
+  // what the EMIT pass writes per entry / per offset (translate_device.hpp: Entry32 + int for a narrow job, pm_entry_t + int64 else)
+  int64_t rec_bytes() const { return narrow ? (int64_t)sizeof(Entry32) : (int64_t)sizeof(pm_entry_t); }
+  int64_t off_bytes() const { return narrow ? 4 : 8; }
   bool narrow = false; // the job runs on the int tables (every table value below PM_NARROW_INPUT_LIMIT, no PM_ST_NARROW seen)
   size_t scan_tmp32_bytes = 0;
   size_t scan_tmp_bytes = 0;
@@ -875,35 +910,35 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   }
   // 4. emit pass over the live units
   if(emit && U > 0) {
-#define PM_EMIT_ARGS                                                                                                              \
+#define PM_EMIT_ARGS_OF(I)                                                                                                        \
   U, (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,                \
       (const int *)j->live_pos.p, nullptr, nullptr, nullptr, (const i64 *)j->ent_off.p, (const i64 *)j->off_off.p,                 \
-      (pm_entry_t *)j->entries.p, (i64 *)j->offsets.p, j->ent_cap, j->off_cap, (int *)j->overflow.p, j->states.p,                  \
+      (EntRecT<I>::type *)j->entries.p, (I *)j->offsets.p, j->ent_cap, j->off_cap, (int *)j->overflow.p, j->states.p,              \
       (int *)j->narrow_trip.p, nullptr
     if(j->narrow) {
-      translate_kernel<true, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS, nullptr, 0,
-                                                             nullptr, nullptr);
+      translate_kernel<true, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS_OF(int),
+                                                             nullptr, 0, nullptr, nullptr);
     }
     else {
-      translate_kernel<true, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS, nullptr, 0, nullptr,
-                                                             nullptr);
+      translate_kernel<true, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS_OF(i64), nullptr, 0,
+                                                             nullptr, nullptr);
     }
     PM_HIP(hipGetLastError());
     if(j->n_slow > 0) { // the FIX pass: the few units whose offsets are not what on-the-fly emission gives
       const unsigned fblocks = (unsigned)((j->n_slow + 63) / 64);
       if(j->narrow) {
-        translate_kernel<true, int><<<fblocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS,
+        translate_kernel<true, int><<<fblocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS_OF(int),
                                                                 (const int *)j->slow_units.p, j->n_slow, (i64 *)j->slow_scratch.p,
                                                                 (const i64 *)j->slow_scratch_off.p);
       }
       else {
-        translate_kernel<true, i64><<<fblocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS,
+        translate_kernel<true, i64><<<fblocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS_OF(i64),
                                                                 (const int *)j->slow_units.p, j->n_slow, (i64 *)j->slow_scratch.p,
                                                                 (const i64 *)j->slow_scratch_off.p);
       }
       PM_HIP(hipGetLastError());
     }
-#undef PM_EMIT_ARGS
+#undef PM_EMIT_ARGS_OF
   }
   if(ev) {
     PM_HIP(hipEventRecord(ev[4], stream));
@@ -1174,8 +1209,9 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
     }
     JTRY(j->states.alloc((size_t)(n_live > 0 ? n_live : 1) * sizeof(UnitState))); // the int layout needs less
   }
-  JTRY(j->entries.alloc((size_t)j->ent_cap * sizeof(pm_entry_t)));
-  JTRY(j->offsets.alloc((size_t)j->off_cap * 8));
+  // (+ 32: a whole-sector store of staged offsets never starts inside the array and ends outside it, but keep a sector of slack)
+  JTRY(j->entries.alloc((size_t)j->ent_cap * (size_t)j->rec_bytes()));
+  JTRY(j->offsets.alloc((size_t)j->off_cap * (size_t)j->off_bytes() + 32));
   // free the SoA staging copies
   j->left.raw_s.release();
   j->left.raw_e.release();
@@ -1349,11 +1385,29 @@ int pm_job_fetch(pm_job_t *j, int32_t *unit_status, int64_t *unit_entry_off, pm_
   if(unit_entry_off) {
     PM_HIP(hipMemcpy(unit_entry_off, j->ent_off.p, (size_t)(U + 1) * 8, hipMemcpyDeviceToHost));
   }
-  if(entries && ne > 0) {
-    PM_HIP(hipMemcpy(entries, j->entries.p, (size_t)ne * sizeof(pm_entry_t), hipMemcpyDeviceToHost));
+  if(j->narrow) { // the job holds 32-byte records and int offsets: widened on the device into the C ABI's types, then copied
+    if(entries && ne > 0) {
+      DevBuf wide;
+      PM_TRY(wide.alloc((size_t)ne * sizeof(pm_entry_t)));
+      widen_entries_kernel<<<(unsigned)((ne + 255) / 256), 256>>>(ne, (const Entry32 *)j->entries.p, (pm_entry_t *)wide.p);
+      PM_HIP(hipGetLastError());
+      PM_HIP(hipMemcpy(entries, wide.p, (size_t)ne * sizeof(pm_entry_t), hipMemcpyDeviceToHost));
+    }
+    if(offsets && no > 0) {
+      DevBuf wide;
+      PM_TRY(wide.alloc((size_t)no * 8));
+      widen_offsets_kernel<<<(unsigned)((no + 255) / 256), 256>>>(no, (const int *)j->offsets.p, (i64 *)wide.p);
+      PM_HIP(hipGetLastError());
+      PM_HIP(hipMemcpy(offsets, wide.p, (size_t)no * 8, hipMemcpyDeviceToHost));
+    }
   }
-  if(offsets && no > 0) {
-    PM_HIP(hipMemcpy(offsets, j->offsets.p, (size_t)no * 8, hipMemcpyDeviceToHost));
+  else {
+    if(entries && ne > 0) {
+      PM_HIP(hipMemcpy(entries, j->entries.p, (size_t)ne * sizeof(pm_entry_t), hipMemcpyDeviceToHost));
+    }
+    if(offsets && no > 0) {
+      PM_HIP(hipMemcpy(offsets, j->offsets.p, (size_t)no * 8, hipMemcpyDeviceToHost));
+    }
   }
   for(i64 u = 0; u < U; ++u) {
     if(st[u] != PM_ST_OK) {
@@ -1430,9 +1484,16 @@ int pm_job_text(pm_job_t *j, const char *const *left_major, const char *const *r
   names.length[1] = (const i64 *)j->right.length.p;
   PM_HIP(hipMemsetAsync((i64 *)j->t_len.p + E, 0, 8, stream));
   if(E > 0) {
-    text_entries_kernel<false><<<(unsigned)((E + 255) / 256), 256, 0, stream>>>(
-        E, U, (const i64 *)j->ent_off.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->t_last_ne.p, (const int *)j->t_word.p,
-        (const pm_entry_t *)j->entries.p, (const i64 *)j->offsets.p, names, (int *)j->t_eunit.p, (i64 *)j->t_len.p, nullptr, nullptr);
+#define PM_TEXT_LAUNCH(WRITE, I, LEN, POS, TEXT)                                                                                                   \
+  text_entries_kernel<WRITE, I><<<(unsigned)((E + 255) / 256), 256, 0, stream>>>(                                                                   \
+      E, U, (const i64 *)j->ent_off.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->t_last_ne.p, (const int *)j->t_word.p, \
+      (const EntRecT<I>::type *)j->entries.p, (const I *)j->offsets.p, names, (int *)j->t_eunit.p, LEN, POS, TEXT)
+    if(j->narrow) {
+      PM_TEXT_LAUNCH(false, int, (i64 *)j->t_len.p, nullptr, nullptr);
+    }
+    else {
+      PM_TEXT_LAUNCH(false, i64, (i64 *)j->t_len.p, nullptr, nullptr);
+    }
     PM_HIP(hipGetLastError());
     size_t tmp = j->t_scan_tmp.bytes;
     PM_HIP(rocprim::exclusive_scan(j->t_scan_tmp.p, tmp, (i64 *)j->t_len.p, (i64 *)j->t_pos.p, (i64)0, (size_t)(E + 1), rocprim::plus<i64>(), stream));
@@ -1445,10 +1506,13 @@ int pm_job_text(pm_job_t *j, const char *const *left_major, const char *const *r
     if((i64)j->t_text.bytes < total) {
       PM_TRY(j->t_text.alloc((size_t)total));
     }
-    text_entries_kernel<true><<<(unsigned)((E + 255) / 256), 256, 0, stream>>>(
-        E, U, (const i64 *)j->ent_off.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->t_last_ne.p, (const int *)j->t_word.p,
-        (const pm_entry_t *)j->entries.p, (const i64 *)j->offsets.p, names, (int *)j->t_eunit.p, nullptr, (const i64 *)j->t_pos.p,
-        (char *)j->t_text.p);
+    if(j->narrow) {
+      PM_TEXT_LAUNCH(true, int, nullptr, (const i64 *)j->t_pos.p, (char *)j->t_text.p);
+    }
+    else {
+      PM_TEXT_LAUNCH(true, i64, nullptr, (const i64 *)j->t_pos.p, (char *)j->t_text.p);
+    }
+#undef PM_TEXT_LAUNCH
     PM_HIP(hipGetLastError());
     j->text_bytes = total;
   }
@@ -1496,7 +1560,7 @@ int pm_job_algorithmic_bytes(pm_job_t *j, int64_t *bytes) {
     return fail(PM_E_INVALID, "pm_job_algorithmic_bytes: null argument");
   }
   // inputs once + per unit status/counts/offsets + entries + offsets
-  *bytes = j->input_bytes + j->n_units * (4 + 16 + 16) + j->ent_cap * (int64_t)sizeof(pm_entry_t) + j->off_cap * 8;
+  *bytes = j->input_bytes + j->n_units * (4 + 16 + 16) + j->ent_cap * j->rec_bytes() + j->off_cap * j->off_bytes();
   return PM_OK;
 }
 
@@ -1514,7 +1578,7 @@ int pm_job_kernel_bytes(pm_job_t *j, int64_t *count_bytes, int64_t *emit_bytes, 
   // emit pass: the live list and the saved states, the gap lists again, output offsets, entries and offsets written
   if(emit_bytes) {
     *emit_bytes = (int64_t)live * (4 + 32 + state_bytes) + (j->left.G + j->right.G + j->deltas.Gr + j->deltas.Gq) * (j->narrow ? 8 : 16) +
-                  j->ent_cap * (int64_t)sizeof(pm_entry_t) + j->off_cap * 8;
+                  j->ent_cap * j->rec_bytes() + j->off_cap * j->off_bytes();
   }
   if(n_live) {
     *n_live = live;

@@ -167,14 +167,24 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
   if(eo[U] > entries_cap || oo[U] > offsets_cap) {
     return 1; // caller re-calls with bigger buffers
   }
+  // the EMIT pass writes its own record and offset types (Entry32 + int in the int instantiation); widened below for the caller
+  typedef typename EntRecT<I>::type Rec;
+  std::vector<Rec> rec((size_t)eo[U] + 1);
+  std::vector<I> off((size_t)oo[U] + 8);
+  I stage[Sink<true, I>::T]; // the lane's sector of staged offsets (LDS on the device)
   for(i64 u = 0; u < U; ++u) { // EMIT pass
     Sink<true, I> sink;
     memset(&sink, 0, sizeof sink);
-    sink.ent = entries + eo[u];
+    sink.ent = rec.data() + eo[u];
     sink.ent_cap = (I)(eo[u + 1] - eo[u]);
-    sink.off = (i64 *)offsets;
+    sink.off = off.data();
     sink.off_base = oo[u];
     sink.off_cap = (I)(oo[u + 1] - oo[u]);
+    sink.stage = stage;
+    sink.stage_stride = 1;
+    for(int k = 0; k < Sink<true, I>::T; ++k) {
+      stage[k] = (I)0x5a5a5a5a; // whatever the previous unit left must not matter
+    }
     int st = run_unit<true>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], sink);
     if(st != status[u]) {
       return 2; // the two passes must agree
@@ -183,9 +193,9 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
       std::vector<i64> scratch((size_t)(2 * (oo[u + 1] - oo[u]) + 2), 0);
       Sink<true, I> fx;
       memset(&fx, 0, sizeof fx);
-      fx.ent = entries + eo[u];
+      fx.ent = rec.data() + eo[u];
       fx.ent_cap = (I)(eo[u + 1] - eo[u]);
-      fx.off = (i64 *)offsets;
+      fx.off = off.data();
       fx.off_base = oo[u];
       fx.off_cap = (I)(oo[u + 1] - oo[u]);
       fx.fix = scratch.data();
@@ -195,6 +205,17 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
         return 2;
       }
     }
+  }
+  for(i64 e = 0; e < eo[U]; ++e) {
+    entries[e].ref_start = rec[(size_t)e].ref_start;
+    entries[e].ref_end = rec[(size_t)e].ref_end;
+    entries[e].qry_start = rec[(size_t)e].qry_start;
+    entries[e].qry_end = rec[(size_t)e].qry_end;
+    entries[e].offset_begin = rec[(size_t)e].offset_begin;
+    entries[e].n_offsets = rec[(size_t)e].n_offsets;
+  }
+  for(i64 o = 0; o < oo[U]; ++o) {
+    offsets[o] = off[(size_t)o];
   }
   return 0;
 }

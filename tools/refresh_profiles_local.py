@@ -16,13 +16,17 @@ P = os.environ.get("PM_PROFILE_OUT") or os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 tool = os.path.join(ROOT, "tools", "summarize_prof.py")
-bench = json.load(open(os.path.join(O, "bench.json")))
-shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "%s_bench_default.json" % TAG))
+if os.path.exists(os.path.join(O, "bench.json")):
+    bench = json.load(open(os.path.join(O, "bench.json")))
+    shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "%s_bench_default.json" % TAG))
+else:  # a subset run (PM_REFRESH_ONLY): the line of the last full run names the workloads
+    bench = json.load(open(os.path.join(ROOT, "profiles", "%s_bench_default.json" % TAG)))
 table_path = os.path.join(P, "pmc_traffic.json")
 old_table = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 table = json.load(open(old_table)) if os.path.exists(old_table) else {}
 keep = ("FETCH_SIZE", "WRITE_SIZE")
-sq_all = {}
+old_sq = os.path.join(ROOT, "profiles", "%s_sq_counters.json" % TAG)
+sq_all = json.load(open(old_sq)) if os.path.exists(old_sq) else {}  # a subset run replaces only its own workloads
 keys = {"ns": "dp:ns:%d:%d:%d" % (bench["config"]["pairs_per_rank"], bench["config"]["rows"], bench["config"]["columns"]),
         "c1": "dp:c1:10000:2:1000", "c2": "dp:c2:100000:4:0", "deep": "dp:deep:4096:32:10000", "tr": "translate:4:1000000:2500:16:6000"}
 for name, key in keys.items():
