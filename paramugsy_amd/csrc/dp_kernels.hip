@@ -985,7 +985,16 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   }
   if(pipelined) {
     if(!h->path_stream) {
-      PM_HIP(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking));
+      // PM_DP_PATH_PRIORITY=high|low: an experiment (the path kernels' waves ahead of / behind the fill kernel's at dispatch)
+      const char *pr = getenv("PM_DP_PATH_PRIORITY");
+      if(pr && (pr[0] == 'h' || pr[0] == 'l')) {
+        int least = 0, greatest = 0;
+        PM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        PM_HIP(hipStreamCreateWithPriority(&h->path_stream, hipStreamNonBlocking, pr[0] == 'h' ? greatest : least));
+      }
+      else {
+        PM_HIP(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking));
+      }
     }
     while(h->ev_fill.size() < h->chunk_tb.size()) {
       hipEvent_t a = nullptr, b = nullptr;
