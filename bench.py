@@ -78,7 +78,7 @@ def parse_args():
     ap.add_argument("--dp-pairs", type=int, default=0)
     ap.add_argument("--dp-rows", type=int, default=0)
     ap.add_argument("--dp-len", type=int, default=0)
-    ap.add_argument("--dp-budget-gib", type=float, default=0.0, help="path workspace budget (0: the library's default, 96 GiB or 40 %% of the device's memory)")
+    ap.add_argument("--dp-budget-gib", type=float, default=0.0, help="path workspace budget (0: the library's default, 60 %% of the device's memory)")
     return ap.parse_args()
 
 
@@ -414,9 +414,15 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
     stream = torch.cuda.current_stream().cuda_stream
     dt = timed_region(torch, dist, lambda: batch.run(True, stream), steps, warmup)
     info = batch.info()
-    prof = [batch.run_profiled(True, stream) for _ in range(max(3, min(steps, 10)))]
-    ms_fill = sum(p[0] for p in prof) / len(prof)
+    prof = []
+    for _ in range(max(3, min(steps, 10))):
+        a, b = batch.run_profiled(True, stream)
+        prof.append((a, b, batch.fill_busy_ms()))
+    ms_fill_sum = sum(p[0] for p in prof) / len(prof)  # summed over the step's launches: what a kernel trace adds up
     ms_tb = sum(p[1] for p in prof) / len(prof)
+    # the time during which SOME fill kernel ran: the fill launches of a batch of several chunks overlap (each slot of the workspace
+    # has a stream of its own), so this is what the step's bytes and cells are divided by; one chunk: the same number
+    ms_fill = sum(p[2] for p in prof) / len(prof)
     cells = info["cells"]
     cells_all = sum_over_ranks(torch, dist, cells)
     variant = batch.variant()
@@ -442,16 +448,27 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
                    "name": cfg_name, "pairs_in_job": n_total, "pairs_per_rank": n, "rows": rows, "columns": cfg["len"],
                    "cells_per_step_per_rank": cells, "chunks": info["chunks"], "kernel_variant": variant,
                    "reference_counterpart": "none: the reference has no DP (SURVEY.md 0); specification and oracle are this repo's own"},
-        "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_walk_kernel" if variant.get("checkpoints") else "dp_traceback_kernel": ms_tb,
-                      "note": "device time summed over the step's launches (one fill and one path launch per workspace chunk; with several "
-                              "chunks the path kernel of chunk c runs beside the fill kernel of chunk c + 1, so the two sums overlap)"},
+        "kernel_ms": {"dp_fill_kernel": ms_fill, "dp_fill_kernel_summed_over_launches": ms_fill_sum,
+                      "dp_walk_kernel" if variant.get("checkpoints") else "dp_traceback_kernel": ms_tb,
+                      "note": "dp_fill_kernel: the time during which some fill kernel ran; ..._summed_over_launches: the launches' own "
+                              "durations added up, as a kernel trace does (one fill and one path launch per workspace chunk; with several "
+                              "chunks the fill kernels of consecutive chunks overlap on their own streams -- one takes the SIMDs the other "
+                              "leaves as it drains -- and the path kernel of a chunk runs beside the fill kernels of the next, so the sums "
+                              "exceed the step)"},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": measured_traffic("dp_fill_kernel", "dp:%s:%d:%d:%d" % (cfg_name, n, rows, cfg["len"]), launches),
                      "kernel": "dp_fill_kernel",
                      "launches_per_step": launches,
-                     "avg_launch_ms": ms_fill / launches,
+                     "avg_launch_ms": ms_fill_sum / launches,
+                     "launch_concurrency": ms_fill_sum / ms_fill if ms_fill > 0 else 1.0,
                      "algorithmic_bytes_per_launch": alg_bytes // launches,
+                     "achieved_per_launch": (alg_bytes / launches) / (ms_fill_sum / launches * 1e-3) / 1e9,
+                     "how": "achieved = the step's algorithmic bytes / the time during which a fill kernel ran (HIP events around every "
+                            "launch on its stream, the union of the intervals).  With one launch per step that is bytes per launch / the "
+                            "launch's duration.  With several, launch_concurrency of them run side by side, each on its share of the "
+                            "chip: achieved_per_launch = bytes per launch / avg_launch_ms is what ONE launch gets (the figure a kernel "
+                            "trace's average duration reproduces), and achieved = achieved_per_launch x launch_concurrency",
                      "valu": {"ops_per_cell": ops_per_cell, "achieved_Tops": cells * ops_per_cell / (ms_fill * 1e-3) / 1e12,
                               "peak_Tops": valu_peak / 1e12, "frac": cells * ops_per_cell / (ms_fill * 1e-3) / valu_peak,
                               "definition": "useful cell instructions only (per-step overhead, wavefront fill/drain and column padding excluded), "

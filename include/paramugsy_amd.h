@@ -229,9 +229,10 @@ typedef struct pm_dp_params {
 
 typedef struct pm_dp_batch pm_dp_batch_t; /* opaque; owns device memory */
 
-/* Upload a batch (host pointers).  tb_budget_bytes bounds the path workspace (<= 0: 96 GiB, at most 40 % of the device's
- * memory); a batch that needs more is processed in chunks that fit it, the path kernel of one chunk beside the fill kernel of
- * the next. */
+/* Upload a batch (host pointers).  tb_budget_bytes bounds the path workspace (<= 0: 60 % of the device's memory; only what the
+ * batch needs is allocated); a batch that needs more is processed in chunks of a third of it, the fill kernels of consecutive
+ * chunks on streams of their own (one takes the SIMDs the other leaves as it drains), the path kernel of a chunk beside the
+ * fill kernels of the next. */
 int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
                        const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out);
 /* One pass over every pair: fill (scores, and what the path walk needs) and, when traceback != 0, the path walk.
@@ -239,6 +240,9 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
 int pm_dp_batch_run(pm_dp_batch_t *batch, int traceback, void *hip_stream);
 /* Same, timed with HIP events on the stream (waits): device milliseconds of the fill and traceback kernels. */
 int pm_dp_batch_run_profiled(pm_dp_batch_t *batch, int traceback, void *hip_stream, float *ms_fill, float *ms_traceback);
+/* After pm_dp_batch_run_profiled: the time during which SOME fill kernel was running.  ms_fill above is the sum over the step's
+ * launches (what a kernel trace adds up); the fill launches of a batch of several chunks overlap, so the two differ there. */
+int pm_dp_batch_fill_busy_ms(pm_dp_batch_t *batch, float *ms);
 /* scores[n_pairs]; n_ops[n_pairs]; ops: pair k owns bytes [off_a[k]+off_b[k], off_a[k+1]+off_b[k+1]) and its path is
  * the LAST n_ops[k] bytes of that slot, first op first (0 = M, 1 = I: column of B against a gap, 2 = D). */
 int pm_dp_batch_fetch(pm_dp_batch_t *batch, int32_t *scores, uint8_t *ops, int32_t *n_ops);

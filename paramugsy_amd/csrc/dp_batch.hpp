@@ -38,10 +38,17 @@ struct pm_dp_batch {
   pm::i64 band_work_items = 0; // 0: no band
   int band_lanes = 0;          // the lanes per pair the band's blocks are laid out for
   hipStream_t last_stream = nullptr;
-  // chunk pipeline (more than one chunk): the workspace is two halves, chunk c uses half c % 2; the path kernel of chunk c runs
-  // on `path_stream` beside the fill kernel of chunk c + 1
+  // chunk pipeline (more than one chunk): the workspace is n_slots equal parts, chunk c uses part c % n_slots; the path kernel of
+  // chunk c runs on `path_stream` beside the fill kernels of the chunks after it
   pm::i64 tb_half_words = 0;
   hipStream_t path_stream = nullptr;
+  // the fill kernels of every slot run on a stream of their own, so that chunk c + 1's first wavefronts take the SIMDs chunk c's
+  // last ones leave (a launch ends with the chip draining: its last round of pairs fills only part of it); ev_begin orders that
+  // stream behind whatever the caller's stream held when dp_run was called
+  float last_fill_busy_ms = 0;           // profiled run: the time during which some fill kernel ran (launches may overlap)
+  int n_slots = 3;                       // parts of the workspace that consecutive chunks use in turn (PM_DP_SLOTS)
+  std::vector<hipStream_t> fill_streams; // for the chunks of slots 1 .. n_slots - 1 (slot 0: the caller's stream)
+  hipEvent_t ev_begin = nullptr;
   std::vector<hipEvent_t> ev_fill, ev_path;                       // per chunk: fill done / path done
   std::vector<hipEvent_t> tv_fill0, tv_fill1, tv_path0, tv_path1; // timing events of the profiled run
   // dp_stream.hip: the columns arrive in segments of consecutive pairs (seg_first: first pair of each, plus n_pairs); ev_seg[k]
@@ -64,6 +71,12 @@ struct pm_dp_batch {
     if(path_stream) {
       (void)hipStreamDestroy(path_stream);
     }
+    for(hipStream_t st : fill_streams) {
+      (void)hipStreamDestroy(st);
+    }
+    if(ev_begin) {
+      (void)hipEventDestroy(ev_begin);
+    }
     if(pinned) {
       (void)hipHostFree(pinned);
     }
@@ -73,6 +86,7 @@ struct pm_dp_batch {
 namespace pm {
 
 // The steps pm_dp_batch_create is made of (dp_kernels.hip).  A reusable batch goes reserve once, then load / plan / run per slice.
+int64_t dp_default_budget_bytes();
 int dp_batch_check_params(const pm_dp_params_t *params);
 int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device);
 int dp_clear_pipe_error(pm_dp_batch *h); // synchronous (see dp_kernels.hip)

@@ -545,6 +545,10 @@ int dp_clear_pipe_error(pm_dp_batch *h) {
 
 int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device) {
   h->device = device;
+  if(const char *e = getenv("PM_DP_SLOTS")) { // parts of the path workspace / fill streams of a batch that needs several chunks
+    const int k = atoi(e);
+    h->n_slots = k >= 2 && k <= 8 ? k : 3;
+  }
   if(const char *e = getenv("PM_DP_WAVES")) {
     h->waves_override = atoi(e);
   }
@@ -577,14 +581,8 @@ int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budge
       }
     }
   }
-  // default path workspace: 96 GiB, at most 40 % of the device's memory (288 GB of HBM3E: the north-star's per-GPU share of
-  // 12 500 pairs of 8 x 4 kbp needs 53 GB of checkpoints and then runs as one chunk, one fill launch with every SIMD full)
   if(tb_budget_bytes <= 0) {
-    size_t free_b = 0, total_b = 0;
-    tb_budget_bytes = (int64_t)96 << 30;
-    if(hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
-      tb_budget_bytes = std::min<int64_t>(tb_budget_bytes, (int64_t)(total_b / 10 * 4));
-    }
+    tb_budget_bytes = dp_default_budget_bytes();
   }
   h->tb_budget_bytes = tb_budget_bytes;
   PM_TRY(h->pipe_error.alloc(4));
@@ -950,7 +948,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   bool pipelined = false;
   for(i64 budget = h->tb_budget_bytes;; budget /= 2) {
     const bool one_chunk = total_words <= budget / 4;
-    const i64 budget_words = one_chunk ? budget / 4 : budget / 8;
+    const i64 budget_words = one_chunk ? budget / 4 : budget / (4 * h->n_slots);
     // chunk_first: positions in `order`; chunk_tb: the word offset of every position's pair inside its chunk's workspace
     h->chunk_first.assign(1, 0);
     h->chunk_tb.clear();
@@ -974,7 +972,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     h->tb_words_cap = std::max(h->tb_words_cap, used);
     pipelined = h->chunk_tb.size() > 1;
     h->tb_half_words = pipelined ? ((h->tb_words_cap + 63) / 64) * 64 : 0;
-    const int rc = grow(h->tb, (size_t)(pipelined ? 2 * h->tb_half_words : h->tb_words_cap) * 4);
+    const int rc = grow(h->tb, (size_t)(pipelined ? std::min<i64>(h->n_slots, (i64)h->chunk_tb.size()) * h->tb_half_words : h->tb_words_cap) * 4);
     if(rc == PM_OK) {
       break;
     }
@@ -994,6 +992,16 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       }
       else {
         PM_HIP(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking));
+      }
+    }
+    if(!getenv("PM_DP_ONE_FILL_STREAM")) {
+      while((int)h->fill_streams.size() < h->n_slots - 1) {
+        hipStream_t st = nullptr;
+        PM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        h->fill_streams.push_back(st);
+      }
+      if(!h->ev_begin) {
+        PM_HIP(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
       }
     }
     while(h->ev_fill.size() < h->chunk_tb.size()) {
@@ -1286,6 +1294,19 @@ static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStre
 // ends up waiting for the last path kernels, so the caller sees one asynchronous operation on its stream.
 // Timed: device time of the fill and of the path kernels, summed over the chunks (events around every launch on its stream).
 namespace pm {
+// Default path workspace: 60 % of the device's memory (172 GB of an MI355X's 288 GB).  A launch ends with the chip draining -- the
+// last round of pairs fills only part of it -- so the fewer launches the better: the 100 000 ragged pairs of bench.py's c2 (139 GB
+// of checkpoints) and configs[4]'s 4 096 deep pairs (108 GB) run as ONE fill launch and one path launch (4 100 and 4 060 GCUPS
+// against 3 900 and 3 490 in 48 GiB chunks); a batch that needs more (the headline batch: 424 GB) is cut into chunks of a third of
+// the budget whose fill kernels overlap on streams of their own (dp_run).  The workspace is only as large as the chunks need.
+int64_t dp_default_budget_bytes() {
+  size_t free_b = 0, total_b = 0;
+  if(hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+    return (int64_t)(total_b / 10 * 6);
+  }
+  return (int64_t)96 << 30;
+}
+
 int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, float *ms_path) {
   const size_t nc = h->chunk_tb.size();
   const bool timed = ms_fill || ms_path;
@@ -1300,14 +1321,27 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
     }
   }
   unsigned *tb = (unsigned *)h->tb.p;
+  // two fill streams (see dp_batch.hpp): the fill kernel of an odd chunk is held back only by the path kernel that frees its half
+  // of the workspace, not by the fill kernel of the chunk before it
+  const int K = h->n_slots;
+  const bool two_fills = pipelined && (int)h->fill_streams.size() >= K - 1 && h->ev_begin && h->seg_first.empty();
+  if(two_fills) {
+    PM_HIP(hipEventRecord(h->ev_begin, stream));
+    for(int k = 0; k < K - 1; ++k) {
+      PM_HIP(hipStreamWaitEvent(h->fill_streams[(size_t)k], h->ev_begin, 0));
+    }
+  }
+  hipStream_t caller_stream = stream;
   for(size_t c = 0; c < nc; ++c) {
     if(h->chunk_first[c + 1] - h->chunk_first[c] <= 0) {
       continue;
     }
-    unsigned *tbw = tb + (h->tb_half_words ? (c & 1) * h->tb_half_words : 0);
-    hipStream_t ps = pipelined ? h->path_stream : stream;
-    if(pipelined && c >= 2) {
-      PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c - 2], 0)); // the half is free again
+    const size_t slot = c % (size_t)K;
+    unsigned *tbw = tb + (h->tb_half_words ? (i64)slot * h->tb_half_words : 0);
+    hipStream_t ps = pipelined ? h->path_stream : caller_stream;
+    stream = two_fills && slot ? h->fill_streams[slot - 1] : caller_stream; // this chunk's fill stream
+    if(pipelined && c >= (size_t)K) {
+      PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c - (size_t)K], 0)); // the part is free again
     }
     if(timed) {
       PM_HIP(hipEventRecord(h->tv_fill0[c], stream));
@@ -1351,8 +1385,10 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       }
     }
   }
-  if(pipelined) { // the caller's stream is done when the last two path kernels are
-    for(size_t c = nc >= 2 ? nc - 2 : 0; c < nc; ++c) {
+  stream = caller_stream;
+  if(pipelined) { // the caller's stream is done when the last two path kernels are (each behind its chunk's fill kernel, and the
+                  // path stream runs them in chunk order: every earlier kernel of either fill stream is behind them too)
+    for(size_t c = nc >= (size_t)K ? nc - (size_t)K : 0; c < nc; ++c) {
       PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c], 0));
     }
   }
@@ -1360,6 +1396,11 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
   if(timed) {
     PM_HIP(hipStreamSynchronize(stream));
     float acc_fill = 0, acc_path = 0;
+    std::vector<std::pair<float, float> > spans;
+    size_t first_chunk = 0;
+    while(first_chunk + 1 < nc && h->chunk_first[first_chunk + 1] - h->chunk_first[first_chunk] <= 0) {
+      ++first_chunk;
+    }
     for(size_t c = 0; c < nc; ++c) {
       if(h->chunk_first[c + 1] - h->chunk_first[c] <= 0) {
         continue;
@@ -1371,7 +1412,23 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       }
       acc_fill += a;
       acc_path += b;
+      // where the launch lies on the step's clock (the first chunk's start): for the time during which SOME fill kernel ran
+      float at = 0;
+      if(c != first_chunk) {
+        PM_HIP(hipEventElapsedTime(&at, h->tv_fill0[first_chunk], h->tv_fill0[c]));
+      }
+      spans.push_back(std::make_pair(at, at + a));
     }
+    std::sort(spans.begin(), spans.end());
+    float busy = 0, upto = -1e30f;
+    for(const std::pair<float, float> &sp : spans) {
+      const float lo = std::max(sp.first, upto);
+      if(sp.second > lo) {
+        busy += sp.second - lo;
+        upto = sp.second;
+      }
+    }
+    h->last_fill_busy_ms = busy;
     if(ms_fill) {
       *ms_fill = acc_fill;
     }
@@ -1413,6 +1470,14 @@ int pm_dp_batch_run_profiled(pm_dp_batch_t *h, int traceback, void *hip_stream, 
     *ms_traceback = b;
   }
   return rc;
+}
+
+int pm_dp_batch_fill_busy_ms(pm_dp_batch_t *h, float *ms) {
+  if(!h || !ms) {
+    return fail(PM_E_INVALID, "pm_dp_batch_fill_busy_ms: null argument");
+  }
+  *ms = h->last_fill_busy_ms;
+  return PM_OK;
 }
 
 int pm_dp_batch_fetch(pm_dp_batch_t *h, int32_t *scores, uint8_t *ops, int32_t *n_ops) {

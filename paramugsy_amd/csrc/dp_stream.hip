@@ -329,11 +329,9 @@ int pm_dp_align_multi(const uint8_t *cols_a, const int64_t *off_a, const uint8_t
     for(int k = 0; k < n_devices; ++k) {
       sharing += devices[k] == device;
     }
-    int64_t workspace = 0; // the library's default: 96 GiB, at most 40 % of the device's memory
+    int64_t workspace = 0; // the library's default (dp_default_budget_bytes)
     if(sharing > 1) {
-      size_t free_b = 0, total_b = 0;
-      PM_HIP(hipMemGetInfo(&free_b, &total_b));
-      workspace = std::min<int64_t>((int64_t)96 << 30, (int64_t)(total_b / 10 * 4)) / sharing;
+      workspace = dp_default_budget_bytes() / sharing;
     }
     std::vector<int64_t> oa((size_t)(hi - lo) + 1), ob((size_t)(hi - lo) + 1);
     for(int64_t k = lo; k <= hi; ++k) {

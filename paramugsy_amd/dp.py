@@ -72,6 +72,7 @@ def _lib():
                                          C.c_int, C.POINTER(C.c_void_p)]
         l.pm_dp_batch_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         l.pm_dp_batch_run_profiled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.pm_dp_batch_fill_busy_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.pm_dp_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_dp_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         l.pm_dp_batch_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -142,6 +143,12 @@ class DpBatch:
         a, b = C.c_float(), C.c_float()
         capi.check(_lib().pm_dp_batch_run_profiled(self._h, 1 if traceback else 0, C.c_void_p(stream), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def fill_busy_ms(self) -> float:
+        """After run_profiled: the time during which some fill kernel ran (the launches of a batch of several chunks overlap)."""
+        v = C.c_float()
+        capi.check(_lib().pm_dp_batch_fill_busy_ms(self._h, C.byref(v)))
+        return v.value
 
     def info(self):
         cells, tb, inp, chunks = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()

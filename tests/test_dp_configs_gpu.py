@@ -96,13 +96,15 @@ def test_pairs_split_over_workgroups_repeat_exactly(n_pairs, rows, L, oracle_bui
         batch.close()
 
 
-@pytest.mark.parametrize("n,budget_gib", [(20000, 8), (100000, 0)])
+@pytest.mark.parametrize("n,budget_gib", [(20000, 8), (100000, 0), (100000, 96)])
 def test_ragged_segment_batch_stand_in_for_config_2(n, budget_gib, oracle_build):
     """Stand-in for BASELINE.json configs[2] ("~100 k segment profile alignments"; nucmer is not in the image): ragged 4-row
     pairs, lengths log-normal (median 1 500, sigma 0.6, clipped to [200, 8 000]), lb = la * (1 + N(0, 0.05)) -- at the full
-    100 000 pairs with the default workspace budget (what bench.py's `c2` runs; the columns are drawn on the GPU,
-    paramugsy_amd/synth_device.py), and at 20 000 pairs with 8 GiB.  Either way the batch is cut into at least three workspace
-    chunks and the sample holds the pairs either side of every chunk border."""
+    100 000 pairs with the default workspace budget (what bench.py's `c2` runs: 139 GB of checkpoints, ONE chunk in the default
+    60 % of the device's memory; the columns are drawn on the GPU, paramugsy_amd/synth_device.py), the same batch with 96 GiB
+    (chunks of a third of that, their fill kernels overlapping on three streams), and 20 000 pairs with 8 GiB.  With a budget
+    given the batch is cut into at least three workspace chunks and the sample holds the pairs either side of every chunk
+    border."""
     rows = 4
     la, lb = dp.ragged_lengths(20261003, n)
     if n > 20000:
@@ -113,7 +115,7 @@ def test_ragged_segment_batch_stand_in_for_config_2(n, budget_gib, oracle_build)
     params = dp.make_params(rows, rows)
     batch = dp.DpBatch(inputs, params, tb_budget_bytes=budget_gib << 30)
     chunks, porder = batch.chunks()
-    assert len(chunks) - 1 >= 3
+    assert len(chunks) - 1 >= (3 if budget_gib else 1)
     assert sorted(porder.tolist()) == list(range(n))  # a permutation: longest pairs first
     batch.run(traceback=True)
     scores, ops, n_ops = batch.fetch()

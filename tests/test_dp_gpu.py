@@ -89,6 +89,38 @@ def test_chunked_workspace_gives_same_results(mode, oracle_build, monkeypatch):
     assert np.array_equal(s1, s2) and all(np.array_equal(a, b) for a, b in zip(p1, p2))
 
 
+@pytest.mark.parametrize("slots", ["2", "3", "5"])
+@pytest.mark.parametrize("one_stream", [False, True])
+def test_chunks_on_overlapping_fill_streams_repeat_exactly(slots, one_stream, oracle_build, monkeypatch):
+    """A batch of several chunks: the workspace in 2, 3 or 5 parts, the fill kernels of every part on a stream of their own
+    (chunk c + 1's kernel starts while chunk c's drains; it waits only for the path kernel that frees its part) or all on the
+    caller's stream -- the oracle's scores and paths whichever way, run after run on the same batch, and on a caller's stream
+    that is not the null stream."""
+    import pyoracle
+    import torch
+    monkeypatch.setenv("PM_DP_SLOTS", slots)
+    if one_stream:
+        monkeypatch.setenv("PM_DP_ONE_FILL_STREAM", "1")
+    inputs = dp.synth_pairs(781, 120, 4, 700, indel_rate=0.02, vary_length=True)
+    params = dp.make_params(4, 4)
+    o_scores, o_paths = pyoracle.dp_align(inputs, params)
+    batch = dp.DpBatch(inputs, params, tb_budget_bytes=6 << 20)
+    assert batch.info()["chunks"] >= 2 * int(slots)
+    side = torch.cuda.Stream()
+    for rep in range(4):
+        stream = side.cuda_stream if rep & 1 else 0
+        if rep == 3:
+            ms_fill, ms_path = batch.run_profiled(True, stream)
+            assert 0 < batch.fill_busy_ms() <= ms_fill * 1.001
+        else:
+            batch.run(True, stream)
+        scores, ops, n_ops = batch.fetch()
+        assert np.array_equal(scores, o_scores), rep
+        paths = batch.paths(ops, n_ops)
+        assert all(np.array_equal(a, b) for a, b in zip(paths, o_paths)), rep
+    batch.close()
+
+
 @pytest.mark.parametrize("waves", ["1", "2", "4", "8", "16"])
 @pytest.mark.parametrize("cols", ["8", "16"])
 @pytest.mark.parametrize("dot4", ["0", "1"])
