@@ -41,6 +41,13 @@ struct pm_dp_batch {
   // chunk pipeline (more than one chunk): the workspace is n_slots equal parts, chunk c uses part c % n_slots; the path kernel of
   // chunk c runs on `path_stream` beside the fill kernels of the chunks after it
   pm::i64 tb_half_words = 0;
+  // where every chunk's part of the workspace starts (words).  A batch whose workspace fits the budget but is cut into chunks all
+  // the same (dp_batch_plan: so that the path kernel of one chunk runs beside the fill kernel of the next) gives every chunk a
+  // part of its own (slot_reuse false); a batch that does not fit reuses n_slots parts in turn
+  std::vector<pm::i64> chunk_base;
+  bool slot_reuse = false;
+  std::vector<pm::i64> chunk_groups; // workgroups of every chunk's fill launch (filled in by dp_run as it launches)
+  pm::DevBuf fill_started;           // per chunk: workgroups of its fill kernel that have started (the gate of the next chunk's)
   hipStream_t path_stream = nullptr;
   // the fill kernels of every slot run on a stream of their own, so that chunk c + 1's first wavefronts take the SIMDs chunk c's
   // last ones leave (a launch ends with the chip draining: its last round of pairs fills only part of it); ev_begin orders that

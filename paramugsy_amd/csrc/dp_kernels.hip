@@ -90,8 +90,12 @@ template <int C, int MODE, bool DOT4, int NW, bool UNI>
 __global__ void __launch_bounds__(64 * NW)
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
-               int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P, int ng, int *__restrict__ gprog) {
+               int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P, int ng, int *__restrict__ gprog,
+               int *__restrict__ started) {
   static_assert(C % 8 == 0, "whole traceback words per lane per step");
+  if(started && threadIdx.x == 0) { // dp_gate_kernel: once every workgroup of this launch has started, the next chunk's may
+    __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   constexpr bool TRACE = MODE == DP_MODE_BITS;
   constexpr bool CKPT = MODE == DP_MODE_CKPT;
   constexpr int TBW = C / 8;
@@ -945,10 +949,21 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // of the next (dp_run)
   // the workspace is allocated to what the chunks need; if the device cannot give that much (other allocations beside this
   // batch) the budget is halved and the batch cut into more chunks, down to 256 MiB
+  // A batch that fits is ONE chunk: one fill launch, one path launch.  Cutting it all the same (PM_DP_SPLIT=N: N chunks of about
+  // equal workspace, each with a part of its own, the path kernel of one beside the fill kernel of the next, nothing lost at the
+  // cuts thanks to dp_gate_kernel) was measured and does not pay: the path kernel is real work for the same SIMDs, it takes as
+  // long beside a fill kernel as it saves, and small path launches are slower (profiles/r03_dp_chunks.txt: the ragged 100 k-pair
+  // batch 109.6 ms whole, 108.1 in 3, 110.7 in 9; 10 k pairs of 2 x 1 kbp 2.88 ms whole, 3.28 in 2).
+  i64 split = 1;
+  if(const char *e = getenv("PM_DP_SPLIT")) {
+    const i64 v = atoll(e);
+    split = v >= 1 && v <= 64 && !staged ? std::min<i64>(v, std::max<i64>(n_pairs, 1)) : split;
+  }
   bool pipelined = false;
   for(i64 budget = h->tb_budget_bytes;; budget /= 2) {
     const bool one_chunk = total_words <= budget / 4;
-    const i64 budget_words = one_chunk ? budget / 4 : budget / (4 * h->n_slots);
+    const i64 budget_words = one_chunk ? (total_words + split - 1) / split + 64 : budget / (4 * h->n_slots);
+    h->slot_reuse = !one_chunk;
     // chunk_first: positions in `order`; chunk_tb: the word offset of every position's pair inside its chunk's workspace
     h->chunk_first.assign(1, 0);
     h->chunk_tb.clear();
@@ -972,7 +987,12 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     h->tb_words_cap = std::max(h->tb_words_cap, used);
     pipelined = h->chunk_tb.size() > 1;
     h->tb_half_words = pipelined ? ((h->tb_words_cap + 63) / 64) * 64 : 0;
-    const int rc = grow(h->tb, (size_t)(pipelined ? std::min<i64>(h->n_slots, (i64)h->chunk_tb.size()) * h->tb_half_words : h->tb_words_cap) * 4);
+    const i64 parts = pipelined ? (h->slot_reuse ? std::min<i64>(h->n_slots, (i64)h->chunk_tb.size()) : (i64)h->chunk_tb.size()) : 1;
+    h->chunk_base.assign(h->chunk_tb.size(), 0);
+    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+      h->chunk_base[c] = pipelined ? (i64)(h->slot_reuse ? c % (size_t)h->n_slots : c) * h->tb_half_words : 0;
+    }
+    const int rc = grow(h->tb, (size_t)(pipelined ? parts * h->tb_half_words : h->tb_words_cap) * 4);
     if(rc == PM_OK) {
       break;
     }
@@ -1138,8 +1158,26 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
 
 } // extern "C"
 
-// The fill kernel of chunk c into workspace `tbw`.
-static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int traceback, hipStream_t stream) {
+// In front of the fill kernel of chunk c + 1, on its stream: holds it back until every workgroup of chunk c's fill kernel has
+// STARTED, i.e. until that launch has nothing left to dispatch and the chip begins to drain -- chunk c + 1's workgroups then take
+// the SIMDs as they fall free, instead of competing with chunk c's from the start (two fill kernels side by side would both
+// finish late, and the path kernel of chunk c with them) or waiting for the last of them to end (the drain left idle).  One lane
+// polls.  Nothing depends on it for correctness, so the wait is simply bounded (about a second).
+__global__ void dp_gate_kernel(const int *__restrict__ started, int total) {
+  if(threadIdx.x == 0) {
+    for(unsigned spins = 0; spins < (1u << 18); ++spins) {
+      if(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) {
+        break;
+      }
+      __builtin_amdgcn_s_sleep(127);
+    }
+  }
+}
+
+// The fill kernel of chunk c into workspace `tbw`.  started: the chunk's counter of started workgroups, or null; *groups: the launch's
+// workgroups.
+static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int traceback, hipStream_t stream, int *started = nullptr,
+                          i64 *groups = nullptr) {
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
   // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
@@ -1203,7 +1241,8 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
   dp_fill_kernel<CC, TR, D4, NWV, UN><<<(unsigned)(n * ng), 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,    \
                                                                                    (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p,    \
                                                                                    order, tb_off, tbw, (int2 *)h->bnd.p, (int *)h->scores.p, \
-                                                                                   (int *)h->pipe_error.p, h->params, ng, (int *)h->gprog.p)
+                                                                                   (int *)h->pipe_error.p, h->params, ng, (int *)h->gprog.p, \
+                                                                                   started)
 #define DP_LAUNCH_FILL_D4(CC, TR, NWV)         \
   if(h->dot4 && h->uni) {                      \
     DP_LAUNCH_FILL(CC, TR, true, NWV, true);   \
@@ -1256,6 +1295,9 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
 #undef DP_LAUNCH_FILL_D4
 #undef DP_LAUNCH_FILL
   PM_HIP(hipGetLastError());
+  if(groups) {
+    *groups = n * ng;
+  }
   return PM_OK;
 }
 
@@ -1325,23 +1367,34 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
   // of the workspace, not by the fill kernel of the chunk before it
   const int K = h->n_slots;
   const bool two_fills = pipelined && (int)h->fill_streams.size() >= K - 1 && h->ev_begin && h->seg_first.empty();
+  int *started = nullptr;
   if(two_fills) {
+    PM_TRY(grow(h->fill_started, nc * sizeof(int)));
+    started = (int *)h->fill_started.p;
+    PM_HIP(hipMemsetAsync(started, 0, nc * sizeof(int), stream)); // ordered before every fill stream's work by ev_begin
+    h->chunk_groups.assign(nc, 0);
     PM_HIP(hipEventRecord(h->ev_begin, stream));
     for(int k = 0; k < K - 1; ++k) {
       PM_HIP(hipStreamWaitEvent(h->fill_streams[(size_t)k], h->ev_begin, 0));
     }
   }
+  static const bool gate_on = getenv("PM_DP_NO_GATE") == nullptr;
+  long prev_chunk = -1; // the last chunk that had pairs
   hipStream_t caller_stream = stream;
   for(size_t c = 0; c < nc; ++c) {
     if(h->chunk_first[c + 1] - h->chunk_first[c] <= 0) {
       continue;
     }
     const size_t slot = c % (size_t)K;
-    unsigned *tbw = tb + (h->tb_half_words ? (i64)slot * h->tb_half_words : 0);
+    unsigned *tbw = tb + (c < h->chunk_base.size() ? h->chunk_base[c] : 0);
     hipStream_t ps = pipelined ? h->path_stream : caller_stream;
     stream = two_fills && slot ? h->fill_streams[slot - 1] : caller_stream; // this chunk's fill stream
-    if(pipelined && c >= (size_t)K) {
+    if(pipelined && h->slot_reuse && c >= (size_t)K) {
       PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c - (size_t)K], 0)); // the part is free again
+    }
+    if(two_fills && gate_on && prev_chunk >= 0 && h->chunk_groups[(size_t)prev_chunk] > 0) {
+      dp_gate_kernel<<<1, 64, 0, stream>>>(started + prev_chunk, (int)std::min<i64>(h->chunk_groups[(size_t)prev_chunk], 0x7fffffff));
+      PM_HIP(hipGetLastError());
     }
     if(timed) {
       PM_HIP(hipEventRecord(h->tv_fill0[c], stream));
@@ -1362,8 +1415,14 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
         at = s_hi;
       }
       if(at < c_hi) {
-        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream));
+        const bool whole = at == c_lo; // one launch for the chunk: the next chunk's gate can count its workgroups
+        i64 groups = 0;
+        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, two_fills && whole ? started + c : nullptr, &groups));
+        if(two_fills && whole) {
+          h->chunk_groups[c] = groups;
+        }
       }
+      prev_chunk = (long)c;
     }
     if(timed) {
       PM_HIP(hipEventRecord(h->tv_fill1[c], stream));
