@@ -985,6 +985,8 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     h->chunk_tb.push_back(cur);
     h->chunk_first.push_back(n_pairs);
     h->tb_words_cap = std::max(h->tb_words_cap, used);
+    // (cutting the last chunk once more, so that the path kernel that runs alone at the very end is a short one, was measured and
+    // costs more than it saves: the headline batch 310.2 -> 312.4 ms, profiles/r03_dp_chunks.txt)
     pipelined = h->chunk_tb.size() > 1;
     h->tb_half_words = pipelined ? ((h->tb_words_cap + 63) / 64) * 64 : 0;
     const i64 parts = pipelined ? (h->slot_reuse ? std::min<i64>(h->n_slots, (i64)h->chunk_tb.size()) : (i64)h->chunk_tb.size()) : 1;
