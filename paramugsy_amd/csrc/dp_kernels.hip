@@ -1380,7 +1380,7 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       PM_HIP(hipStreamWaitEvent(h->fill_streams[(size_t)k], h->ev_begin, 0));
     }
   }
-  static const bool gate_on = getenv("PM_DP_NO_GATE") == nullptr;
+  const bool gate_on = getenv("PM_DP_NO_GATE") == nullptr;
   long prev_chunk = -1; // the last chunk that had pairs
   hipStream_t caller_stream = stream;
   for(size_t c = 0; c < nc; ++c) {

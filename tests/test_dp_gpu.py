@@ -121,6 +121,27 @@ def test_chunks_on_overlapping_fill_streams_repeat_exactly(slots, one_stream, or
     batch.close()
 
 
+@pytest.mark.parametrize("gate", [True, False])
+def test_batch_that_fits_cut_into_chunks_with_parts_of_their_own(gate, oracle_build, monkeypatch):
+    """PM_DP_SPLIT=N cuts a batch whose workspace fits the budget into N chunks, every one with its own part of the workspace (no
+    part is reused, so no fill kernel waits for a path kernel); with and without the gate kernel in front of the fill kernels."""
+    import pyoracle
+    monkeypatch.setenv("PM_DP_SPLIT", "5")
+    if not gate:
+        monkeypatch.setenv("PM_DP_NO_GATE", "1")
+    inputs = dp.synth_pairs(782, 90, 4, 650, indel_rate=0.02, vary_length=True)
+    params = dp.make_params(4, 4)
+    o_scores, o_paths = pyoracle.dp_align(inputs, params)
+    batch = dp.DpBatch(inputs, params)
+    assert batch.info()["chunks"] in (4, 5, 6)
+    for rep in range(3):
+        batch.run(True)
+        scores, ops, n_ops = batch.fetch()
+        assert np.array_equal(scores, o_scores), rep
+        assert all(np.array_equal(a, b) for a, b in zip(batch.paths(ops, n_ops), o_paths)), rep
+    batch.close()
+
+
 @pytest.mark.parametrize("waves", ["1", "2", "4", "8", "16"])
 @pytest.mark.parametrize("cols", ["8", "16"])
 @pytest.mark.parametrize("dot4", ["0", "1"])

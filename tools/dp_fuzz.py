@@ -19,7 +19,12 @@ from paramugsy_amd import dp  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 KNOBS = {"PM_DP_MODE": ["ckpt", "ckpt", "bits", None], "PM_DP_COLS": ["8", "16", None], "PM_DP_WAVES": ["1", "2", "4", "8", "16", None, None],
-         "PM_DP_GROUPS": ["1", "2", "4", "8", None, None], "PM_DP_BAND": ["0", "1", None], "PM_DP_WALK_LANES": ["4", "8", "16", "32", None, None]}
+         "PM_DP_GROUPS": ["1", "2", "4", "8", None, None], "PM_DP_BAND": ["0", "1", None], "PM_DP_WALK_LANES": ["4", "8", "16", "32", None, None],
+         # the chunk pipeline (these matter for the resident batch when the case draws a small workspace budget, below): parts of the
+         # workspace, the fill kernels of every part on a stream of their own or not, the gate kernel in front of them or not, a batch
+         # that fits cut into chunks all the same
+         "PM_DP_SLOTS": ["2", "3", "4", None, None], "PM_DP_ONE_FILL_STREAM": ["1", None, None, None], "PM_DP_NO_GATE": ["1", None, None],
+         "PM_DP_SPLIT": ["2", "3", "5", None, None, None]}
 
 
 def random_case(rng):
@@ -120,7 +125,11 @@ while time.time() < t_end:
             paths = dp.paths_of(inputs, ops, n_ops)
             v = {"checkpoints": "?", "cols_per_lane": "?"}
         else:
-            b = dp.DpBatch(inputs, p)
+            # a third of the resident batches with a workspace budget that cuts them into several chunks
+            small = rng.random() < 0.33
+            b = dp.DpBatch(inputs, p, tb_budget_bytes=int(rng.choice([1, 4, 16])) << 20 if small else 0)
+            if small:
+                env = dict(env, chunks=b.info()["chunks"])
             b.run(True)
             scores, ops, n_ops = b.fetch()
             paths = b.paths(ops, n_ops)
