@@ -1179,7 +1179,7 @@ __global__ void dp_gate_kernel(const int *__restrict__ started, int total) {
 // The fill kernel of chunk c into workspace `tbw`.  started: the chunk's counter of started workgroups, or null; *groups: the launch's
 // workgroups.
 static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int traceback, hipStream_t stream, int *started = nullptr,
-                          i64 *groups = nullptr) {
+                          i64 *groups = nullptr, bool allow_groups = true) {
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
   // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
@@ -1212,7 +1212,9 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
       hipDeviceProp_t prop;
       return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
     }();
-    const int groups_env = getenv("PM_DP_GROUPS") ? atoi(getenv("PM_DP_GROUPS")) : -1; // 1: never; 2, 4, ..: that many
+    // (allow_groups false: the launch may run beside another fill launch of this batch -- dp_run's fill streams -- and several
+    // workgroups per pair need every workgroup of the launch resident, and the batch's one set of progress words to themselves)
+    const int groups_env = !allow_groups ? 1 : (getenv("PM_DP_GROUPS") ? atoi(getenv("PM_DP_GROUPS")) : -1); // 1: never; 2, 4, ..: that many
     if(fits && groups_env > 1 && h->waves_override >= 2 && n * groups_env <= cus) { // both forced (tests)
       ng = groups_env;
     }
@@ -1419,7 +1421,7 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       if(at < c_hi) {
         const bool whole = at == c_lo; // one launch for the chunk: the next chunk's gate can count its workgroups
         i64 groups = 0;
-        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, two_fills && whole ? started + c : nullptr, &groups));
+        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, two_fills && whole ? started + c : nullptr, &groups, !two_fills));
         if(two_fills && whole) {
           h->chunk_groups[c] = groups;
         }

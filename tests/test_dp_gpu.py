@@ -142,6 +142,27 @@ def test_batch_that_fits_cut_into_chunks_with_parts_of_their_own(gate, oracle_bu
     batch.close()
 
 
+@pytest.mark.parametrize("mode", ["bits", "ckpt"])
+def test_few_long_pairs_in_chunks_on_overlapping_streams_keep_one_workgroup_per_pair(mode, oracle_build, monkeypatch):
+    """Found by tools/dp_fuzz.py (seed 900234): two long pairs cut into two chunks whose fill launches overlap, each launch asked for
+    several workgroups per pair -- which need every workgroup of the launch resident and share the batch's one set of progress
+    words.  Launches that may overlap keep one workgroup per pair."""
+    import pyoracle
+    for k, v in (("PM_DP_MODE", mode), ("PM_DP_WAVES", "4"), ("PM_DP_GROUPS", "8"), ("PM_DP_SLOTS", "4"), ("PM_DP_SPLIT", "5")):
+        monkeypatch.setenv(k, v)
+    inputs = dp.synth_batch(900234, np.array([4213, 4534]), np.array([1424, 1399]), 8, 8)
+    params = dp.make_params(8, 8)
+    o_scores, o_paths = pyoracle.dp_align(inputs, params)
+    batch = dp.DpBatch(inputs, params)
+    assert batch.info()["chunks"] == 2
+    for rep in range(3):
+        batch.run(True)
+        scores, ops, n_ops = batch.fetch()
+        assert np.array_equal(scores, o_scores), rep
+        assert all(np.array_equal(a, b) for a, b in zip(batch.paths(ops, n_ops), o_paths)), rep
+    batch.close()
+
+
 @pytest.mark.parametrize("waves", ["1", "2", "4", "8", "16"])
 @pytest.mark.parametrize("cols", ["8", "16"])
 @pytest.mark.parametrize("dot4", ["0", "1"])
