@@ -18,10 +18,6 @@ lib: $(LIB)
 OBJDIR    = build/obj
 LIB_OBJS  = $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(LIB_SRCS))
 
-# the make stage (profiles_make.hip) does all its device work on the default stream with blocking copies, and a tree node runs
-# its two makes in two host threads: with the per-thread default stream they stop waiting for each other's copies
-$(OBJDIR)/profiles_make.hip.o: HIPFLAGS += -fgpu-default-stream=per-thread
-
 $(OBJDIR)/%.hip.o: $(CSRC)/%.hip $(LIB_HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
