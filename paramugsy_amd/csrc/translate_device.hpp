@@ -432,32 +432,9 @@ struct Sink {
   I stage_lo;
 
   PM_HD __forceinline__ void stage_write(i64 g_first, i64 g_end) { // the staged offsets with global indices [g_first, g_end)
-    i64 g = g_first;
-    for(; g < g_end && (g & (S - 1)) != 0; ++g) { // up to the first sector boundary
-      off[g] = stage[(int)(g & (T - 1)) * stage_stride];
-    }
-    for(; g + S <= g_end; g += S) { // whole sectors
-      const I *src = stage + (int)(g & (T - 1)) * stage_stride;
-      I *dst = off + g;
-#ifdef __HIP_DEVICE_COMPILE__
-      struct alignas(16) Half {
-        I v[S / 2];
-      };
-      Half lo, hi; // the array starts on a sector (hipMalloc), g is a multiple of S: two 16-byte stores
-#pragma unroll
-      for(int k = 0; k < S / 2; ++k) {
-        lo.v[k] = src[k * stage_stride];
-        hi.v[k] = src[(k + S / 2) * stage_stride];
-      }
-      reinterpret_cast<Half *>(dst)[0] = lo;
-      reinterpret_cast<Half *>(dst)[1] = hi;
-#else
-      for(int k = 0; k < S; ++k) {
-        dst[k] = src[k * stage_stride];
-      }
-#endif
-    }
-    for(; g < g_end; ++g) { // the tail
+    // one store per offset, back to back: the stores of a sector reach the L2 together and leave it as one write (a 16-byte
+    // vector path for whole sectors cost the kernel 40 registers -- a third of its resident wavefronts -- and bought nothing)
+    for(i64 g = g_first; g < g_end; ++g) {
       off[g] = stage[(int)(g & (T - 1)) * stage_stride];
     }
   }
