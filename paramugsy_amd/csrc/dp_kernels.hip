@@ -945,8 +945,8 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     h->cells += (h->off_a[k + 1] - h->off_a[k]) * (h->off_b[k + 1] - h->off_b[k]);
   }
   // chunks: consecutive pairs whose workspace fits the budget.  A batch that fits is one chunk; otherwise the budget is cut
-  // in two halves that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernel
-  // of the next (dp_run)
+  // in n_slots parts that consecutive chunks use in turn, so that the path kernel of one chunk can run beside the fill kernels
+  // of the next, and those beside each other where one drains and the next fills in (dp_run)
   // the workspace is allocated to what the chunks need; if the device cannot give that much (other allocations beside this
   // batch) the budget is halved and the batch cut into more chunks, down to 256 MiB
   // A batch that fits is ONE chunk: one fill launch, one path launch.  Cutting it all the same (PM_DP_SPLIT=N: N chunks of about
@@ -1335,10 +1335,12 @@ static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStre
   return PM_OK;
 }
 
-// One pass over every chunk.  One chunk: fill, then path, on `stream`.  Several chunks: fill kernels on `stream`, path kernels
-// on the batch's own stream, chunk c's path beside chunk c + 1's fill (the two halves of the workspace alternate); `stream`
+// One pass over every chunk.  One chunk: fill, then path, on `stream`.  Several chunks: the fill kernels of the workspace's parts
+// on `stream` and on the batch's own fill streams, each behind a gate kernel that lets it go when the chunk before it has nothing
+// left to dispatch; path kernels on the batch's path stream, chunk c's beside the fill kernels of the chunks after it; `stream`
 // ends up waiting for the last path kernels, so the caller sees one asynchronous operation on its stream.
-// Timed: device time of the fill and of the path kernels, summed over the chunks (events around every launch on its stream).
+// Timed: device time of the fill and of the path kernels, summed over the chunks (events around every launch on its stream), and
+// the time during which some fill kernel ran (h->last_fill_busy_ms).
 namespace pm {
 // Default path workspace: 60 % of the device's memory (172 GB of an MI355X's 288 GB).  A launch ends with the chip draining -- the
 // last round of pairs fills only part of it -- so the fewer launches the better: the 100 000 ragged pairs of bench.py's c2 (139 GB
