@@ -234,6 +234,25 @@ def test_unit_list_made_on_the_device_equals_the_hosts_loops(mode, overlap, orac
     job.close()
 
 
+@pytest.mark.parametrize("name", ["typical", "gappy", "reverse", "tiny_blocks", "empty"])
+def test_unit_list_made_on_the_device_on_the_golden_jobs(name):
+    """The five golden jobs (the last one has no work units at all): the device's list = the host's, and a job of zero units runs."""
+    case = os.path.join(GOLDEN, "translate_" + name)
+    with open(os.path.join(case, "nucmer.list")) as f:
+        deltas = [os.path.join(case, ln.strip()) for ln in f if ln.strip()]
+    wl = Workload.load(os.path.join(case, "profiles-l"), os.path.join(case, "profiles-r"), deltas)
+    t = wl.tables()
+    job = TranslateJob.from_workload(wl)
+    assert job.n_units == t.n_units
+    got = job.units()
+    for k in ("delta", "left", "right"):
+        assert np.array_equal(got[k], t.units[k]), k
+    job.run()
+    res = job.fetch()
+    assert len(res.status) == t.n_units and res.all_ok
+    job.close()
+
+
 def test_unit_list_on_the_device_with_sequences_a_side_does_not_have(tmp_path):
     """Entries whose reference or query sequence has no rows on its side yield no units (m_translate.cc:676-681)."""
     w = synth.make_workload(str(tmp_path / "job"), 99, n_left=3, n_right=3, row_prob=1.0)
