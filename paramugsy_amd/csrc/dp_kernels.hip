@@ -798,12 +798,17 @@ int dp_batch_plan(pm_dp_batch *h, hipStream_t stream) {
 }
 
 // lanes per pair of the checkpoint walk for a launch of n pairs: as few as still give the launch about two wavefronts per SIMD
-// (1 024 SIMDs)
+// (1 024 SIMDs) -- but at least as many as leave a lane four columns of a block: with eight columns per lane a block's decisions
+// are 4-byte words, the workgroup's LDS 24 KB, and a CU holds six wavefronts of a kernel that lives on hiding latency (the ragged
+// 100 k-pair batch's walk, alone on the chip: 18.8 ms with 8 lanes per pair, 15.0 with 16; the headline batch 329 -> 312 ms per step)
 static int dp_walk_lanes_for(const pm_dp_batch *h, i64 n) {
   int lpp = h->walk_lanes;
   if(lpp == 0) {
     lpp = 2;
     while(!dp_walk_lanes_ok(h->cols_per_lane, lpp)) {
+      lpp *= 2;
+    }
+    while(lpp < 32 && h->cols_per_lane * DP_CK_W / lpp > 4 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2)) {
       lpp *= 2;
     }
     while(lpp < 32 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp <= 2 * 1024 * 64) {
