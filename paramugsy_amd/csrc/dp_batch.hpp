@@ -46,6 +46,13 @@ struct pm_dp_batch {
   // part of its own (slot_reuse false); a batch that does not fit reuses n_slots parts in turn
   std::vector<pm::i64> chunk_base;
   bool slot_reuse = false;
+  // The longest pairs of a chunk in launches of their own (dp_batch_plan): a wavefront works through its pair's stripes one after the
+  // other, so a launch lasts at least as long as its longest pair -- in a ragged launch of 12 500 pairs that pair alone took as long
+  // as all the others together.  chunk_tiers[c]: positions (in `order`) where the chunk's launch is cut: the first few hundred pairs
+  // run in small launches, for which dp_launch_fill chooses several wavefronts per pair, on side streams beside the launch of the rest
+  std::vector<std::vector<pm::i64> > chunk_tiers;
+  std::vector<hipStream_t> tier_streams;
+  std::vector<hipEvent_t> tier_events;
   std::vector<pm::i64> chunk_groups; // workgroups of every chunk's fill launch (filled in by dp_run as it launches)
   pm::DevBuf fill_started;           // per chunk: workgroups of its fill kernel that have started (the gate of the next chunk's)
   hipStream_t path_stream = nullptr;
@@ -80,6 +87,12 @@ struct pm_dp_batch {
     }
     for(hipStream_t st : fill_streams) {
       (void)hipStreamDestroy(st);
+    }
+    for(hipStream_t st : tier_streams) {
+      (void)hipStreamDestroy(st);
+    }
+    for(hipEvent_t e : tier_events) {
+      (void)hipEventDestroy(e);
     }
     if(ev_begin) {
       (void)hipEventDestroy(ev_begin);

@@ -1039,6 +1039,65 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       h->ev_path.push_back(b);
     }
   }
+  // tiers of long pairs (dp_batch.hpp): per chunk, the pairs that alone would take more than half of what the launch takes when the
+  // chip is evenly loaded (steps of all its pairs / 4 096 wavefronts) go first, in launches of at most 256, 512 and 1 024 pairs --
+  // small enough for dp_launch_fill to give them 8, 4 and 2 wavefronts each.  Uniform batches have no such pairs.  PM_DP_NO_TIERS=1: not.
+  h->chunk_tiers.assign(h->chunk_tb.size(), std::vector<i64>());
+  if(h->seg_first.empty() && !staged && !getenv("PM_DP_NO_TIERS") && !getenv("PM_DP_KEEP_ORDER") && h->waves_override == 0) {
+    bool any = false;
+    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+      const i64 c_lo = h->chunk_first[c], c_hi = h->chunk_first[c + 1], n = c_hi - c_lo;
+      if(n < 4096) {
+        continue; // dp_launch_fill already gives such a launch several wavefronts per pair
+      }
+      auto cost_at = [&](i64 q) {
+        const i64 k = h->order[(size_t)q];
+        return dp_ck_stripes(h->off_b[k + 1] - h->off_b[k], h->cols_per_lane) * (h->off_a[k + 1] - h->off_a[k] + 63);
+      };
+      double total = 0;
+      for(i64 q = c_lo; q < c_hi; ++q) {
+        total += (double)cost_at(q);
+      }
+      // only a launch that its longest pair bounds: that pair's steps against the steps every wavefront gets when the chip is
+      // evenly loaded.  A wavefront that has a SIMD to itself steps about three times as fast as one of five sharing it, so the
+      // longest pair finishes with the others up to a ratio of about three (measured on the ragged stand-in: ratio 3.9 at
+      // 12 500 pairs, 1 877 -> 2 625 GCUPS with the tiers; 1.9 at 25 000 pairs, 3 550 -> 3 386: the launches of several
+      // wavefronts per pair are the less efficient ones)
+      if((double)cost_at(c_lo) < 3.0 * total / 4096.0) {
+        continue;
+      }
+      const double limit = total / 4096.0 / 2.0;
+      i64 heavy = 0; // the order is longest first: the heavy pairs are a prefix
+      while(heavy < n && heavy < 1792 && (double)cost_at(c_lo + heavy) > limit) {
+        ++heavy;
+      }
+      if(heavy == 0 || heavy * 2 > n) {
+        continue;
+      }
+      std::vector<i64> &cuts = h->chunk_tiers[c];
+      i64 at = 0;
+      for(i64 size : {(i64)256, (i64)512, (i64)1024}) {
+        if(at >= heavy) {
+          break;
+        }
+        at = std::min(heavy, at + size);
+        cuts.push_back(c_lo + at);
+      }
+      any = true;
+    }
+    if(any) {
+      while(h->tier_streams.size() < 3) {
+        hipStream_t st = nullptr;
+        PM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        h->tier_streams.push_back(st);
+      }
+      while(h->tier_events.size() < 4) {
+        hipEvent_t e = nullptr;
+        PM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->tier_events.push_back(e);
+      }
+    }
+  }
   // the workspace offset of every pair (indexed by pair) and the processing order go to the device
   {
     const size_t npad = (size_t)std::max<i64>(n_pairs, 1);
@@ -1424,6 +1483,24 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
         }
         PM_TRY(dp_launch_fill(h, at, s_hi - at, tbw, traceback, stream));
         at = s_hi;
+      }
+      // the chunk's longest pairs in small launches of their own, on side streams, beside the launch of the rest
+      if(at == c_lo && c < h->chunk_tiers.size() && !h->chunk_tiers[c].empty() && h->tier_streams.size() >= h->chunk_tiers[c].size() &&
+         !h->tier_events.empty()) {
+        const std::vector<i64> &cuts = h->chunk_tiers[c];
+        PM_HIP(hipEventRecord(h->tier_events[0], stream)); // whatever this chunk's fill waits for, the side streams wait for too
+        for(size_t tier = 0; tier < cuts.size(); ++tier) {
+          hipStream_t ts = h->tier_streams[tier];
+          PM_HIP(hipStreamWaitEvent(ts, h->tier_events[0], 0));
+          PM_TRY(dp_launch_fill(h, at, cuts[tier] - at, tbw, traceback, ts, nullptr, nullptr, false));
+          PM_HIP(hipEventRecord(h->tier_events[1 + tier], ts));
+          at = cuts[tier];
+        }
+        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, nullptr, nullptr, false));
+        for(size_t tier = 0; tier < cuts.size(); ++tier) {
+          PM_HIP(hipStreamWaitEvent(stream, h->tier_events[1 + tier], 0));
+        }
+        at = c_hi;
       }
       if(at < c_hi) {
         const bool whole = at == c_lo; // one launch for the chunk: the next chunk's gate can count its workgroups

@@ -96,13 +96,15 @@ def test_pairs_split_over_workgroups_repeat_exactly(n_pairs, rows, L, oracle_bui
         batch.close()
 
 
-@pytest.mark.parametrize("n,budget_gib", [(20000, 8), (100000, 0), (100000, 96)])
+@pytest.mark.parametrize("n,budget_gib", [(12500, 0), (20000, 8), (100000, 0), (100000, 96)])
 def test_ragged_segment_batch_stand_in_for_config_2(n, budget_gib, oracle_build):
     """Stand-in for BASELINE.json configs[2] ("~100 k segment profile alignments"; nucmer is not in the image): ragged 4-row
     pairs, lengths log-normal (median 1 500, sigma 0.6, clipped to [200, 8 000]), lb = la * (1 + N(0, 0.05)) -- at the full
     100 000 pairs with the default workspace budget (what bench.py's `c2` runs: 139 GB of checkpoints, ONE chunk in the default
     60 % of the device's memory; the columns are drawn on the GPU, paramugsy_amd/synth_device.py), the same batch with 96 GiB
-    (chunks of a third of that, their fill kernels overlapping on three streams), and 20 000 pairs with 8 GiB.  With a budget
+    (chunks of a third of that, their fill kernels overlapping on three streams), 20 000 pairs with 8 GiB, and 12 500 pairs -- one
+    GPU's eighth of the batch, configs[3]'s per-GPU share: a launch its longest pair bounds, so the longest pairs run in small
+    launches of several wavefronts per pair beside the rest (dp_batch_plan's tiers; the sample holds pairs of every tier).  With a budget
     given the batch is cut into at least three workspace chunks and the sample holds the pairs either side of every chunk
     border."""
     rows = 4
@@ -121,7 +123,7 @@ def test_ragged_segment_batch_stand_in_for_config_2(n, budget_gib, oracle_build)
     scores, ops, n_ops = batch.fetch()
     paths = batch.paths(ops, n_ops)
     order = np.argsort(la * lb)
-    sample = [0, n - 1, order[0], order[-1], order[n // 2], porder[0], porder[-1]]
+    sample = [0, n - 1, order[0], order[-1], order[n // 2], porder[0], porder[-1], porder[100], porder[300], porder[600], porder[1500], porder[2500]]
     for c in range(1, len(chunks) - 1):
         sample += [porder[chunks[c] - 1], porder[chunks[c]]]
     small = [int(k) for k in order[:3]] + [int(order[n // 2])]
