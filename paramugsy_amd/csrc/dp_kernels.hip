@@ -1040,8 +1040,9 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     }
   }
   // tiers of long pairs (dp_batch.hpp): per chunk, the pairs that alone would take more than half of what the launch takes when the
-  // chip is evenly loaded (steps of all its pairs / 4 096 wavefronts) go first, in launches of at most 256, 512 and 1 024 pairs --
-  // small enough for dp_launch_fill to give them 8, 4 and 2 wavefronts each.  Uniform batches have no such pairs.  PM_DP_NO_TIERS=1: not.
+  // chip is evenly loaded (steps of all its pairs / 4 096 wavefronts) go first, in launches of at most 256 and 512 pairs -- small
+  // enough for dp_launch_fill to give them 8 and 4 wavefronts each (a third launch of the next 1 024 pairs, at 4 wavefronts each,
+  // was the last to finish: 14.2 ms beside 11.6 for the rest).  Uniform batches have no such pairs.  PM_DP_NO_TIERS=1: not.
   h->chunk_tiers.assign(h->chunk_tb.size(), std::vector<i64>());
   if(h->seg_first.empty() && !staged && !getenv("PM_DP_NO_TIERS") && !getenv("PM_DP_KEEP_ORDER") && h->waves_override == 0) {
     bool any = false;
@@ -1068,7 +1069,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       }
       const double limit = total / 4096.0 / 2.0;
       i64 heavy = 0; // the order is longest first: the heavy pairs are a prefix
-      while(heavy < n && heavy < 1792 && (double)cost_at(c_lo + heavy) > limit) {
+      while(heavy < n && heavy < 768 && (double)cost_at(c_lo + heavy) > limit) {
         ++heavy;
       }
       if(heavy == 0 || heavy * 2 > n) {
@@ -1076,7 +1077,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       }
       std::vector<i64> &cuts = h->chunk_tiers[c];
       i64 at = 0;
-      for(i64 size : {(i64)256, (i64)512, (i64)1024}) {
+      for(i64 size : {(i64)256, (i64)512}) {
         if(at >= heavy) {
           break;
         }
