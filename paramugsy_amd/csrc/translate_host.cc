@@ -14,6 +14,7 @@
 // files (lib/profiles/m_profile.ml:122-135 printf "%d"; MUMmer) never emit such tokens.
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <functional>
 #include <iterator>
 #include <cerrno>
@@ -600,9 +601,26 @@ static void build_enum_tables(const Side &left, const Side &right, const DeltaTa
       et.entry_seq[sd][d] = last_id;
     }
   };
-  std::thread other(one, 1);
-  one(0);
+  std::exception_ptr failed; // an allocation failure in the helper thread must reach the caller's guard, not std::terminate
+  std::thread other([&]() {
+    try {
+      one(1);
+    }
+    catch(...) {
+      failed = std::current_exception();
+    }
+  });
+  try {
+    one(0);
+  }
+  catch(...) {
+    other.join();
+    throw;
+  }
   other.join();
+  if(failed) {
+    std::rethrow_exception(failed);
+  }
 }
 
 // ------------------------------------------------------------------ text out
@@ -826,9 +844,26 @@ void index_and_enumerate(Workload &w) {
 
 // Only the index: the job lists the units itself (run_workload with w.units_listed false).
 void index_sides(Workload &w) {
-  std::thread other([&]() { build_side_index(w.right); });
-  build_side_index(w.left);
+  std::exception_ptr failed;
+  std::thread other([&]() {
+    try {
+      build_side_index(w.right);
+    }
+    catch(...) {
+      failed = std::current_exception();
+    }
+  });
+  try {
+    build_side_index(w.left);
+  }
+  catch(...) {
+    other.join();
+    throw;
+  }
   other.join();
+  if(failed) {
+    std::rethrow_exception(failed);
+  }
   w.units = UnitList();
   w.units_listed = false;
 }
