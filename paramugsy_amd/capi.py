@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         l.pm_job_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_job_text.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _i64p, _i64p, _i32p]
         l.pm_job_text_fetch.argtypes = [C.c_void_p, C.c_void_p]
+        l.pm_job_text_fetch_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         l.pm_job_algorithmic_bytes.argtypes = [C.c_void_p, _i64p]
         l.pm_job_kernel_bytes.argtypes = [C.c_void_p, _i64p, _i64p, _i64p]
         l.pm_job_coordinate_bits.argtypes = [C.c_void_p, C.POINTER(C.c_int)]

@@ -28,6 +28,7 @@ struct pm_dp_batch {
   bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
   bool uni = false;       // every column of A holds the same number of symbols: gap row folded into the weights (PM_DP_UNI=0 disables)
   int waves_override = 0; // PM_DP_WAVES=1|2|4|8 forces the waves-per-pair choice
+  bool tail = false;      // the narrow last stripes of dp_internal.hpp (checkpoint mode, 16 columns per lane; PM_DP_TAIL=0 disables)
   bool ckpt = true;       // paths from checkpoints + block recomputation (dp_walk.hip), or 4 stored decision bits per cell
   bool mode_auto = true;  // ckpt chosen per batch in dp_batch_plan (PM_DP_MODE=bits|ckpt fixes it)
   int walk_lanes = 0;     // lanes per pair of the checkpoint walk; 0 = chosen per launch; PM_DP_WALK_LANES overrides

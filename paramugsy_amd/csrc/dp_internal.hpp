@@ -44,30 +44,97 @@ struct DpParamsD {
 static_assert((DP_CK_R & (DP_CK_R - 1)) == 0 && DP_CK_R >= 16, "DP_CK_R is a power of two");
 static_assert(DP_CK_W == 1 || DP_CK_W == 2 || DP_CK_W == 4, "DP_CK_W in {1, 2, 4}");
 
-// Words (4 bytes) of checkpoint storage one pair needs.  Per stripe (64 lanes x C columns of B):
+// Stripes.  The columns of B are cut into stripes of 64 lanes x cs columns; a stripe's lane keeps its cs columns in registers
+// while the wavefront sweeps the rows of A.  Full stripes have cs = C columns per lane (C = 16, or 8 for small batches).  A stripe
+// costs (La + 63) steps whatever is left of B, so a ragged batch computed 1.23 x its cells in padding (round 3).  With `tail`
+// (C = 16 only) what is left after the full stripes is therefore cut into NARROWER stripes, in quarters of a full one: up to 256
+// columns left -> one stripe of 4 columns per lane; up to 512 -> one of 8; up to 768 -> one of 8 and one of 4; more -> a full one.
+// A step of a narrow stripe costs (6 cs + 5) / 101 of a full stripe's.  Everything below -- the checkpoints' layout, the walk's
+// blocks -- is addressed by COLUMN (or by column group: DP_CK_W * C columns, the width of a block of the walk), so that it is the
+// same whatever the widths of the stripes the columns were computed in.
+struct DpStripe {
+  int jb; // first column of B (0-based)
+  int cs; // columns per lane
+};
+__host__ __device__ inline int dp_tail_quarters(i64 lb, int C, int tail) { // quarters of a full stripe the remainder needs; 0: none
+  const i64 rem = lb % (64 * C);
+  return !tail || C != 16 || rem == 0 ? 0 : (int)((rem + 16 * C - 1) / (16 * C));
+}
+__host__ __device__ inline i64 dp_ck_stripes(i64 lb, int C, int tail) {
+  const int q = dp_tail_quarters(lb, C, tail);
+  return tail && C == 16 ? lb / (64 * C) + (q == 0 ? 0 : (q == 3 ? 2 : 1)) : (lb + 64 * C - 1) / (64 * C);
+}
+__host__ __device__ inline DpStripe dp_stripe(i64 lb, int C, int tail, i64 s) {
+  const i64 full = lb / (64 * C);
+  DpStripe st = {(int)(s * 64 * C), C};
+  if(tail && C == 16 && s >= full) {
+    const int q = dp_tail_quarters(lb, C, tail);
+    if(q == 1) {
+      st.cs = 4;
+    }
+    else if(q == 2) {
+      st.cs = 8;
+    }
+    else if(q == 3) {
+      st.jb = (int)(full * 64 * C) + (s > full ? 32 * C : 0);
+      st.cs = s > full ? 4 : 8;
+    }
+  }
+  return st;
+}
+__host__ __device__ inline DpStripe dp_stripe_of_col(i64 lb, int C, int tail, i64 j) {
+  const i64 full = lb / (64 * C);
+  i64 s = j / (64 * C);
+  if(tail && C == 16 && s >= full && dp_tail_quarters(lb, C, tail) == 3 && j - full * 64 * C >= 32 * C) {
+    s = full + 1;
+  }
+  return dp_stripe(lb, C, tail, s);
+}
+// the columns the stripes cover (the cells computed are this x the rows of A)
+__host__ __device__ inline i64 dp_padded_cols(i64 lb, int C, int tail) {
+  const int q = dp_tail_quarters(lb, C, tail);
+  return tail && C == 16 ? (lb / (64 * C)) * 64 * C + q * 16 * C : ((lb + 64 * C - 1) / (64 * C)) * 64 * C;
+}
+// what a pair costs the wavefront that works through its stripes, in VALU instructions (6 per cell + about 5 per step): the
+// measure of dp_batch_plan's processing order and of its tiers
+__host__ __device__ inline i64 dp_fill_cost(i64 la, i64 lb, int C, int tail) {
+  i64 per_step = 0;
+  const i64 n = dp_ck_stripes(lb, C, tail);
+  for(i64 s = 0; s < n; ++s) {
+    per_step += 6 * dp_stripe(lb, C, tail, s).cs + 5;
+  }
+  return per_step * (la + 63);
+}
+
+// Words (4 bytes) of checkpoint storage one pair needs:
 //   col[group][t]     int2 {H~ - gop, E~} of the group's last column after the row its last lane was on at step t
-//   row[m][lane][c]   int2 {H~ - gop, F~} of column c after the lane's (m + 1)-th checkpoint step
+//   row[stripe][m][j] int2 {H~ - gop, F~} of column j of the stripe after its lane's (m + 1)-th checkpoint step
 __host__ __device__ inline i64 dp_ck_steps(i64 la) { return la + 63; }
 __host__ __device__ inline i64 dp_ck_nck(i64 la) { return (la + 63) / DP_CK_R; }
-__host__ __device__ inline i64 dp_ck_stripes(i64 lb, int C) { return (lb + 64 * C - 1) / (64 * C); }
-__host__ __device__ inline i64 dp_ck_col_words_per_step() { return (64 / DP_CK_W) * 2; }
-__host__ __device__ inline i64 dp_ck_words(i64 la, i64 lb, int C) {
-  return dp_ck_stripes(lb, C) * (dp_ck_steps(la) * dp_ck_col_words_per_step() + dp_ck_nck(la) * 64 * 2 * C);
+__host__ __device__ inline i64 dp_ck_groups(i64 lb, int C, int tail) { return dp_padded_cols(lb, C, tail) / (DP_CK_W * C); }
+__host__ __device__ inline i64 dp_ck_words(i64 la, i64 lb, int C, int tail) {
+  return dp_ck_groups(lb, C, tail) * dp_ck_steps(la) * 2 + dp_ck_nck(la) * dp_padded_cols(lb, C, tail) * 2;
 }
-// column checkpoint of fill lane `lane` (the last of its group) at step t of stripe s.  Layout [stripe][group][step]: the
-// steps of one group are contiguous, which is how all three readers go through them (the next stripe's seam: lane 63's group,
-// 64 rows at a time; the walk's left edge: one group, the rows of a block); the writer's 16 lanes hit 16 lines per step, each
-// line completed by 16 consecutive steps while it sits in L2.  ([step][group] made the seam read 8 bytes of every 128-byte
-// line: 20 GB of FETCH_SIZE on the headline batch.)
-__host__ __device__ inline i64 dp_ck_col_word(i64 la, i64 s, i64 t, int lane) {
-  return ((s * (64 / DP_CK_W) + lane / DP_CK_W) * dp_ck_steps(la) + t) * 2;
+// column checkpoint of column group g (written by the last lane of the group) at step t.  Layout [group][step]: the steps of one
+// group are contiguous, which is how all three readers go through them (the next stripe's seam: lane 63's group, 64 rows at a
+// time; the walk's left edge: one group, the rows of a block); the writer's 16 lanes hit 16 lines per step, each line completed
+// by 16 consecutive steps while it sits in L2.  ([step][group] made the seam read 8 bytes of every 128-byte line: 20 GB of
+// FETCH_SIZE on the headline batch.)
+__host__ __device__ inline i64 dp_ck_col_word(i64 la, i64 g, i64 t) { return (g * dp_ck_steps(la) + t) * 2; }
+// row checkpoint m of column j, which lies in stripe st: [stripe][m][c][lane] with c = the column's place in its lane.  Lane-minor,
+// so that the fill kernel's store of one c is 64 consecutive 8-byte slots (whole lines); [lane][c] made every lane write a line of
+// its own, 8 bytes at a time -- HBM bytes are the same, L2 write requests four times as many, and those are what the fill kernel
+// runs short of (round 4: 2 048 -> 320 requests per wavefront and 64 steps, with the column checkpoints' staging below)
+__host__ __device__ inline i64 dp_ck_row_word(i64 la, i64 lb, int C, int tail, DpStripe st, i64 m, i64 j) {
+  const int r = (int)(j - st.jb), sh = st.cs == 16 ? 4 : (st.cs == 8 ? 3 : 2);
+  return dp_ck_groups(lb, C, tail) * dp_ck_steps(la) * 2 + ((i64)st.jb * dp_ck_nck(la) + m * 64 * st.cs + (r & (st.cs - 1)) * 64 + (r >> sh)) * 2;
 }
-__host__ __device__ inline i64 dp_ck_row_word(i64 la, i64 lb, int C, i64 s, i64 m, int lane) {
-  return dp_ck_stripes(lb, C) * dp_ck_steps(la) * dp_ck_col_words_per_step() + ((s * dp_ck_nck(la) + m) * 64 + lane) * 2 * C;
-}
+// the first fill lane of column group g (in the stripe it lies in), and the lanes of a group there
+__host__ __device__ inline int dp_group_lane0(int C, DpStripe st, i64 g) { return (int)((g * DP_CK_W * C - st.jb) / st.cs); }
+__host__ __device__ inline int dp_group_lanes(int C, DpStripe st) { return DP_CK_W * C / st.cs; }
 // bytes the fill kernel writes for one pair in checkpoint mode (rows of A it is on, not steps)
-__host__ __device__ inline i64 dp_ck_bytes_written(i64 la, i64 lb, int C) {
-  return dp_ck_stripes(lb, C) * (la * dp_ck_col_words_per_step() + dp_ck_nck(la) * 64 * 2 * C) * 4;
+__host__ __device__ inline i64 dp_ck_bytes_written(i64 la, i64 lb, int C, int tail) {
+  return (dp_ck_groups(lb, C, tail) * la * 2 + dp_ck_nck(la) * dp_padded_cols(lb, C, tail) * 2) * 4;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -138,13 +205,24 @@ __device__ __forceinline__ int pack16(int lo, int hi) { return (int)(((unsigned)
 #define PM_CELL_OPERANDS                                                                                               \
   [dp] "+v"(dp), [dn] "=&v"(dn), [e] "+v"(e), [f] "+v"(f), [hop] "+v"(hop), [acc] "+v"(acc), [t] "=&v"(t), [h] "=&v"(h)  \
       : [hl] "v"(hl), [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az), [w0] "v"(w0), [w1] "v"(w1), [w2n] "v"(w2n), [gop] "s"(gop)
-template <bool TRACE, bool LAST, bool DOT4, bool UNI = false>
+// LAST: 0 = a column in the middle of the lane's run; 1 = the lane's last column, nothing prepared for a next cell (the walk, which
+// forms its neighbour's diagonal itself); 2 = the lane's last column, and dn = the diagonal term of the RIGHT NEIGHBOUR's first cell
+// (w2n = that column's constant, dp_fill_kernel: the neighbour takes it with one DPP move instead of a move and an add).  1 and 2 end
+// in an s_nop that keeps hop two wait states away from the DPP read that follows the step.
+template <bool TRACE, int LAST, bool DOT4, bool UNI = false>
 __device__ __forceinline__ void dp_cell(int &dp, int &dn, int &e, int &f, int &hop, unsigned &acc, int hl, int ax, int ay,
                                         int az, int w0, int w1, int w2n, int gop) {
   int t, h;
 #define PM_CELL_ASM(BODY) asm volatile(BODY : PM_CELL_OPERANDS)
+#define PM_CELL_TAIL(BODY) \
+  if(LAST == 2) {          \
+    PM_CELL_ASM(BODY "\n\ts_nop 1"); \
+  }                        \
+  else {                   \
+    PM_CELL_ASM(BODY);     \
+  }
   if(TRACE) {
-    if(LAST) { // the trailing s_nop keeps hop two wait states away from the DPP read that follows the step
+    if(LAST == 1) {
       if(DOT4) {
         PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_H_T PM_CELL_OUT "\n\ts_nop 1");
       }
@@ -154,23 +232,23 @@ __device__ __forceinline__ void dp_cell(int &dp, int &dn, int &e, int &f, int &h
     }
     else if(UNI) {
       if(DOT4) {
-        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT_U PM_CELL_H_T PM_CELL_OUT);
+        PM_CELL_TAIL(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT_U PM_CELL_H_T PM_CELL_OUT)
       }
       else {
-        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT_U PM_CELL_H_T PM_CELL_OUT);
+        PM_CELL_TAIL(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT_U PM_CELL_H_T PM_CELL_OUT)
       }
     }
     else {
       if(DOT4) {
-        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT);
+        PM_CELL_TAIL(PM_CELL_E_T PM_CELL_SCORE4 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT)
       }
       else {
-        PM_CELL_ASM(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT);
+        PM_CELL_TAIL(PM_CELL_E_T PM_CELL_SCORE2 PM_CELL_F_T PM_CELL_NEXT PM_CELL_H_T PM_CELL_OUT)
       }
     }
   }
   else { // score only: 6 (7) ops; s_nops stand in for the decision ops that separate the dot ops from their readers
-    if(LAST) {
+    if(LAST == 1) {
       if(DOT4) {
         PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F "s_nop 1\n\t" PM_CELL_H PM_CELL_OUT "\n\ts_nop 1");
       }
@@ -180,21 +258,22 @@ __device__ __forceinline__ void dp_cell(int &dp, int &dn, int &e, int &f, int &h
     }
     else if(UNI) {
       if(DOT4) {
-        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT_U "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT);
+        PM_CELL_TAIL(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT_U "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT)
       }
       else {
-        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT_U "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT);
+        PM_CELL_TAIL(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT_U "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT)
       }
     }
     else {
       if(DOT4) {
-        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT);
+        PM_CELL_TAIL(PM_CELL_E PM_CELL_SCORE4 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT)
       }
       else {
-        PM_CELL_ASM(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT);
+        PM_CELL_TAIL(PM_CELL_E PM_CELL_SCORE2 PM_CELL_F PM_CELL_NEXT "s_nop 0\n\t" PM_CELL_H PM_CELL_OUT)
       }
     }
   }
+#undef PM_CELL_TAIL
 #undef PM_CELL_ASM
 }
 
@@ -260,7 +339,7 @@ __device__ __forceinline__ int4 dp_expand_row(u64 col) {
 // cols_per_lane (of the fill kernel) in {8, 16}; lanes_per_pair a power of two for which dp_walk_lanes_ok() holds.
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
-                   const DpBand &band, hipStream_t stream);
+                   const DpBand &band, int tail, hipStream_t stream);
 
 bool dp_walk_lanes_ok(int cols_per_lane, int lanes_per_pair);
 

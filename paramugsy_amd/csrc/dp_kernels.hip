@@ -38,6 +38,7 @@
 #include <functional>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "dp_internal.hpp"
@@ -66,6 +67,346 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
   return stripes * tiles * 64 * 4 * (C / 8);
 }
 
+// What a pair's stripes share (uniform over the wavefront).
+struct DpFillPair {
+  const u64 *A, *B;
+  int la, lb, steps, tiles, n_stripes, gop, ge;
+  unsigned *tbp;   // the pair's workspace: decision bits, or checkpoints
+  int2 *bp;        // bits / score mode: the seam, one {H~ - gop, E~} per row of A
+  i64 row_base;    // checkpoint mode: word offset of the row checkpoints in the workspace
+  int nck;         // checkpoint mode: row checkpoints per lane
+  int ng, team, tw;
+  int *gp;         // ng > 1: the pair's progress words in global memory
+  int *pipe_error;
+};
+
+// One stripe of a pair: 64 lanes x CS columns of B from column st.jb on, against all rows of A.  C is the batch's columns per lane
+// (the full stripes' CS, and what the checkpoints' column groups are made of); the narrow last stripes of dp_internal.hpp have CS < C.
+//
+// A step (lane l on row t - l of A) is 6 CS VALU instructions of cells and, since round 4, three more:
+//   * what the lane's row takes over from the lane to its left -- {H~ - gop, E~} of that lane's last column, and the diagonal term
+//     of the lane's first cell -- arrives with three v_mov_b32_dpp wave_shr:1.  The diagonal term (H~ - gop of the row above, plus
+//     the column's constant) is formed by the LEFT lane, in the slot of its last cell that used to be an s_nop (dp_cell, LAST = 2),
+//     so the receiving lane no longer keeps last step's hand-over and adds to it (a move and an add per step);
+//   * lane 0 has no lane to its left: its three values are the stripe's left boundary (the seam of the stripe before, or the DP's
+//     column 0).  They are written into LDS next to the rows of A when those are staged (every 64 steps), so they arrive in the
+//     DPP instructions' `old` operand with the lane's read of its row -- no v_readlane / v_writelane per step;
+//   * a block is always 64 steps (the steps behind the stripe's last have an empty EXEC mask), so the step loop has a constant
+//     trip count and unrolls by four with its LDS and checkpoint addresses as immediate offsets.
+template <int C, int CS, int MODE, bool DOT4, int NW, bool UNI>
+__device__ __forceinline__ void dp_fill_stripe(const DpFillPair &pp, const DpParamsD &P, const int s, const DpStripe st, int4 *ring, int4 *sbnd,
+                                               int2 *cstage, unsigned *tbstage, int *progress, const int wv, const int lane, int &result) {
+  constexpr bool TRACE = MODE == DP_MODE_BITS;
+  constexpr bool CKPT = MODE == DP_MODE_CKPT;
+  constexpr int TBW = TRACE ? CS / 8 : 1;
+  constexpr int TBS = TRACE ? 64 * TBW : 1;
+  constexpr bool PACKED = DOT4 && UNI; // a row of A is one dword: the boundary's three ride in the same 16-byte ring entry
+  constexpr int GW = DP_CK_W * C / CS; // lanes per column group
+  static_assert(!TRACE || (CS == C && CS % 8 == 0), "decision bits: whole words per lane per step, full stripes only");
+  const int la = pp.la, lb = pp.lb, steps = pp.steps, gop = pp.gop, ng = pp.ng, team = pp.team;
+  const u64 *A = pp.A, *B = pp.B;
+  unsigned *tbp = pp.tbp;
+  const int jb = st.jb;
+  const int j0 = jb + lane * CS; // this lane's first column of B (0-based)
+  const i64 g0 = jb / (DP_CK_W * C); // the stripe's first column group
+  int w0[CS], w1[CS], w2[CS], hop[CS], f[CS];
+#pragma unroll
+  for(int c = 0; c < CS; ++c) {
+    const int j = j0 + c;
+    const bool in = j < lb;
+    dp_column_weights<DOT4, UNI>(in ? B[j] : 0ull, in, P, w0[c], w1[c], w2[c], P.rows_a);
+    hop[c] = -2 * gop; // H~[0][j+1] - gop, H~[0][j] = -gop for j >= 1
+    f[c] = DP_NEG_INF;
+  }
+  const int w2nb = __shfl_down(w2[0], 1);                        // the constant of the right neighbour's first column
+  const int w2_l0 = __builtin_amdgcn_readfirstlane(w2[0]);       // and of lane 0's
+  int e = DP_NEG_INF; // the running E of this lane's row; between steps: what the lane hands to its right neighbour
+  int dn_last = 0;    // between steps: the diagonal term of the right neighbour's first cell
+  // H~ - gop above-left of lane 0's first cell of the block's first row: H~[0][jb] - gop at the top, then the boundary's last row
+  int hl_carry = (jb == 0 ? 0 : -gop) - gop;
+  if(jb > 0 && ng == 1) { // lane 63's stores of the stripe to the left must be visible to every lane's loads
+    if constexpr(CKPT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (they are inline asm, the fence below does not know of them)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (several workgroups: the seam is read with agent-scope atomic loads)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  // Column checkpoints ({H~ - gop, E~} of a group's last column, row by row): the lanes that close a group put theirs into LDS step
+  // by step -- cstage[group][step & 15], 17 slots a group so that the lanes' writes fall into different banks -- and every 16 steps
+  // the wavefront writes the 16 steps of every group out, 16 lanes per group: whole 128-byte lines, four groups per store (a store
+  // per lane and step was 16 partial-line write requests per step; L2 write requests are what this kernel runs short of)
+  constexpr int NGRP = 64 / GW;
+  const int2 *const ck_col = reinterpret_cast<const int2 *>(tbp) + g0 * steps; // group 0 of the stripe, step 0
+  const bool closes_group = (lane & (GW - 1)) == GW - 1;
+  unsigned cs_put = (unsigned)(size_t)cstage + (unsigned)(lane / GW) * 136u;              // + (step & 15) * 8
+  const unsigned cs_get = (unsigned)(size_t)cstage + (unsigned)(lane >> 4) * 136u + (unsigned)(lane & 15) * 8u; // + 4 i groups
+  const unsigned ck_put = ((unsigned)(lane >> 4) * (unsigned)steps + (unsigned)(lane & 15)) * 8u;                // the same in HBM
+
+  for(int t0 = 0; t0 < steps; t0 += 64) {
+    {
+      // stage rows [t0, t0+63] of A (one coalesced 8-byte load per lane, expanded) and the left boundary of the same rows
+      const int r = t0 + lane;
+      const int4 v = r < la ? dp_expand_row<DOT4>(A[r]) : make_int4(0, 0, 0, 0);
+      if(NW > 1 && s > 0) {
+        // rows [t0, t0+63] of the left stripe's boundary must have been published by its wave
+        const int need = ((s - 1) / team) * la + min(t0 + 64, la);
+        int spins = 0;
+        if(ng > 1) {
+          int *word = pp.gp + (s - 1) % team;
+          while(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            if((spins & 1023) == 0 && __hip_atomic_load(pp.pipe_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              break; // the launch has already failed somewhere: do not wait, let the grid drain
+            }
+            __builtin_amdgcn_s_sleep(4);
+            if(++spins > (1 << 22)) {
+              if(lane == 0) {
+                atomicOr(pp.pipe_error, 1);
+              }
+              break;
+            }
+          }
+          asm volatile("" ::: "memory");
+        }
+        else {
+          volatile int *word = &progress[(s - 1) % NW];
+          while(*word < need) {
+            if((spins & 1023) == 0 && __hip_atomic_load(pp.pipe_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            if(++spins > (1 << 22)) {
+              if(lane == 0) {
+                atomicOr(pp.pipe_error, 1);
+              }
+              break;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+      }
+      // what the column left of the stripe hands to lane 0 for row r: the seam of the stripe to the left, or for the first stripe
+      // the DP's own column 0, H~[r+1][0] - gop = -2 gop with no E
+      int2 b = make_int2(-2 * gop, DP_NEG_INF);
+      if(jb > 0 && r < la) {
+        const int2 *src;
+        if constexpr(CKPT) { // lane 63 closes a column group: its column checkpoints in the stripe to the left are the seam
+          src = reinterpret_cast<const int2 *>(tbp + dp_ck_col_word(la, g0 - 1, (i64)r + 63));
+        }
+        else {
+          src = pp.bp + r;
+        }
+        if(ng > 1) {
+          const unsigned long long q =
+              __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          b = make_int2((int)(unsigned)q, (int)(unsigned)(q >> 32));
+        }
+        else {
+          b = *src;
+        }
+      }
+      // the diagonal term of lane 0's first cell on row r: H~ - gop of the boundary one row up, plus the column's constant
+      const int hl_up = from_left(hl_carry, b.x);
+      hl_carry = __builtin_amdgcn_readlane(b.x, 63);
+      const int dg = UNI ? hl_up + w2_l0 : dot2(v.y, w2_l0, hl_up);
+      if constexpr(PACKED) {
+        const int4 ent = make_int4(v.x, b.x, dg, b.y);
+        ring[r & 127] = ent;
+        ring[(r & 127) + 128] = ent;
+      }
+      else {
+        ring[r & 127] = v;
+        ring[(r & 127) + 128] = v;
+        sbnd[lane] = make_int4(b.x, dg, b.y, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // where this lane's row of step t0 lies in the doubled ring: place (rbase & 127) + (row - rbase) with rbase = t0 - 64, the oldest
+    // row the block can read: between 1 and 191 for the rows of the block.  (LDS byte addresses: the low half of the generic ones.)
+    unsigned rrow = (unsigned)(size_t)ring + (unsigned)((((t0 - 64) & 127) + 64 - lane) * 16);
+    unsigned brow = (unsigned)(size_t)sbnd;
+    // one step; K = t & 3 is a constant, so that four steps share their address registers (immediate offsets)
+    auto step = [&](auto kc, const int t) __attribute__((always_inline)) {
+      constexpr int K = decltype(kc)::value;
+      // the lane's row of A; and (lane 0) the boundary's values for it.  Separate dwords: a 16-byte read comes back as a register
+      // tuple, and taking the DPP instructions' tied operands out of a tuple costs copies.
+      int ax, ay = 0, az = 0, b_hl, b_dg, b_e;
+      if constexpr(PACKED) {
+        asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\t"
+                     "ds_read_b32 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(b_hl), "=&v"(b_dg), "=&v"(b_e), "=&v"(ax)
+                     : "v"(rrow), "n"(K * 16 + 4), "n"(K * 16 + 8), "n"(K * 16 + 12), "n"(K * 16)
+                     : "memory");
+      }
+      else { // the boundary: the same address in every lane, row t of the block's 64
+        asm volatile("ds_read_b32 %0, %6 offset:%8\n\tds_read_b32 %1, %6 offset:%9\n\tds_read_b32 %2, %6 offset:%10\n\t"
+                     "ds_read_b32 %3, %7 offset:%11\n\tds_read_b32 %4, %7 offset:%12\n\tds_read_b32 %5, %7 offset:%13\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(b_hl), "=&v"(b_dg), "=&v"(b_e), "=&v"(ax), "=&v"(ay), "=&v"(az)
+                     : "v"(brow), "v"(rrow), "n"(K * 16), "n"(K * 16 + 4), "n"(K * 16 + 8), "n"(K * 16), "n"(K * 16 + 4), "n"(K * 16 + 8)
+                     : "memory");
+      }
+      // from the lane to the left (all 64 lanes enabled); hop[CS-1], e and dn_last change only in the steps a lane is on a row, so
+      // they are what its right neighbour needs one step later
+      const int ho_in = from_left(b_hl, hop[CS - 1]);
+      const int d0 = from_left(b_dg, dn_last);
+      e = from_left(b_e, e);
+      // the lanes that are on a row of A at this step, 0 <= t - lane < la, are lanes max(0, t - la + 1) .. min(63, t): the mask is built
+      // on the scalar unit and becomes EXEC as it is (no per-lane compare: v_cmp is a half-rate VALU instruction, once a step); it
+      // is empty in the steps behind the stripe's last
+      const int lane_lo = min(63, max(0, t - la + 1)), lane_hi = min(63, t);
+      const unsigned long long on_a_row = t < steps ? (~0ull >> (63 - max(0, lane_hi - lane_lo))) << lane_lo : 0ull;
+      if(__builtin_amdgcn_inverse_ballot_w64(on_a_row)) {
+        unsigned accw[TBW];
+#pragma unroll
+        for(int k = 0; k < TBW; ++k) {
+          asm volatile("" : "=v"(accw[k])); // no initial value needed: 8 cells x 4 bits shift every old bit out
+        }
+        {
+          int dd[2];
+          dd[0] = d0;
+#pragma unroll
+          for(int c = 0; c < CS; ++c) {
+            const int hl = c == 0 ? ho_in : hop[c == 0 ? 0 : c - 1];
+            if(c == CS - 1) {
+              dp_cell<TRACE, 2, DOT4, UNI>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[TRACE ? c / 8 : 0], hl, ax, ay, DOT4 ? ax : az,
+                                           w0[c], DOT4 ? w0[c] : w1[c], w2nb, gop);
+            }
+            else {
+              dp_cell<TRACE, 0, DOT4, UNI>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[TRACE ? c / 8 : 0], hl, ax, ay, DOT4 ? ax : az,
+                                           w0[c], DOT4 ? w0[c] : w1[c], w2[c + 1 < CS ? c + 1 : c], gop);
+            }
+          }
+          dn_last = dd[CS & 1];
+        }
+        if constexpr(TRACE) { // into this lane's slot of the tile being assembled in LDS
+#pragma unroll
+          for(int k = 0; k < TBW; ++k) {
+            tbstage[K * TBS + lane * TBW + k] = accw[k];
+          }
+        }
+        if constexpr(!CKPT) {
+          if(lane == 63 && s + 1 < pp.n_stripes) {
+            if(ng > 1) {
+              __hip_atomic_store(reinterpret_cast<unsigned long long *>(pp.bp + (t - 63)),
+                                 (unsigned long long)(unsigned)hop[CS - 1] | ((unsigned long long)(unsigned)e << 32), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else {
+              pp.bp[t - 63] = make_int2(hop[CS - 1], e);
+            }
+          }
+        }
+        if constexpr(CKPT) { // what this row hands to the next column group, into the staging of the current 16 steps
+          if(closes_group) {
+            const unsigned long long he = (unsigned long long)(unsigned)hop[CS - 1] | ((unsigned long long)(unsigned)e << 32);
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(cs_put), "v"(he), "n"(K * 8) : "memory");
+          }
+        }
+      }
+      if constexpr(CKPT) {
+        // the lane's column state every DP_CK_R steps, the lanes of a group one step apart (after the same row of A): lane l
+        // stores after the steps t with t + 1 - l % GW a positive multiple of DP_CK_R.  A scalar test lets GW of every DP_CK_R
+        // steps through to the per-lane test (kept behind it by an opaque asm, or the compiler would hoist the vector compare
+        // into every step).
+        const int tm = (t + 1) & (DP_CK_R - 1);
+        if(tm < GW && t < steps) {
+          const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); // the lane, not kept for this
+          int tc;
+          asm volatile("v_sub_u32 %0, %1, %2" : "=v"(tc) : "s"(t + 1), "v"(ln & (GW - 1)));
+          if(tc > 0 && (tc & (DP_CK_R - 1)) == 0) {
+            // [c][lane]: the store of one c is consecutive 8-byte slots over the lanes.  One store after the other through inline asm:
+            // left to itself the compiler assembles all of them side by side first, 32 registers that the step loop then does without
+            const char *rowp = reinterpret_cast<const char *>(tbp + pp.row_base + ((i64)jb * pp.nck + (i64)(tc / DP_CK_R - 1) * 64 * CS) * 2) +
+                               (unsigned)ln * 8u;
+#pragma unroll
+            for(int c = 0; c < CS; ++c) {
+              const unsigned long long hf = (unsigned long long)(unsigned)hop[c] | ((unsigned long long)(unsigned)f[c] << 32);
+              asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(rowp + (c >> 3) * 4096), "v"(hf), "n"((c & 7) * 512) : "memory");
+            }
+          }
+        }
+      }
+      if constexpr(TRACE) if((K == 3 && t < steps) || t == steps - 1) {
+        // tile complete (or the stripe's last, partial tile): every lane writes its own 4 x TBW words, contiguously;
+        // the wave's store covers one contiguous 1-2 KiB tile
+        unsigned *dst = tbp + (((i64)s * pp.tiles + (t >> 2)) * 64 + lane) * (4 * TBW);
+#pragma unroll
+        for(int q = 0; q < 4; ++q) {
+#pragma unroll
+          for(int k = 0; k < TBW; ++k) {
+            dst[q * TBW + k] = tbstage[q * TBS + lane * TBW + k];
+          }
+        }
+      }
+    };
+    for(int tb = 0; tb < 64; tb += 4) {
+      step(std::integral_constant<int, 0>(), t0 + tb);
+      step(std::integral_constant<int, 1>(), t0 + tb + 1);
+      step(std::integral_constant<int, 2>(), t0 + tb + 2);
+      step(std::integral_constant<int, 3>(), t0 + tb + 3);
+      rrow += 64;
+      brow += 64;
+      if constexpr(CKPT) {
+        cs_put += 32;
+        if((tb & 12) == 12) { // 16 steps staged: out with them (the slots of steps behind the stripe's last are not written)
+          cs_put -= 128;
+          const int t16 = t0 + tb - 12;
+          const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+          if(t16 + (ln & 15) < steps) {
+            const int2 *base = ck_col + t16;
+            // (the compiler does not count these stores: whoever reads them in this kernel waits for vmcnt(0) itself)
+            unsigned long long he[NGRP / 4];
+#pragma unroll
+            for(int i = 0; i < NGRP / 4; ++i) {
+              asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(he[i]) : "v"(cs_get), "n"(i * 4 * 136) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for(int i = 0; i < NGRP / 4; ++i) {
+              if(NW > 1 && i == NGRP / 4 - 1 && ng > 1) { // lane 63's group is the seam for another workgroup: past this XCD's L2
+                asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(ck_put), "v"(he[i]), "s"(base + (i64)i * 4 * steps) : "memory");
+              }
+              else {
+                asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(ck_put), "v"(he[i]), "s"(base + (i64)i * 4 * steps) : "memory");
+              }
+            }
+          }
+        }
+      }
+    }
+    if(NW > 1) {
+      // lane 63 has stored the boundary of rows < t0 + 64 - 63: publish the count (cumulated over this wave's stripes)
+      const int done = (s / team) * la + max(0, min(t0 + 1, la));
+      if(ng > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // lane 63's seam stores have been acknowledged
+        if(lane == 0) {
+          __hip_atomic_store(pp.gp + pp.tw, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      else {
+        if constexpr(CKPT) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if(lane == 0) {
+          *(volatile int *)&progress[wv] = done;
+        }
+      }
+    }
+  }
+  if(s == pp.n_stripes - 1) {
+    const int jj = lb - 1 - jb;
+    const int cstar = jj % CS;
+    int hv = hop[0];
+#pragma unroll
+    for(int c = 1; c < CS; ++c) {
+      hv = c == cstar ? hop[c] : hv;
+    }
+    result = __builtin_amdgcn_readlane(hv, jj / CS) + gop - (la + lb) * pp.ge; // un-skew
+  }
+}
+
 // DOT4: every count of A and every ACGT weight of B fits int8 (checked at batch creation), so the four base terms of
 // the column score are one v_dot4_i32_i8 instead of two v_dot2_i32_i16.
 // NW: wavefronts per pair.  NW = 1 is the mapping described above.  NW > 1 (used when a launch has too few pairs to
@@ -75,9 +416,9 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 // *pipe_error and lets the wave run on, so the grid always drains).
 // NG (run time, `ng`): workgroups per pair.  A workgroup sits on one CU, so with fewer pairs than CUs most of the chip would idle:
 // the pair's stripes are then dealt round robin to the NG * NW waves of NG consecutive workgroups, the progress words live
-// in global memory (`gprog`, zeroed by the host before the launch), and the seam values and the progress words are written and
-// read as agent-scope atomics (sc1: past the XCD's L2), ordered by the wave's own s_waitcnt vmcnt(0) -- agent-scope release /
-// acquire FENCES write back and invalidate the whole L2 of the XCD every time and made 128 pairs of 32 x 10 kbp 3.5x slower.
+// in global memory (`gprog`, this launch's own, zeroed by the host before the launch), and the seam values and the progress words
+// are written and read as agent-scope atomics (sc1: past the XCD's L2), ordered by the wave's own s_waitcnt vmcnt(0) -- agent-scope
+// release / acquire FENCES write back and invalidate the whole L2 of the XCD every time and made 128 pairs of 32 x 10 kbp 3.5x slower.
 // The host asks for this only while every workgroup can have a CU of its own (n * NG <= CUs).  No workgroup can wait for ever on
 // one that has not started, by construction: a workgroup does not take its (pair, team slot) from blockIdx -- HIP promises no
 // dispatch order -- but from a ticket it draws at entry (the word after the progress words, zeroed with them).  The tickets
@@ -86,29 +427,32 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 // T holds fewer than NG <= 16 workgroups, which cannot fill the chip, so the dispatcher goes on starting workgroups and T
 // grows.  The bounded waits stay as the last line of defence, and a wave that finds *pipe_error set (by any wave of the grid)
 // stops waiting at once, so a failed launch drains in milliseconds instead of paying the time-out at every block.
+// tail: the narrow last stripes of dp_internal.hpp (kernels with 16 columns per lane that store no decision bits).
 template <int C, int MODE, bool DOT4, int NW, bool UNI>
-__global__ void __launch_bounds__(64 * NW)
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DOT4 && NW <= 4 ? 5 : 4)))
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
                int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P, int ng, int *__restrict__ gprog,
-               int *__restrict__ started) {
+               int *__restrict__ started, int tail) {
   static_assert(C % 8 == 0, "whole traceback words per lane per step");
   if(started && threadIdx.x == 0) { // dp_gate_kernel: once every workgroup of this launch has started, the next chunk's may
     __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   constexpr bool TRACE = MODE == DP_MODE_BITS;
   constexpr bool CKPT = MODE == DP_MODE_CKPT;
+  constexpr bool TAILS = C == 16 && !TRACE; // the narrow stripes are compiled in
   constexpr int TBW = C / 8;
+  constexpr bool PACKED = DOT4 && UNI;
   // A's expanded rows, 128 rows deep, every row written at two places 128 apart: the 127 rows a 64-step block reads (64 lanes one row
   // apart, 64 steps) then lie at consecutive places whatever the block, and a lane's read address only advances, 16 bytes a step
   __shared__ int4 ring_all[NW][256];
+  __shared__ int4 sbnd_all[NW][PACKED ? 1 : 64]; // the left boundary of the block's 64 rows, where it does not fit the ring's entries
+  __shared__ int2 cstage_all[NW][CKPT ? 16 * 17 : 1]; // checkpoint mode: the column checkpoints of the current 16 steps (dp_fill_stripe)
   __shared__ int progress[NW]; // per wave: rows of boundary published so far, cumulated over the wave's stripes
   constexpr int TBS = TRACE ? 64 * TBW : 1;
-  __shared__ unsigned tbstage_all[NW][TRACE ? 4 : 1][TBS]; // the decisions of the current tile (4 steps), per wave
+  __shared__ unsigned tbstage_all[NW][(TRACE ? 4 : 1) * TBS]; // the decisions of the current tile (4 steps), per wave
   const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  int4 *ring = ring_all[wv];
-  unsigned(*tbstage)[TBS] = tbstage_all[wv];
   unsigned bid = blockIdx.x;
   if(NW > 1 && ng > 1) { // the ticket (see above): the order in which workgroups START, whatever their blockIdx
     __shared__ unsigned ticket;
@@ -119,28 +463,35 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     bid = ticket;
   }
   const int pos = ng > 1 ? (int)(bid / (unsigned)ng) : (int)bid;
-  const int team = NW * ng;                                     // waves of this pair
-  const int tw = ng > 1 ? wv * ng + (int)(bid % (unsigned)ng) : wv; // this wave's place among them: consecutive stripes go to
-                                                                 // different workgroups
-  int *gp = ng > 1 ? gprog + (i64)pos * team : nullptr;
+  DpFillPair pp;
+  pp.ng = ng;
+  pp.team = NW * ng;                                                // waves of this pair
+  pp.tw = ng > 1 ? wv * ng + (int)(bid % (unsigned)ng) : wv;        // this wave's place among them: consecutive stripes go to
+                                                                    // different workgroups
+  pp.gp = ng > 1 ? gprog + (i64)pos * pp.team : nullptr;
+  pp.pipe_error = pipe_error;
   const i64 pair = order[pos]; // the launch's pairs in processing order (dp_batch_plan)
   const i64 a0 = off_a[pair], b0 = off_b[pair];
   const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
-  const u64 *A = cols_a + a0;
-  const u64 *B = cols_b + b0;
-  unsigned *tbp = (TRACE || CKPT) ? tb + tb_off[pair] : nullptr;
-  int2 *bp = bnd + a0;
-  const int go = P.go, ge = P.ge;
-  const int gop = go - ge; // cost of opening over extending, the only gap constant left in skewed coordinates
-  constexpr int W = 64 * C;
-  const int n_stripes = (lb + W - 1) / W;
-  const int steps = la + 63;
-  const int tiles = (steps + 3) / 4;
+  const int tl = TAILS ? tail : 0;
+  pp.A = cols_a + a0;
+  pp.B = cols_b + b0;
+  pp.la = la;
+  pp.lb = lb;
+  pp.tbp = (TRACE || CKPT) ? tb + tb_off[pair] : nullptr;
+  pp.bp = bnd + a0;
+  pp.gop = P.go - P.ge; // cost of opening over extending, the only gap constant left in skewed coordinates
+  pp.ge = P.ge;
+  pp.n_stripes = (int)dp_ck_stripes(lb, C, tl);
+  pp.steps = la + 63;
+  pp.tiles = (pp.steps + 3) / 4;
+  pp.row_base = dp_ck_groups(lb, C, tl) * dp_ck_steps(la) * 2;
+  pp.nck = (int)dp_ck_nck(la);
   int result = 0;
   if(la == 0 || lb == 0) { // one profile empty: a single gap run
     int n = la + lb;
-    if(lane == 0 && tw == 0) {
-      scores[pair] = n == 0 ? 0 : -(go + (n - 1) * ge);
+    if(lane == 0 && pp.tw == 0) {
+      scores[pair] = n == 0 ? 0 : -(P.go + (n - 1) * P.ge);
     }
     return;
   }
@@ -150,253 +501,21 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     }
     __syncthreads();
   }
-
-  for(int s = tw; s < n_stripes; s += team) {
-    const int j0 = s * W + lane * C; // this lane's first column of B (0-based)
-    int w0[C], w1[C], w2[C], hop[C], f[C];
-#pragma unroll
-    for(int c = 0; c < C; ++c) {
-      const int j = j0 + c;
-      const bool in = j < lb;
-      dp_column_weights<DOT4, UNI>(in ? B[j] : 0ull, in, P, w0[c], w1[c], w2[c], P.rows_a);
-      hop[c] = -2 * gop;                      // H~[0][j+1] - gop, H~[0][j] = -gop for j >= 1
-      f[c] = DP_NEG_INF;
+  for(int s = pp.tw; s < pp.n_stripes; s += pp.team) {
+    const DpStripe st = dp_stripe(lb, C, tl, s);
+    if(!TAILS || st.cs == C) {
+      dp_fill_stripe<C, C, MODE, DOT4, NW, UNI>(pp, P, s, st, ring_all[wv], sbnd_all[wv], cstage_all[wv], tbstage_all[wv], progress, wv, lane, result);
     }
-    int diag_in = (j0 == 0 ? 0 : -gop) - gop; // H~[0][j0] - gop
-    int e = DP_NEG_INF; // the running E of this lane's row; between steps: what the lane hands to its right neighbour
-    // what the column left of the stripe hands to lane 0, 64 rows at a time (lane r & 63 holds row r's): the seam of the stripe to
-    // the left, or for the first stripe the DP's own column 0, H~[t+1][0] - gop = -2 gop with no E -- constants kept in the same
-    // registers, so that with several waves per pair (few pairs: a wave's own branches are what its steps wait for) the step reads
-    // them the same way whatever the stripe; one wave per pair keeps the branch, which saves the first stripe two v_readlane a step
-    int bin_ho = -2 * gop, bin_e = DP_NEG_INF;
-    if(s > 0) {
-      // lane 63's stores of the previous stripe must be visible to every lane's loads
-      if(ng == 1) { // (several workgroups: the seam is read with agent-scope atomic loads instead)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      }
-    }
-
-    for(int t0 = 0; t0 < steps; t0 += 64) {
-      {
-        // stage rows [t0, t0+63] of A: one coalesced 8-byte load per lane, expanded to int16 pairs
-        const int r = t0 + lane;
-        // (nGap, 1) sits next to x, so that the int8 path reads 8 bytes per row
-        const int4 v = r < la ? dp_expand_row<DOT4>(A[r]) : make_int4(0, 0, 0, 0);
-        ring[r & 127] = v;
-        ring[(r & 127) + 128] = v;
-        if(NW > 1 && s > 0) {
-          // rows [t0, t0+63] of the left stripe's boundary must have been published by its wave
-          const int need = ((s - 1) / team) * la + min(t0 + 64, la);
-          int spins = 0;
-          if(ng > 1) {
-            int *word = gp + (s - 1) % team;
-            while(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-              if((spins & 1023) == 0 && __hip_atomic_load(pipe_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                break; // the launch has already failed somewhere: do not wait, let the grid drain
-              }
-              __builtin_amdgcn_s_sleep(4);
-              if(++spins > (1 << 22)) {
-                if(lane == 0) {
-                  atomicOr(pipe_error, 1);
-                }
-                break;
-              }
-            }
-            asm volatile("" ::: "memory");
-          }
-          else {
-            volatile int *word = &progress[(s - 1) % NW];
-            while(*word < need) {
-              if((spins & 1023) == 0 && __hip_atomic_load(pipe_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                break;
-              }
-              __builtin_amdgcn_s_sleep(2);
-              if(++spins > (1 << 22)) {
-                if(lane == 0) {
-                  atomicOr(pipe_error, 1);
-                }
-                break;
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          }
-        }
-        if(s > 0) {
-          int2 b = make_int2(0, DP_NEG_INF);
-          if(r < la) {
-            const int2 *src;
-            if constexpr(CKPT) { // lane 63 closes a column group: its column checkpoints of stripe s - 1 are the seam
-              src = reinterpret_cast<const int2 *>(tbp + dp_ck_col_word(la, s - 1, (i64)r + 63, 63));
-            }
-            else {
-              src = bp + r;
-            }
-            if(ng > 1) {
-              const unsigned long long v =
-                  __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              b = make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
-            }
-            else {
-              b = *src;
-            }
-          }
-          // consume the loaded values here, so the wait for them sits in this block (once per 64 steps) and
-          // not in front of the v_readlane of every step
-          asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(bin_ho), "=v"(bin_e) : "v"(b.x), "v"(b.y));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-      const int t1 = min(t0 + 64, steps);
-      int ii16 = (t0 - lane) * 16; // 16 x this lane's row of A (0-based)
-      // where this lane's row of step t0 lies in the doubled ring: place (rbase & 127) + (row - rbase) with rbase = t0 - 64, the oldest
-      // row the block can read: between 1 and 191 for the rows of the block
-      int raddr = (((t0 - 64) & 127) + 64 - lane) * 16;
-      for(int t = t0; t < t1; ++t, ii16 += 16, raddr += 16) {
-      // what the column left of the stripe hands to lane 0 for row t
-      int b_ho, b_e;
-      if(NW == 1 && s == 0) {
-        b_ho = -2 * gop; // H~[t+1][0] - gop
-        b_e = DP_NEG_INF;
+    else if constexpr(TAILS) {
+      if(st.cs == 8) {
+        dp_fill_stripe<C, 8, MODE, DOT4, NW, UNI>(pp, P, s, st, ring_all[wv], sbnd_all[wv], cstage_all[wv], tbstage_all[wv], progress, wv, lane, result);
       }
       else {
-        b_ho = __builtin_amdgcn_readlane(bin_ho, t & 63);
-        b_e = __builtin_amdgcn_readlane(bin_e, t & 63);
+        dp_fill_stripe<C, 4, MODE, DOT4, NW, UNI>(pp, P, s, st, ring_all[wv], sbnd_all[wv], cstage_all[wv], tbstage_all[wv], progress, wv, lane, result);
       }
-      // hop[C-1] and e change only in the steps the lane is on a row, so they are what the right neighbour needs
-      const int ho_in = from_left(b_ho, hop[C - 1]);
-      // e moves one lane to the right in place; lane 0 takes the boundary's
-      asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                   "v_writelane_b32 %0, %1, 0"
-                   : "+v"(e)
-                   : "s"(b_e));
-      const int tq = t & 3;
-      // the lanes that are on a row of A at this step, 0 <= t - lane < la, are lanes max(0, t - la + 1) .. min(63, t): the mask is built
-      // on the scalar unit and becomes EXEC as it is (no per-lane compare: v_cmp is a half-rate VALU instruction, once a step)
-      const int lane_lo = max(0, t - la + 1), lane_hi = min(63, t);
-      const unsigned long long on_a_row = (~0ull >> (63 - (lane_hi - lane_lo))) << lane_lo;
-      if(__builtin_amdgcn_inverse_ballot_w64(on_a_row)) {
-        const int4 a = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(ring) + raddr);
-        unsigned accw[TBW];
-#pragma unroll
-        for(int k = 0; k < TBW; ++k) {
-          asm volatile("" : "=v"(accw[k])); // no initial value needed: 8 cells x 4 bits shift every old bit out
-        }
-        {
-          int dd[2];
-          if(UNI) {
-            dd[0] = diag_in + w2[0];
-          }
-          else {
-            asm volatile("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(dd[0]) : "v"(a.y), "v"(w2[0]), "v"(diag_in));
-          }
-#pragma unroll
-          for(int c = 0; c < C; ++c) {
-            const int hl = c == 0 ? ho_in : hop[c == 0 ? 0 : c - 1];
-            if(c == C - 1) {
-              dp_cell<TRACE, true, DOT4, UNI>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, DOT4 ? a.x : a.z,
-                                              w0[c], DOT4 ? w0[c] : w1[c], 0, gop);
-            }
-            else {
-              dp_cell<TRACE, false, DOT4, UNI>(dd[c & 1], dd[(c + 1) & 1], e, f[c], hop[c], accw[c / 8], hl, a.x, a.y, DOT4 ? a.x : a.z,
-                                               w0[c], DOT4 ? w0[c] : w1[c], w2[c + 1 < C ? c + 1 : c], gop);
-            }
-          }
-        }
-        if constexpr(TRACE) { // into this lane's slot of the tile being assembled in LDS
-#pragma unroll
-          for(int k = 0; k < TBW; ++k) {
-            tbstage[tq][lane * TBW + k] = accw[k];
-          }
-        }
-        diag_in = ho_in;
-        if constexpr(!CKPT) {
-          if(lane == 63 && s + 1 < n_stripes) {
-            if(ng > 1) {
-              __hip_atomic_store(reinterpret_cast<unsigned long long *>(bp + (ii16 >> 4)),
-                                 (unsigned long long)(unsigned)hop[C - 1] | ((unsigned long long)(unsigned)e << 32), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-            }
-            else {
-              bp[ii16 >> 4] = make_int2(hop[C - 1], e);
-            }
-          }
-        }
-        if constexpr(CKPT) { // what this row hands to the next column group: one coalesced store per step
-          if(DP_CK_W == 1 || (lane & (DP_CK_W - 1)) == DP_CK_W - 1) {
-            if(NW > 1 && ng > 1 && lane == 63) { // the seam for another workgroup
-              __hip_atomic_store(reinterpret_cast<unsigned long long *>(tbp + dp_ck_col_word(la, s, t, lane)),
-                                 (unsigned long long)(unsigned)hop[C - 1] | ((unsigned long long)(unsigned)e << 32), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-            }
-            else {
-              *reinterpret_cast<int2 *>(tbp + dp_ck_col_word(la, s, t, lane)) = make_int2(hop[C - 1], e);
-            }
-          }
-        }
-      }
-      if constexpr(CKPT) {
-        // the lane's column state every DP_CK_R steps, the lanes of a group one step apart (after the same row of A): lane l
-        // stores after the steps t with t + 1 - l % DP_CK_W a positive multiple of DP_CK_R.  A scalar test lets DP_CK_W of
-        // every DP_CK_R steps through to the per-lane test (kept behind it by an opaque asm, or the compiler would hoist the
-        // vector compare into every step).
-        const int tm = (t + 1) & (DP_CK_R - 1);
-        if(tm < DP_CK_W) {
-          int tt;
-          asm volatile("v_sub_u32 %0, %1, %2" : "=v"(tt) : "s"(t + 1), "v"(lane & (DP_CK_W - 1)));
-          if(tt > 0 && (tt & (DP_CK_R - 1)) == 0) {
-            int4 *dst = reinterpret_cast<int4 *>(tbp + dp_ck_row_word(la, lb, C, s, tt / DP_CK_R - 1, lane));
-#pragma unroll
-            for(int c = 0; c < C; c += 2) {
-              dst[c / 2] = make_int4(hop[c], f[c], hop[c + 1], f[c + 1]);
-            }
-          }
-        }
-      }
-      if constexpr(TRACE) if(tq == 3 || t == steps - 1) {
-        // tile complete (or the stripe's last, partial tile): every lane writes its own 4 x TBW words, contiguously;
-        // the wave's store covers one contiguous 1-2 KiB tile
-        unsigned *dst = tbp + (((i64)s * tiles + (t >> 2)) * 64 + lane) * (4 * TBW);
-#pragma unroll
-        for(int q = 0; q < 4; ++q) {
-#pragma unroll
-          for(int k = 0; k < TBW; ++k) {
-            dst[q * TBW + k] = tbstage[q][lane * TBW + k];
-          }
-        }
-      }
-      }
-      if(NW > 1) {
-        // lane 63 has stored the boundary of rows < t1 - 63: publish the count (cumulated over this wave's stripes)
-        const int done = (s / team) * la + max(0, min(t1 - 63, la));
-        if(ng > 1) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // lane 63's seam stores have been acknowledged
-          if(lane == 0) {
-            __hip_atomic_store(gp + tw, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        else {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if(lane == 0) {
-            *(volatile int *)&progress[wv] = done;
-          }
-        }
-      }
-    }
-    if(s == n_stripes - 1) {
-      const int jj = lb - 1 - s * W;
-      const int cstar = jj % C;
-      int hv = hop[0];
-#pragma unroll
-      for(int c = 1; c < C; ++c) {
-        hv = c == cstar ? hop[c] : hv;
-      }
-      result = __builtin_amdgcn_readlane(hv, jj / C) + gop - (la + lb) * ge; // un-skew
     }
   }
-  if(lane == 0 && tw == (n_stripes - 1) % team) {
+  if(lane == 0 && pp.tw == (pp.n_stripes - 1) % pp.team) {
     scores[pair] = result;
   }
 }
@@ -923,9 +1042,11 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     const bool band_likely = !staged && band_env != 0 && (band_env > 0 || band_pays(n_pairs, dp_walk_lanes_for(h, n_pairs)));
     h->ckpt = fill_saved_s > (band_likely ? 30e-6 + chain_blocks * 4e-6 : chain_blocks * 15e-6);
   }
+  // the narrow last stripes (dp_internal.hpp): wherever the path comes from checkpoints and a lane has 16 columns.  PM_DP_TAIL=0: not.
+  h->tail = h->ckpt && h->cols_per_lane == 16 && !(getenv("PM_DP_TAIL") && atoi(getenv("PM_DP_TAIL")) == 0);
   auto need_words = [&](i64 k) {
     i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
-    return h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane) : dp_tb_words(la, lb, h->cols_per_lane);
+    return h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane, h->tail) : dp_tb_words(la, lb, h->cols_per_lane);
   };
   // processing order: a wavefront works through its pair's stripes one after the other, so a launch lasts at least as long as
   // its longest pair; pairs are therefore taken longest first (stripes x steps, ties in input order), which also puts pairs of
@@ -939,7 +1060,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     std::vector<i64> cost((size_t)n_pairs);
     for(i64 k = 0; k < n_pairs; ++k) {
       const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
-      cost[(size_t)k] = dp_ck_stripes(lb, h->cols_per_lane) * (la + 63);
+      cost[(size_t)k] = dp_fill_cost(la, lb, h->cols_per_lane, h->tail);
     }
     std::stable_sort(h->order.begin(), h->order.end(), [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
   }
@@ -1053,7 +1174,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       }
       auto cost_at = [&](i64 q) {
         const i64 k = h->order[(size_t)q];
-        return dp_ck_stripes(h->off_b[k + 1] - h->off_b[k], h->cols_per_lane) * (h->off_a[k + 1] - h->off_a[k] + 63);
+        return dp_fill_cost(h->off_a[k + 1] - h->off_a[k], h->off_b[k + 1] - h->off_b[k], h->cols_per_lane, h->tail);
       };
       double total = 0;
       for(i64 q = c_lo; q < c_hi; ++q) {
@@ -1255,7 +1376,7 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
     for(i64 q = first; q < first + n; ++q) {
       const i64 k = h->order[(size_t)q];
       i64 lbk = h->off_b[k + 1] - h->off_b[k];
-      max_stripes = std::max(max_stripes, (lbk + 64 * h->cols_per_lane - 1) / (64 * h->cols_per_lane));
+      max_stripes = std::max(max_stripes, dp_ck_stripes(lbk, h->cols_per_lane, h->tail));
       max_la = std::max(max_la, h->off_a[k + 1] - h->off_a[k]);
     }
     bool fits = (max_stripes + 2) * max_la < ((i64)1 << 30); // the progress word is an int
@@ -1311,7 +1432,7 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
                                                                                    (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p,    \
                                                                                    order, tb_off, tbw, (int2 *)h->bnd.p, (int *)h->scores.p, \
                                                                                    (int *)h->pipe_error.p, h->params, ng, (int *)h->gprog.p, \
-                                                                                   started)
+                                                                                   started, h->tail ? 1 : 0)
 #define DP_LAUNCH_FILL_D4(CC, TR, NWV)         \
   if(h->dot4 && h->uni) {                      \
     DP_LAUNCH_FILL(CC, TR, true, NWV, true);   \
@@ -1386,7 +1507,7 @@ static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStre
     }
     return dp_launch_walk(h->cols_per_lane, lpp, h->dot4, (const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
                           (const i64 *)h->d_off_b.p, order, n, tb_off, tbw, (unsigned char *)h->ops.p, (int *)h->n_ops.p, h->params, band,
-                          stream);
+                          h->tail ? 1 : 0, stream);
   }
   if(h->cols_per_lane == 16) {
     dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, order, tb_off, tbw,
@@ -1669,7 +1790,7 @@ int pm_dp_batch_info(pm_dp_batch_t *h, int64_t *cells, int64_t *traceback_bytes_
     for(i64 k = 0; k < h->n_pairs; ++k) {
       i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
       if(h->ckpt) { // what the fill kernel writes: the column checkpoints of the rows it is on + the row checkpoints
-        words += dp_ck_bytes_written(la, lb, h->cols_per_lane) / 4;
+        words += dp_ck_bytes_written(la, lb, h->cols_per_lane, h->tail) / 4;
       }
       else {
         words += dp_tb_words(la, lb, h->cols_per_lane);
@@ -1682,8 +1803,7 @@ int pm_dp_batch_info(pm_dp_batch_t *h, int64_t *cells, int64_t *traceback_bytes_
     i64 bytes = h->total_b * 8;
     for(i64 k = 0; k < h->n_pairs; ++k) {
       i64 lb = h->off_b[k + 1] - h->off_b[k];
-      i64 W = 64 * h->cols_per_lane;
-      bytes += ((lb + W - 1) / W) * (h->off_a[k + 1] - h->off_a[k]) * 8;
+      bytes += dp_ck_stripes(lb, h->cols_per_lane, h->tail) * (h->off_a[k + 1] - h->off_a[k]) * 8;
     }
     *input_bytes = bytes;
   }

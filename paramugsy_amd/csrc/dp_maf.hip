@@ -35,6 +35,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
+
 #include "dp_batch.hpp"
 #include "multi.hpp"
 #include "dp_internal.hpp"
@@ -362,7 +364,7 @@ static int maf_index(const std::string &path, MafDpBlocks &out) {
   std::vector<int> rc(n_ranges, PM_OK);
   std::vector<std::string> msg(n_ranges);
   {
-    std::vector<std::thread> th;
+    std::vector<JoinThread> th;
     auto work = [&](size_t k) {
       rc[k] = parse_maf_range(text, cut[k], cut[k + 1], path, part[k], k > 0 && cut[k] < size);
       if(rc[k]) {
@@ -370,11 +372,11 @@ static int maf_index(const std::string &path, MafDpBlocks &out) {
       }
     };
     for(size_t k = 1; k < n_ranges; ++k) {
-      th.emplace_back(work, k);
+      th.emplace_back([&work, k]() { work(k); });
     }
     work(0);
     for(size_t k = 0; k < th.size(); ++k) {
-      th[k].join();
+      th[k].join_and_rethrow();
     }
   }
   for(size_t k = 0; k < n_ranges; ++k) {
@@ -615,14 +617,14 @@ int pm_dp_emit_maf(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_ro
 static int parse_two_mafs(const char *maf_a, const char *maf_b, MafDpBlocks &A, MafDpBlocks &B, const char *who) {
   int rc_b = PM_OK;
   std::string err_b;
-  std::thread other([&]() {
+  JoinThread other([&]() {
     rc_b = parse_maf_blocks(maf_b, B);
     if(rc_b) {
       err_b = pm_last_error();
     }
   });
   const int rc_a = parse_maf_blocks(maf_a, A);
-  other.join();
+  other.join_and_rethrow();
   if(rc_a) {
     return rc_a;
   }
@@ -791,7 +793,8 @@ struct BlockSlice {
 // sent_a / sent_b: the sides' texts already in device memory (the whole files; only with lo = 0 and hi = every block), or null.
 static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t lo, int64_t hi, const pm_dp_params_t *params, int device,
                              bool with_header, OutSink out, const std::function<void(const char *)> &lap,
-                             std::unique_ptr<MafSideDev> sent_a = nullptr, std::unique_ptr<MafSideDev> sent_b = nullptr) {
+                             std::unique_ptr<MafSideDev> sent_a = nullptr, std::unique_ptr<MafSideDev> sent_b = nullptr,
+                             const std::function<int()> &before_write = nullptr) {
   const int64_t n = hi - lo;
   std::string blob;
   if(with_header) {
@@ -819,7 +822,7 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
     // the two sides go up side by side (two copies from mapped files, each bound by the host's copy into staging memory)
     int rc_b = PM_OK;
     std::string msg_b;
-    std::thread other([&]() {
+    JoinThread other([&]() {
       rc_b = use_device(device);
       if(!rc_b) {
         rc_b = SB.upload(sb.text, sb.row_off.data(), sb.n_rows, sb.block_row.data(), n, cob.data());
@@ -829,7 +832,7 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
       }
     });
     const int rc_a = SA.upload(sa.text, sa.row_off.data(), sa.n_rows, sa.block_row.data(), n, coa.data());
-    other.join();
+    other.join_and_rethrow();
     if(rc_a) {
       return rc_a;
     }
@@ -953,17 +956,38 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
   }
   lap("file image (device)");
   // everything but the image is released beside its way to the host (a dozen milliseconds of hipFree for a few GB)
-  std::thread reaper([&]() {
+  JoinThread reaper([&]() {
     if(use_device(device) == PM_OK) {
       batch_release(std::move(batch));
       SAp.reset();
       SBp.reset();
     }
   });
+  if(before_write) { // the caller's last word before bytes reach its sink (pm_dp_align_maf: the output file is emptied only now)
+    const int rc_bw = before_write();
+    if(rc_bw) {
+      reaper.join();
+      return rc_bw;
+    }
+  }
   const int rc_out = device_bytes_to_sink((const char *)d_out.p, n_out, out, timing, []() {});
   reaper.join();
   PM_TRY(rc_out);
   lap("to the host + write");
+  return PM_OK;
+}
+
+// The output must not be one of the inputs: they are mapped, and emptying a mapped file pulls its pages from under the readers
+// (SIGBUS -- in a resident `serve` process the end of the worker).
+static int output_is_no_input(const char *out_maf, const char *maf_a, const char *maf_b, const char *who) {
+  struct stat so, si;
+  if(stat(out_maf, &so) == 0) {
+    for(const char *in : {maf_a, maf_b}) {
+      if(stat(in, &si) == 0 && si.st_dev == so.st_dev && si.st_ino == so.st_ino) {
+        return fail(PM_E_INVALID, std::string(who) + ": the output " + out_maf + " is one of the input files");
+      }
+    }
+  }
   return PM_OK;
 }
 
@@ -983,25 +1007,35 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
       t0 = t1;
     }
   };
-  // the output file is opened beside everything below (truncating a big file that is already there takes as long as the DP)
+  // The inputs first: a call that cannot even map them leaves an output file that is already there as it is.
+  MafDpBlocks A, B;
+  PM_TRY(maf_map(maf_a, A));
+  PM_TRY(maf_map(maf_b, B));
+  PM_TRY(output_is_no_input(out_maf, maf_a, maf_b, "pm_dp_align_maf"));
+  // The output file is opened beside everything below, WITHOUT truncation: it is emptied only when the inputs have been indexed and
+  // found to pair up and the DP has run -- right before the first byte is written (emptying a big file that is already there takes
+  // as long as the DP; a failure before that point leaves it untouched).
   FILE *f = nullptr;
-  std::thread opener([&]() { f = fopen(out_maf, "wb"); });
-  struct JoinOpener {
-    std::thread &t;
+  JoinThread opener([&]() {
+    const int fd = open(out_maf, O_WRONLY | O_CREAT | O_CLOEXEC, 0666);
+    if(fd >= 0) {
+      f = fdopen(fd, "wb");
+      if(!f) {
+        close(fd);
+      }
+    }
+  });
+  struct CloseUnlessKept {
+    JoinThread &t;
     FILE *&f;
     bool keep = false;
-    ~JoinOpener() {
-      if(t.joinable()) {
-        t.join();
-      }
+    ~CloseUnlessKept() {
+      t.join();
       if(f && !keep) {
         fclose(f);
       }
     }
-  } join_opener{opener, f};
-  MafDpBlocks A, B;
-  PM_TRY(maf_map(maf_a, A));
-  PM_TRY(maf_map(maf_b, B));
+  } close_unless_kept{opener, f};
   lap("files mapped");
   // the files' bytes go to the device as they are, while their lines are being indexed (four threads: two copies, two indexers,
   // each indexer with its range threads)
@@ -1015,13 +1049,13 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
         msg4[k] = pm_last_error();
       }
     };
-    std::thread t1([&]() { guarded(1, [&]() { PM_TRY(use_device(device)); return sent_a->upload_text((const uint8_t *)A.bytes, A.n_bytes); }); });
-    std::thread t2([&]() { guarded(2, [&]() { PM_TRY(use_device(device)); return sent_b->upload_text((const uint8_t *)B.bytes, B.n_bytes); }); });
-    std::thread t3([&]() { guarded(3, [&]() { return maf_index(maf_b, B); }); });
+    JoinThread t1([&]() { guarded(1, [&]() { PM_TRY(use_device(device)); return sent_a->upload_text((const uint8_t *)A.bytes, A.n_bytes); }); });
+    JoinThread t2([&]() { guarded(2, [&]() { PM_TRY(use_device(device)); return sent_b->upload_text((const uint8_t *)B.bytes, B.n_bytes); }); });
+    JoinThread t3([&]() { guarded(3, [&]() { return maf_index(maf_b, B); }); });
     guarded(0, [&]() { return maf_index(maf_a, A); });
-    t1.join();
-    t2.join();
-    t3.join();
+    t1.join_and_rethrow();
+    t2.join_and_rethrow();
+    t3.join_and_rethrow();
     for(int k : {0, 3, 1, 2}) {
       if(rc4[k]) {
         return fail(rc4[k], msg4[k]);
@@ -1033,13 +1067,18 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
   }
   const int64_t n = (int64_t)A.block_row.size() - 1;
   lap("indexed, and the bytes on the device");
-  opener.join();
+  opener.join_and_rethrow();
   if(!f) {
     return fail(PM_E_IO, std::string("cannot write ") + out_maf);
   }
-  join_opener.keep = true; // closed below, with its error checked
+  close_unless_kept.keep = true; // closed below, with its error checked
   lap("output file opened");
-  int rc = align_maf_to_sink(A, B, 0, n, params, device, true, OutSink(f), lap, std::move(sent_a), std::move(sent_b));
+  int rc = align_maf_to_sink(A, B, 0, n, params, device, true, OutSink(f), lap, std::move(sent_a), std::move(sent_b), [&]() -> int {
+    if(ftruncate(fileno(f), 0) != 0 && errno != EINVAL) { // (EINVAL: not a regular file -- a pipe, /dev/stdout: nothing to empty)
+      return fail(PM_E_IO, std::string("cannot empty ") + out_maf + ": " + strerror(errno));
+    }
+    return PM_OK;
+  });
   std::string msg = rc ? pm_last_error() : "";
   lap("small device buffers released");
   if(fclose(f) != 0 && !rc) {
@@ -1171,6 +1210,7 @@ extern "C" int pm_dp_align_maf_multi(const char *maf_a, const char *maf_b, const
   PM_TRY(check_devices(devices, n_devices, "pm_dp_align_maf_multi"));
   MafDpBlocks A, B;
   PM_TRY(parse_two_mafs(maf_a, maf_b, A, B, "pm_dp_align_maf_multi"));
+  PM_TRY(output_is_no_input(out_maf, maf_a, maf_b, "pm_dp_align_maf_multi"));
   const int64_t n = (int64_t)A.block_row.size() - 1;
   // every worker assembles the file bytes of its slice's merged blocks on its device and brings them to a buffer of its own; the
   // host-side gather is writing the buffers in pair order

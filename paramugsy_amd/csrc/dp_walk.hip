@@ -50,7 +50,7 @@ template <int C, int LPP, bool DOT4>
 __global__ void __launch_bounds__(64)
 dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b, const i64 *__restrict__ off_b,
                const int *__restrict__ order, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
-               int *__restrict__ n_ops, DpParamsD P, DpBand band, int band_mode, int ablate) {
+               int *__restrict__ n_ops, DpParamsD P, DpBand band, int band_mode, int ablate, int tail) {
   // band_mode 0: the walk, every block recomputed; 1: no walk, the band's blocks computed and stored (work items = the band's
   // (pair, column group) list); 2: the walk, blocks inside the band read back, the others recomputed
   constexpr int R = DP_CK_R;
@@ -109,7 +109,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       if(pass == DP_BAND_BLOCKS) {
         break;
       }
-      const int l0w = (ggw * DP_CK_W) & 63;
+      const int l0w = dp_group_lane0(C, dp_stripe_of_col(lb, C, tail, (i64)ggw * BW), ggw);
       const int kb = dp_band_row_block(la, lb, BW, ggw, l0w) - DP_BAND_BLOCKS / 2 + pass;
       const int top = kb * R - l0w;
       live = have && kb >= 0 && top < la && top + R >= 1;
@@ -136,9 +136,10 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
       live = have && i > 0 && j > 0;
     }
-    // ---- the block the walk is in: column group gg (lanes l0 .. l0 + DP_CK_W - 1 of stripe s of the fill kernel), row block k
+    // ---- the block the walk is in: column group gg (lanes l0 .. of the stripe of the fill kernel it lies in), row block k
     const int gg = live ? (j - 1) / BW : 0;
-    const int s = (gg * DP_CK_W) >> 6, l0 = (gg * DP_CK_W) & 63;
+    const DpStripe st = dp_stripe_of_col(lb, C, tail, (i64)gg * BW);
+    const int l0 = dp_group_lane0(C, st, gg);
     const int k = live ? (i - 1 + l0) / R : 0;
     const int i0 = max(0, k * R - l0);
     // the walk only moves up and left: rows below row i - 1 and columns right of column j - 1 are never visited and no
@@ -168,11 +169,9 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     // ---- top edge: the state of the lane's columns after row i0 - 1 (the group's row checkpoint k - 1)
     const bool has_top = comp && k * R - l0 >= 1 && !(ablate & 2);
     if(has_top) {
-      const int lf = (q * C2) / C, cf = (q * C2) % C;
-      const int2 *src = reinterpret_cast<const int2 *>(ckp + dp_ck_row_word(la, lb, C, s, k - 1, l0 + lf)) + cf;
 #pragma unroll
       for(int c = 0; c < C2; ++c) {
-        const int2 v = src[c];
+        const int2 v = *reinterpret_cast<const int2 *>(ckp + dp_ck_row_word(la, lb, C, tail, st, k - 1, j0 + q * C2 + c));
         hop[c] = v.x;
         f[c] = v.y;
       }
@@ -203,7 +202,9 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           sh_a[grp][r] = v;
         }
       }
-      const int gl = gg * DP_CK_W - 1, sl = gl >> 6, ll = gl & 63; // the lane left of the group (of the previous stripe for l0 = 0)
+      // the lane left of the group: the last lane of the group to the left, in the stripe that group lies in
+      const DpStripe stl = dp_stripe_of_col(lb, C, tail, gg > 0 ? (i64)gg * BW - 1 : 0);
+      const int ll = gg > 0 ? (gg * BW - 1 - stl.jb) / stl.cs : 0;
       for(int rr = q; rr <= nrows; rr += LPP) {
         const int row = i0 - 1 + rr; // row of A; -1 is the DP's row 0
         int2 v;
@@ -214,7 +215,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           v = make_int2(-2 * gop, DP_NEG_INF); // H~[0][j0] - gop, j0 >= 1
         }
         else {
-          v = *reinterpret_cast<const int2 *>(ckp + dp_ck_col_word(la, sl, (i64)row + ll, ll));
+          v = *reinterpret_cast<const int2 *>(ckp + dp_ck_col_word(la, gg - 1, (i64)row + ll));
         }
         sh_left[grp][rr] = v;
       }
@@ -394,7 +395,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
 
 template <int C, int LPP, bool DOT4>
 static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b, const int *order, i64 n, const i64 *tb_off,
-                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, const DpBand &band, hipStream_t stream) {
+                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, const DpBand &band, int tail, hipStream_t stream) {
   constexpr int G = 64 / LPP;
   const unsigned blocks = (unsigned)((n + G - 1) / G);
   static const int ablate = getenv("PM_DP_WALK_ABLATE") ? atoi(getenv("PM_DP_WALK_ABLATE")) : 0;
@@ -402,18 +403,18 @@ static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, c
   if(with_band) {
     const unsigned bblocks = (unsigned)((band.n_work + G - 1) / G);
     dp_walk_kernel<C, LPP, DOT4><<<bblocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, band.n_work, tb_off, ck, ops, n_ops, P, band, 1,
-                                                             ablate);
+                                                             ablate, tail);
     PM_HIP(hipGetLastError());
   }
   dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, with_band ? 2 : 0,
-                                                          ablate);
+                                                          ablate, tail);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
 
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
-                   const DpBand &band, hipStream_t stream) {
+                   const DpBand &band, int tail, hipStream_t stream) {
   if(n <= 0) {
     return PM_OK;
   }
@@ -421,8 +422,8 @@ int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *
 #define WALK(CC, LL)                                                                                                        \
   if constexpr((CC * DP_CK_W) % LL == 0 && (CC * DP_CK_W) / LL >= 1 && (CC * DP_CK_W) / LL <= 8 && CC % ((CC * DP_CK_W) / LL) == 0) { \
     if(lanes_per_pair == LL) {                                                                                              \
-      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, stream) \
-                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, stream); \
+      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, stream) \
+                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, stream); \
     }                                                                                                                       \
   }
   if(cols_per_lane == 16) {

@@ -93,7 +93,10 @@ static int run_command(const std::string &cmd, std::map<std::string, std::string
       fprintf(stderr, "-devices takes a comma-separated list of device indices\n");
       return 2;
     }
-    if(!devs.empty()) {
+    if(devs.size() == 1) { // a list of one is the one-device path on that device (as in m_translate)
+      device = devs[0];
+    }
+    if(devs.size() > 1) {
       rc = pm_translate_files_multi(flag["-profiles_left"].c_str(), flag["-profiles_right"].c_str(), cpaths.data(), (int)cpaths.size(),
                                     flag["-out_delta"].c_str(), devs.data(), (int)devs.size());
     }
@@ -125,7 +128,10 @@ static int run_command(const std::string &cmd, std::map<std::string, std::string
       fprintf(stderr, "-devices takes a comma-separated list of device indices\n");
       return 2;
     }
-    if(!devs.empty()) {
+    if(devs.size() == 1) {
+      device = devs[0];
+    }
+    if(devs.size() > 1) {
       rc = pm_dp_align_maf_multi(flag["-left_maf"].c_str(), flag["-right_maf"].c_str(), &prm, flag["-out_maf"].c_str(), devs.data(), (int)devs.size());
     }
     else {

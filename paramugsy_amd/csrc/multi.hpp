@@ -44,7 +44,8 @@ template <typename F>
 int run_on_devices(const int *devices, int n_devices, F fn, std::vector<int> *rc_out = nullptr) {
   std::vector<int> rc((size_t)n_devices, PM_OK);
   std::vector<std::string> msg((size_t)n_devices);
-  std::vector<std::thread> th;
+  std::vector<JoinThread> th; // (joined also when starting a later worker throws)
+  th.reserve((size_t)n_devices);
   for(int w = 0; w < n_devices; ++w) {
     th.emplace_back([&, w]() {
       int r = use_device(devices[w]);
@@ -54,6 +55,9 @@ int run_on_devices(const int *devices, int n_devices, F fn, std::vector<int> *rc
         }
         catch(const std::exception &e) {
           r = fail(PM_E_INVALID, std::string("worker failed: ") + e.what());
+        }
+        catch(...) {
+          r = fail(PM_E_INVALID, "worker failed");
         }
       }
       rc[(size_t)w] = r;

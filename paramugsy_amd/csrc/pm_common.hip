@@ -101,6 +101,19 @@ void DevPool::trim() {
   }
 }
 
+hipError_t malloc_trimming(void **p, size_t n) {
+  hipError_t e = hipMalloc(p, n);
+  if(e == hipErrorOutOfMemory) {
+    (void)hipGetLastError(); // the failed allocation's sticky error
+    // only what nobody is using at the moment is kept in these caches, so giving it back cannot pull a buffer from under a call
+    dp_batch_cache_trim();
+    text_staging_trim();
+    DevPool::trim();
+    e = hipMalloc(p, n);
+  }
+  return e;
+}
+
 } // namespace pm
 
 extern "C" {

@@ -5,8 +5,11 @@
 
 #include <cstddef>
 #include <exception>
+#include <memory>
 #include <new>
 #include <string>
+#include <thread>
+#include <utility>
 
 #include "../../include/paramugsy_amd.h"
 
@@ -48,6 +51,59 @@ int guarded(const char *who, F body) {
   }
 }
 
+// A helper thread that is joined when it goes out of scope: an exception (or an early return) that unwinds past a joinable
+// std::thread ends the process in std::terminate instead of reaching guarded() above.  The body runs inside a catch-all: what it
+// throws is kept and thrown again by join_and_rethrow() in the thread that started it (plain join() and the destructor drop it).
+class JoinThread {
+public:
+  JoinThread() = default;
+  template <typename F>
+  explicit JoinThread(F body) : thrown_(std::make_shared<std::exception_ptr>()) {
+    std::shared_ptr<std::exception_ptr> slot = thrown_;
+    t_ = std::thread([body, slot]() mutable {
+      try {
+        body();
+      }
+      catch(...) {
+        *slot = std::current_exception();
+      }
+    });
+  }
+  JoinThread(JoinThread &&) = default;
+  JoinThread &operator=(JoinThread &&o) {
+    join();
+    t_ = std::move(o.t_);
+    thrown_ = std::move(o.thrown_);
+    return *this;
+  }
+  JoinThread(const JoinThread &) = delete;
+  JoinThread &operator=(const JoinThread &) = delete;
+  ~JoinThread() { join(); }
+  bool joinable() const { return t_.joinable(); }
+  void join() {
+    if(t_.joinable()) {
+      t_.join();
+    }
+  }
+  void join_and_rethrow() {
+    join();
+    if(thrown_ && *thrown_) {
+      std::exception_ptr e = *thrown_;
+      *thrown_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+
+private:
+  std::thread t_;
+  std::shared_ptr<std::exception_ptr> thrown_;
+};
+
+// hipMalloc that, when the device is out of memory, gives back what this library keeps from call to call (the buffer pool, the
+// kept DP batches with their gigabytes of workspace, the pinned staging pieces) and tries once more: a resident process must not
+// fail -- or quietly run a DP in more chunks -- while gigabytes sit unused in its own caches.
+hipError_t malloc_trimming(void **p, size_t n);
+
 // Owning device allocation.
 struct DevBuf {
   void *p = nullptr;
@@ -68,7 +124,7 @@ struct DevBuf {
     if(n == 0) {
       n = 16; // keep pointers non-null so kernels can take them unconditionally
     }
-    hipError_t e = hipMalloc(&p, n);
+    hipError_t e = malloc_trimming(&p, n);
     if(e != hipSuccess) {
       p = nullptr;
       return fail(PM_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -126,7 +182,7 @@ struct PooledBuf {
     device = dev;
     p = DevPool::take(dev, n, &bytes);
     if(!p) {
-      hipError_t e = hipMalloc(&p, n);
+      hipError_t e = malloc_trimming(&p, n);
       if(e != hipSuccess) {
         p = nullptr;
         return fail(PM_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));

@@ -481,22 +481,22 @@ extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const 
   Workload w;
   int rc_l = PM_OK, rc_r = PM_OK;
   std::string msg_l, msg_r;
-  std::thread tl([&]() {
+  JoinThread tl([&]() {
     rc_l = make_profiles(left_maf, left_dir, left_basename, device, &w.left);
     if(rc_l) {
       msg_l = pm_last_error(); // the error slot is per thread
     }
   });
-  std::thread tr([&]() {
+  JoinThread tr([&]() {
     rc_r = make_profiles(right_maf, right_dir, right_basename, device, &w.right);
     if(rc_r) {
       msg_r = pm_last_error();
     }
   });
-  std::thread td([&]() { parse_deltas(paths, w); }); // touches w.table and w.parse_* only
-  tl.join();
-  tr.join();
-  td.join();
+  JoinThread td([&]() { parse_deltas(paths, w); }); // touches w.table and w.parse_* only
+  tl.join_and_rethrow();
+  tr.join_and_rethrow();
+  td.join_and_rethrow();
   if(rc_l) {
     return fail(rc_l, msg_l);
   }

@@ -510,13 +510,13 @@ void enumerate_units(const Side &left, const Side &right, const DeltaTable &t, s
     hi = first + n * (k + 1) / n_threads;
   };
   auto run = [&](const std::function<void(size_t)> &fn) {
-    std::vector<std::thread> th;
+    std::vector<JoinThread> th;
     for(size_t k = 1; k < n_threads; ++k) {
-      th.emplace_back(fn, k);
+      th.emplace_back([&fn, k]() { fn(k); });
     }
     fn(0);
     for(size_t k = 0; k < th.size(); ++k) {
-      th[k].join();
+      th[k].join_and_rethrow();
     }
   };
   run([&](size_t k) {
@@ -601,26 +601,9 @@ static void build_enum_tables(const Side &left, const Side &right, const DeltaTa
       et.entry_seq[sd][d] = last_id;
     }
   };
-  std::exception_ptr failed; // an allocation failure in the helper thread must reach the caller's guard, not std::terminate
-  std::thread other([&]() {
-    try {
-      one(1);
-    }
-    catch(...) {
-      failed = std::current_exception();
-    }
-  });
-  try {
-    one(0);
-  }
-  catch(...) {
-    other.join();
-    throw;
-  }
-  other.join();
-  if(failed) {
-    std::rethrow_exception(failed);
-  }
+  JoinThread other([&]() { one(1); }); // (what it throws -- an allocation failure -- reaches the caller's guard, not std::terminate)
+  one(0);
+  other.join_and_rethrow();
 }
 
 // ------------------------------------------------------------------ text out
@@ -660,13 +643,13 @@ static void touch_pages(const std::vector<std::pair<char *, size_t> > &bufs) {
       }
     }
   };
-  std::vector<std::thread> th;
+  std::vector<JoinThread> th;
   for(size_t t = 1; t < n_threads; ++t) {
-    th.emplace_back(work, t);
+    th.emplace_back([&work, t]() { work(t); });
   }
   work(0);
   for(size_t k = 0; k < th.size(); ++k) {
-    th[k].join();
+    th[k].join_and_rethrow();
   }
 }
 
@@ -775,13 +758,13 @@ void parse_deltas(const std::vector<std::string> &delta_paths, Workload &w) {
       }
     }
   };
-  std::vector<std::thread> th;
+  std::vector<JoinThread> th;
   for(size_t k = 1; k < n_threads; ++k) {
-    th.emplace_back(work);
+    th.emplace_back([&work]() { work(); });
   }
   work();
   for(size_t k = 0; k < th.size(); ++k) {
-    th[k].join();
+    th[k].join_and_rethrow();
   }
   size_t upto = n;
   for(size_t k = 0; k < n; ++k) {
@@ -844,26 +827,9 @@ void index_and_enumerate(Workload &w) {
 
 // Only the index: the job lists the units itself (run_workload with w.units_listed false).
 void index_sides(Workload &w) {
-  std::exception_ptr failed;
-  std::thread other([&]() {
-    try {
-      build_side_index(w.right);
-    }
-    catch(...) {
-      failed = std::current_exception();
-    }
-  });
-  try {
-    build_side_index(w.left);
-  }
-  catch(...) {
-    other.join();
-    throw;
-  }
-  other.join();
-  if(failed) {
-    std::rethrow_exception(failed);
-  }
+  JoinThread other([&]() { build_side_index(w.right); });
+  build_side_index(w.left);
+  other.join_and_rethrow();
   w.units = UnitList();
   w.units_listed = false;
 }
@@ -900,7 +866,7 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   int init_rc = PM_OK;
   std::string init_msg;
   double init_s = 0;
-  std::thread init([&]() {
+  JoinThread init([&]() {
     const double i0 = wall_now();
     init_rc = use_device(device);
     if(init_rc) {
@@ -921,7 +887,7 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   Workload w;
   int load_rc = load_workload(left_dir, right_dir, delta_paths, w, false);
   std::string load_msg = load_rc ? pm_last_error() : "";
-  init.join();
+  init.join_and_rethrow();
   if(init_rc) {
     return fail(init_rc, init_msg);
   }
@@ -1039,7 +1005,7 @@ int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool tim
     written[(size_t)k].store(0);
   }
   std::atomic<int> write_failed(0);
-  std::vector<std::thread> writers;
+  std::vector<JoinThread> writers;
   for(int w = 0; w < n_writers; ++w) {
     writers.emplace_back([&, w]() {
       for(int64_t k = w; k < n_pieces; k += n_writers) {
@@ -1048,6 +1014,9 @@ int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool tim
             return;
           }
           std::this_thread::yield();
+        }
+        if(write_failed.load()) { // the output has failed already (a full disk): no further piece of it is written
+          return;
         }
         const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
         const char *src = stage.p[k % n_buf];
@@ -1077,6 +1046,10 @@ int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool tim
       }
       std::this_thread::yield();
     }
+    if(write_failed.load()) { // no copy into a buffer a writer may still hold, no further copies for an output that has failed
+      ready.store(-1, std::memory_order_release);
+      break;
+    }
     const int64_t first = k * piece, n = std::min(piece, n_bytes - first);
     hipError_t e = hipMemcpy(stage.p[k % n_buf], dev + first, (size_t)n, hipMemcpyDeviceToHost);
     if(e != hipSuccess) {
@@ -1093,6 +1066,9 @@ int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool tim
   const double t1 = wall_now();
   for(size_t w = 0; w < writers.size(); ++w) {
     writers[w].join();
+  }
+  for(size_t w = 0; w < writers.size(); ++w) {
+    writers[w].join_and_rethrow();
   }
   if(!rc && write_failed.load()) {
     rc = fail(PM_E_IO, std::string("write failed: ") + strerror(write_failed.load()));
@@ -1175,8 +1151,8 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
     }
     double t4 = now();
     // the job's forty device buffers are freed (milliseconds of hipFree) while the last pieces of the text are written
-    std::thread reaper;
-    auto reap = [&]() { reaper = std::thread([job]() { pm_job_destroy(job); }); };
+    JoinThread reaper;
+    auto reap = [&]() { reaper = JoinThread([job]() { pm_job_destroy(job); }); };
     if(!rc && n_bytes > 0) {
       rc = device_bytes_to_sink(job_text_device(job), n_bytes, out, timing, reap);
     }
@@ -1277,7 +1253,7 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
     // the two sides side by side; the devices' runtimes come up meanwhile
     int rc_r = PM_OK;
     std::string msg_r;
-    std::thread other([&]() {
+    JoinThread other([&]() {
       rc_r = load_side(right_dir, right);
       if(rc_r) {
         msg_r = pm_last_error();
@@ -1286,7 +1262,7 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
         build_side_index(right);
       }
     });
-    std::thread warm([&]() {
+    JoinThread warm([&]() {
       for(int k = 0; k < n_devices; ++k) {
         if(use_device(devices[k]) == PM_OK) {
           (void)warm_translate_kernels();
@@ -1298,7 +1274,7 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
       build_side_index(left);
     }
     std::string msg_l = rc_l ? pm_last_error() : "";
-    other.join();
+    other.join_and_rethrow();
     warm.join();
     if(rc_l) {
       return fail(rc_l, msg_l);
