@@ -229,12 +229,41 @@ typedef struct pm_dp_params {
 
 typedef struct pm_dp_batch pm_dp_batch_t; /* opaque; owns device memory */
 
+/* How a batch is run -- every field 0: chosen per batch by the library (what production callers pass, or NULL).  Tests, the fuzzer and
+ * the timing tools set fields to force one variant or another; the library reads no environment variable for any of this.  A batch
+ * takes its options when it is created (pm_dp_batch_create_opt, pm_dp_stream_create_opt); the entry points that make their batches
+ * themselves (pm_dp_align_*, pm_dp_stream_create, pm_dp_batch_create) take the process's defaults, pm_dp_set_default_options. */
+typedef struct pm_dp_options {
+  int32_t path_mode;       /* 1: paths from stored decision bits; 2: from checkpoints and recomputed blocks */
+  int32_t cols_per_lane;   /* 8 or 16 columns of B per lane and stripe */
+  int32_t waves_per_pair;  /* 1, 2, 4, 8, 16 wavefronts per pair */
+  int32_t groups_per_pair; /* 1: one workgroup per pair, always; 2, 4, ...: that many (with waves_per_pair >= 2) */
+  int32_t band;            /* 1: never; 2: whenever it fits (the walk's precomputed blocks around the diagonal) */
+  int32_t walk_lanes;      /* lanes per pair of the checkpoint walk (a power of two) */
+  int32_t int16_weights;   /* 1: the int16 column weights also where int8 would do */
+  int32_t no_uniform_depth;/* 1: the general column score also where every column of A holds the same number of symbols */
+  int32_t keep_order;      /* 1: pairs are processed in input order (default: longest first) */
+  int32_t no_tiers;        /* 1: a chunk's longest pairs are not put into launches of their own */
+  int32_t tier_min_pairs;  /* chunks of at least this many pairs may get tiers (default 4 096) */
+  int32_t full_stripes;    /* 1: the last stripe of a pair is as wide as the others (default: narrower last stripes, 16 columns per lane) */
+  int32_t slots;           /* 2..8 parts of the path workspace that the chunks of a batch that does not fit use in turn (default 3) */
+  int32_t split;           /* N >= 1: a batch that fits is cut into N chunks all the same (default: 1 or 2, by the size of its walk) */
+  int32_t no_gate;         /* 1: a chunk's fill kernel is not held back until the chunk before has nothing left to dispatch */
+  int32_t reserved;
+  int64_t segment_cells;   /* host-fed engine: no more upload segments than leave each this many cells (default 5e9) */
+} pm_dp_options_t;
+/* The defaults batches are created with when no options are given (NULL: all zero again).  Copied under a lock. */
+int pm_dp_set_default_options(const pm_dp_options_t *options);
+
 /* Upload a batch (host pointers).  tb_budget_bytes bounds the path workspace (<= 0: 60 % of the device's memory; only what the
  * batch needs is allocated); a batch that needs more is processed in chunks of a third of it, the fill kernels of consecutive
  * chunks on streams of their own (one takes the SIMDs the other leaves as it drains), the path kernel of a chunk beside the
  * fill kernels of the next. */
 int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
                        const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out);
+int pm_dp_batch_create_opt(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
+                           const pm_dp_params_t *params, const pm_dp_options_t *options, int64_t tb_budget_bytes, int device,
+                           pm_dp_batch_t **out);
 /* One pass over every pair: fill (scores, and what the path walk needs) and, when traceback != 0, the path walk.
  * Asynchronous on hip_stream. */
 int pm_dp_batch_run(pm_dp_batch_t *batch, int traceback, void *hip_stream);
@@ -275,6 +304,8 @@ typedef struct pm_dp_stream pm_dp_stream_t;
 int pm_dp_host_alloc(void **ptr, int64_t bytes);
 void pm_dp_host_free(void *ptr);
 int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t workspace_bytes, int device, pm_dp_stream_t **out);
+int pm_dp_stream_create_opt(const pm_dp_params_t *params, const pm_dp_options_t *options, int32_t segments, int64_t workspace_bytes, int device,
+                            pm_dp_stream_t **out);
 int pm_dp_stream_align(pm_dp_stream_t *stream, const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b,
                        int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops);
 /* The same fed with ROW TEXTS instead of packed columns: pair k = block k of each side in the flat description of pm_dp_pack_maf

@@ -12,6 +12,7 @@
 
 struct pm_dp_batch {
   int device = 0;
+  pm_dp_options_t opt = {}; // how this batch is run (all zero: chosen per batch); copied at dp_batch_init
   pm::i64 n_pairs = 0, total_a = 0, total_b = 0;
   std::vector<pm::i64> off_a, off_b;
   pm::DevBuf cols_a, cols_b, d_off_a, d_off_b, bnd, scores, ops, n_ops, tb, d_tb_off, d_order, stats;
@@ -23,17 +24,20 @@ struct pm_dp_batch {
   pm::DpParamsD params;
   int max_sub_acgt = 0, max_sub_all = 0;
   pm::i64 cells = 0;
-  int cols_per_lane = 16; // columns of B a lane owns per stripe: 16, 8 for small batches (dp_batch_plan); PM_DP_COLS fixes it
+  int cols_per_lane = 16; // columns of B a lane owns per stripe: 16, 8 for small batches (dp_batch_plan); opt.cols_per_lane fixes it
   bool cols_forced = false;
-  bool dot4 = false;      // all counts and ACGT weights fit int8 (PM_DP_DOT4=0 forces the int16 path)
-  bool uni = false;       // every column of A holds the same number of symbols: gap row folded into the weights (PM_DP_UNI=0 disables)
-  int waves_override = 0; // PM_DP_WAVES=1|2|4|8 forces the waves-per-pair choice
-  bool tail = false;      // the narrow last stripes of dp_internal.hpp (checkpoint mode, 16 columns per lane; PM_DP_TAIL=0 disables)
+  bool dot4 = false;      // all counts and ACGT weights fit int8 (opt.int16_weights forces the int16 path)
+  bool uni = false;       // every column of A holds the same number of symbols: gap row folded into the weights (opt.no_uniform_depth)
+  int waves_override = 0; // opt.waves_per_pair
+  bool tail = false;      // the narrow last stripes of dp_internal.hpp (checkpoint mode, 16 columns per lane; opt.full_stripes disables)
   bool ckpt = true;       // paths from checkpoints + block recomputation (dp_walk.hip), or 4 stored decision bits per cell
-  bool mode_auto = true;  // ckpt chosen per batch in dp_batch_plan (PM_DP_MODE=bits|ckpt fixes it)
-  int walk_lanes = 0;     // lanes per pair of the checkpoint walk; 0 = chosen per launch; PM_DP_WALK_LANES overrides
+  bool mode_auto = true;  // ckpt chosen per batch in dp_batch_plan (opt.path_mode fixes it)
+  int walk_lanes = 0;     // lanes per pair of the checkpoint walk; 0 = chosen per launch; opt.walk_lanes overrides
   pm::DevBuf pipe_error;
-  pm::DevBuf gprog; // progress words of pairs whose stripes run on several workgroups (dp_fill_kernel, NG)
+  // progress words of pairs whose stripes run on several workgroups (dp_fill_kernel, NG): an arena sized by dp_run for all the
+  // launches of a pass, every launch taking a piece of its own (launches of one pass may overlap on their streams)
+  pm::DevBuf gprog;
+  size_t gprog_used = 0;
   // the band of the checkpoint walk (dp_internal.hpp), set up by dp_batch_plan for one-chunk batches of few pairs
   pm::DevBuf d_band_work, d_band_off, band_bits;
   pm::i64 band_work_items = 0; // 0: no band
@@ -56,12 +60,13 @@ struct pm_dp_batch {
   std::vector<hipEvent_t> tier_events;
   std::vector<pm::i64> chunk_groups; // workgroups of every chunk's fill launch (filled in by dp_run as it launches)
   pm::DevBuf fill_started;           // per chunk: workgroups of its fill kernel that have started (the gate of the next chunk's)
+  pm::DevBuf tier_started;           // per chunk: workgroups of its tiers' fill kernels that have started (the gate of the launch of the rest)
   hipStream_t path_stream = nullptr;
   // the fill kernels of every slot run on a stream of their own, so that chunk c + 1's first wavefronts take the SIMDs chunk c's
   // last ones leave (a launch ends with the chip draining: its last round of pairs fills only part of it); ev_begin orders that
   // stream behind whatever the caller's stream held when dp_run was called
   float last_fill_busy_ms = 0;           // profiled run: the time during which some fill kernel ran (launches may overlap)
-  int n_slots = 3;                       // parts of the workspace that consecutive chunks use in turn (PM_DP_SLOTS)
+  int n_slots = 3;                       // parts of the workspace that consecutive chunks use in turn (opt.slots)
   std::vector<hipStream_t> fill_streams; // for the chunks of slots 1 .. n_slots - 1 (slot 0: the caller's stream)
   hipEvent_t ev_begin = nullptr;
   std::vector<hipEvent_t> ev_fill, ev_path;                       // per chunk: fill done / path done
@@ -109,7 +114,8 @@ namespace pm {
 // The steps pm_dp_batch_create is made of (dp_kernels.hip).  A reusable batch goes reserve once, then load / plan / run per slice.
 int64_t dp_default_budget_bytes();
 int dp_batch_check_params(const pm_dp_params_t *params);
-int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device);
+// options == nullptr: the process's defaults (pm_dp_set_default_options)
+int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, const pm_dp_options_t *options = nullptr);
 int dp_clear_pipe_error(pm_dp_batch *h); // synchronous (see dp_kernels.hip)
 // device buffers for up to cap_pairs pairs with cap_a / cap_b columns in all; only grows
 int dp_batch_reserve(pm_dp_batch *h, i64 cap_pairs, i64 cap_a, i64 cap_b);

@@ -339,7 +339,7 @@ __device__ __forceinline__ int4 dp_expand_row(u64 col) {
 // cols_per_lane (of the fill kernel) in {8, 16}; lanes_per_pair a power of two for which dp_walk_lanes_ok() holds.
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
-                   const DpBand &band, int tail, hipStream_t stream);
+                   const DpBand &band, int tail, int urgent, hipStream_t stream);
 
 bool dp_walk_lanes_ok(int cols_per_lane, int lanes_per_pair);
 

@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -435,6 +436,9 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
                int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P, int ng, int *__restrict__ gprog,
                int *__restrict__ started, int tail) {
   static_assert(C % 8 == 0, "whole traceback words per lane per step");
+  if(NW > 1) { // several wavefronts per pair: a launch of few, long pairs (a tier beside the launch of the rest): ahead of those at issue
+    __builtin_amdgcn_s_setprio(2);
+  }
   if(started && threadIdx.x == 0) { // dp_gate_kernel: once every workgroup of this launch has started, the next chunk's may
     __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -666,29 +670,35 @@ int dp_clear_pipe_error(pm_dp_batch *h) {
   return PM_OK;
 }
 
-int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device) {
+// The process's default options (pm_dp_set_default_options): what a batch is created with when its creator passes none.
+static std::mutex g_default_options_lock;
+static pm_dp_options_t g_default_options = {};
+
+int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, const pm_dp_options_t *options) {
   h->device = device;
-  if(const char *e = getenv("PM_DP_SLOTS")) { // parts of the path workspace / fill streams of a batch that needs several chunks
-    const int k = atoi(e);
-    h->n_slots = k >= 2 && k <= 8 ? k : 3;
+  if(options) {
+    h->opt = *options;
   }
-  if(const char *e = getenv("PM_DP_WAVES")) {
-    h->waves_override = atoi(e);
+  else {
+    std::lock_guard<std::mutex> hold(g_default_options_lock);
+    h->opt = g_default_options;
   }
-  if(const char *e = getenv("PM_DP_COLS")) {
-    h->cols_per_lane = atoi(e) == 8 ? 8 : 16;
-    h->cols_forced = true;
+  const pm_dp_options_t &o = h->opt;
+  if(o.path_mode < 0 || o.path_mode > 2 || (o.cols_per_lane != 0 && o.cols_per_lane != 8 && o.cols_per_lane != 16) ||
+     (o.waves_per_pair != 0 && o.waves_per_pair != 1 && o.waves_per_pair != 2 && o.waves_per_pair != 4 && o.waves_per_pair != 8 &&
+      o.waves_per_pair != 16) ||
+     o.groups_per_pair < 0 || o.band < 0 || o.band > 2 || o.walk_lanes < 0 || (o.slots != 0 && (o.slots < 2 || o.slots > 8)) || o.split < 0 ||
+     o.split > 64 || o.segment_cells < 0 || o.tier_min_pairs < 0) {
+    return fail(PM_E_INVALID, "pm_dp_options_t: a field is out of range");
   }
-  if(const char *e = getenv("PM_DP_MODE")) { // bits | ckpt; anything else (or unset): chosen per batch in dp_batch_plan
-    h->mode_auto = strcmp(e, "bits") != 0 && strcmp(e, "ckpt") != 0;
-    h->ckpt = strcmp(e, "bits") != 0;
-  }
-  if(const char *e = getenv("PM_DP_WALK_LANES")) {
-    int v = atoi(e);
-    if(dp_walk_lanes_ok(h->cols_per_lane, v)) {
-      h->walk_lanes = v;
-    }
-  }
+  // (a batch may be initialised again for its next use -- the kept batches of dp_maf.hip: every field from the options, every time)
+  h->n_slots = o.slots ? o.slots : 3; // parts of the path workspace / fill streams of a batch that needs several chunks
+  h->waves_override = o.waves_per_pair;
+  h->cols_per_lane = o.cols_per_lane == 8 ? 8 : 16;
+  h->cols_forced = o.cols_per_lane != 0;
+  h->mode_auto = o.path_mode == 0; // else fixed; chosen per batch in dp_batch_plan
+  h->ckpt = o.path_mode != 1;
+  h->walk_lanes = o.walk_lanes && dp_walk_lanes_ok(h->cols_per_lane, o.walk_lanes) ? o.walk_lanes : 0;
   memcpy(h->params.sub, params->sub, sizeof h->params.sub);
   h->params.go = params->gap_open;
   h->params.ge = params->gap_extend;
@@ -862,8 +872,7 @@ int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int6
     for(int64_t k = 0; k < n_pairs; ++k) {
       cells += (double)(h->off_a[(size_t)k + 1] - h->off_a[(size_t)k]) * (double)(h->off_b[(size_t)k + 1] - h->off_b[(size_t)k]);
     }
-    const char *env = getenv("PM_DP_SEGMENT_CELLS"); // tests cut tiny batches into many segments
-    const double per_segment = env ? std::max(1.0, atof(env)) : 5e9;
+    const double per_segment = h->opt.segment_cells > 0 ? (double)h->opt.segment_cells : 5e9; // (tests cut tiny batches into many segments)
     segments = (int)std::min<int64_t>(segments, std::max<int64_t>(1, (int64_t)(cells / per_segment)));
   }
   segments = (int)std::max<int64_t>(1, std::min<int64_t>(segments, std::max<int64_t>(n_pairs, 1)));
@@ -983,16 +992,14 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
         h->dot4 = uni_dot4;
       }
     }
-    if(const char *e = getenv("PM_DP_UNI")) {
-      if(atoi(e) == 0 && h->uni) {
-        h->uni = false;
-        h->dot4 = max_a <= 127 && max_colsum_b * h->max_sub_acgt <= 127;
-      }
+    if(h->opt.no_uniform_depth && h->uni) {
+      h->uni = false;
+      h->dot4 = max_a <= 127 && max_colsum_b * h->max_sub_acgt <= 127;
     }
     h->params.rows_a = h->uni ? st[1] : 0;
   }
-  if(const char *e = getenv("PM_DP_DOT4")) {
-    h->dot4 = h->dot4 && atoi(e) != 0;
+  if(h->opt.int16_weights) {
+    h->dot4 = false;
   }
   // Columns of B per lane: 16, or 8 for a batch of a few hundred pairs at most whose profiles fit one 1 024-column stripe --
   // two stripes of 512 then, so twice the wavefronts a pair can keep busy, each with half the work per step (256 pairs of
@@ -1002,7 +1009,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // 7.7 -> 6.9 ms, walk 0.85 -> 1.16 ms; from ~250 pairs up 16 columns win again).
   // the offset tables go through the batch's pinned staging when it has one (dp_stream.hip)
   const bool staged = h->pinned && h->pinned_bytes >= (size_t)(4 * (n_pairs + 1)) * 8 + 64 + 32;
-  const int band_env = getenv("PM_DP_BAND") ? atoi(getenv("PM_DP_BAND")) : -1; // 0: never, 1: whenever it fits
+  const int band_env = h->opt.band == 1 ? 0 : (h->opt.band == 2 ? 1 : -1); // 0: never, 1: whenever it fits, -1: chosen below
   if(!h->cols_forced) {
     i64 max_lb = 0;
     for(i64 k = 0; k < n_pairs; ++k) {
@@ -1042,8 +1049,8 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     const bool band_likely = !staged && band_env != 0 && (band_env > 0 || band_pays(n_pairs, dp_walk_lanes_for(h, n_pairs)));
     h->ckpt = fill_saved_s > (band_likely ? 30e-6 + chain_blocks * 4e-6 : chain_blocks * 15e-6);
   }
-  // the narrow last stripes (dp_internal.hpp): wherever the path comes from checkpoints and a lane has 16 columns.  PM_DP_TAIL=0: not.
-  h->tail = h->ckpt && h->cols_per_lane == 16 && !(getenv("PM_DP_TAIL") && atoi(getenv("PM_DP_TAIL")) == 0);
+  // the narrow last stripes (dp_internal.hpp): wherever the path comes from checkpoints and a lane has 16 columns
+  h->tail = h->ckpt && h->cols_per_lane == 16 && !h->opt.full_stripes;
   auto need_words = [&](i64 k) {
     i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
     return h->ckpt ? dp_ck_words(la, lb, h->cols_per_lane, h->tail) : dp_tb_words(la, lb, h->cols_per_lane);
@@ -1056,7 +1063,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   for(i64 k = 0; k < n_pairs; ++k) {
     h->order[(size_t)k] = (int)k;
   }
-  if(h->seg_first.empty() && !getenv("PM_DP_KEEP_ORDER")) {
+  if(h->seg_first.empty() && !h->opt.keep_order) {
     std::vector<i64> cost((size_t)n_pairs);
     for(i64 k = 0; k < n_pairs; ++k) {
       const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
@@ -1075,20 +1082,39 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // of the next, and those beside each other where one drains and the next fills in (dp_run)
   // the workspace is allocated to what the chunks need; if the device cannot give that much (other allocations beside this
   // batch) the budget is halved and the batch cut into more chunks, down to 256 MiB
-  // A batch that fits is ONE chunk: one fill launch, one path launch.  Cutting it all the same (PM_DP_SPLIT=N: N chunks of about
-  // equal workspace, each with a part of its own, the path kernel of one beside the fill kernel of the next, nothing lost at the
-  // cuts thanks to dp_gate_kernel) was measured and does not pay: the path kernel is real work for the same SIMDs, it takes as
-  // long beside a fill kernel as it saves, and small path launches are slower (profiles/r03_dp_chunks.txt: the ragged 100 k-pair
-  // batch 109.6 ms whole, 108.1 in 3, 110.7 in 9; 10 k pairs of 2 x 1 kbp 2.88 ms whole, 3.28 in 2).
+  // A batch that fits is one chunk -- one fill launch, one path launch -- unless its path kernel is worth hiding: a batch of
+  // at least 4 096 pairs whose fill takes 20 ms or more and whose walk would add 8 % or more to it is cut in two chunks of about equal
+  // workspace, each with a part of its own, the path kernel of the first beside the fill kernel of the second (nothing is lost at
+  // the cut: dp_gate_kernel).  Measured on one MI355X: 12 500 pairs of 8 x 4 096 (one GPU's eighth of the headline batch) 43.9 -> 42.2 ms
+  // (profiles/r04_dp_shares.txt); 25 000 pairs +0.4 %; the ragged 100 k-pair batch 109.6 -> 108.1 ms.  Not for smaller work: the path
+  // kernel is real work for the same SIMDs, and launches of a few milliseconds lose more at their ends than the overlap gains (10 k
+  // pairs of 2 x 1 kbp: 2.88 ms whole, 3.28 in two; more than two chunks: 12 500 pairs 44.7 ms in four).  opt.split fixes the number.
   i64 split = 1;
-  if(const char *e = getenv("PM_DP_SPLIT")) {
-    const i64 v = atoll(e);
-    split = v >= 1 && v <= 64 && !staged ? std::min<i64>(v, std::max<i64>(n_pairs, 1)) : split;
+  bool uneven = false;
+  if(h->opt.split >= 1) {
+    split = !staged ? std::min<i64>(h->opt.split, std::max<i64>(n_pairs, 1)) : 1;
+  }
+  else if(h->ckpt && !staged && h->seg_first.empty() && n_pairs >= 4096) {
+    double padded_cells = 0, walk_cells = 0;
+    for(i64 k = 0; k < n_pairs; ++k) {
+      const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+      padded_cells += (double)(la + 63) * (double)dp_padded_cols(lb, h->cols_per_lane, h->tail);
+      walk_cells += (double)DP_CK_R * (double)(la + lb); // the blocks a path crosses: about 64 (La + Lb) cells
+    }
+    const double fill_s = padded_cells / 5.6e12, walk_s = walk_cells / 1.2e12; // measured rates of the two kernels, each alone
+    if(fill_s >= 0.020 && walk_s >= 0.08 * (fill_s + walk_s)) {
+      split = 2;
+      // three quarters and a quarter, so that the path kernel left alone at the end is the short one (the first has the second chunk's
+      // fill kernel to run beside: a quarter of the fill is still twice the first chunk's walk) -- where a quarter is still a launch
+      // of one wavefront per pair (25 000 pairs of 8 x 4 096: 79.0 ms in halves, 76.7 so; 12 500: 42.2 in halves, 43.9 so -- its
+      // quarter, 3 125 pairs, is a launch of two wavefronts per pair)
+      uneven = n_pairs >= 4 * 4096;
+    }
   }
   bool pipelined = false;
   for(i64 budget = h->tb_budget_bytes;; budget /= 2) {
     const bool one_chunk = total_words <= budget / 4;
-    const i64 budget_words = one_chunk ? (total_words + split - 1) / split + 64 : budget / (4 * h->n_slots);
+    i64 budget_words = one_chunk ? (uneven ? total_words / 4 * 3 : (total_words + split - 1) / split) + 64 : budget / (4 * h->n_slots);
     h->slot_reuse = !one_chunk;
     // chunk_first: positions in `order`; chunk_tb: the word offset of every position's pair inside its chunk's workspace
     h->chunk_first.assign(1, 0);
@@ -1104,6 +1130,9 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
         h->tb_words_cap = std::max(h->tb_words_cap, used);
         cur.clear();
         used = 0;
+        if(one_chunk && uneven) {
+          budget_words = total_words; // the second chunk takes the rest
+        }
       }
       cur.push_back(used);
       used += need;
@@ -1117,10 +1146,22 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     h->tb_half_words = pipelined ? ((h->tb_words_cap + 63) / 64) * 64 : 0;
     const i64 parts = pipelined ? (h->slot_reuse ? std::min<i64>(h->n_slots, (i64)h->chunk_tb.size()) : (i64)h->chunk_tb.size()) : 1;
     h->chunk_base.assign(h->chunk_tb.size(), 0);
-    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
-      h->chunk_base[c] = pipelined ? (i64)(h->slot_reuse ? c % (size_t)h->n_slots : c) * h->tb_half_words : 0;
+    i64 tb_total = pipelined ? parts * h->tb_half_words : h->tb_words_cap;
+    if(pipelined && !h->slot_reuse) { // every chunk has a part of its own, as large as it needs
+      i64 at = 0;
+      for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+        h->chunk_base[c] = at;
+        const i64 c_words = h->chunk_tb[c].empty() ? 0 : h->chunk_tb[c].back() + need_words(h->order[(size_t)(h->chunk_first[c + 1] - 1)]);
+        at += ((c_words + 63) / 64) * 64;
+      }
+      tb_total = at;
     }
-    const int rc = grow(h->tb, (size_t)(pipelined ? parts * h->tb_half_words : h->tb_words_cap) * 4);
+    else {
+      for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+        h->chunk_base[c] = pipelined ? (i64)(c % (size_t)h->n_slots) * h->tb_half_words : 0;
+      }
+    }
+    const int rc = grow(h->tb, (size_t)tb_total * 4);
     if(rc == PM_OK) {
       break;
     }
@@ -1130,27 +1171,16 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     }
   }
   if(pipelined) {
-    if(!h->path_stream) {
-      // PM_DP_PATH_PRIORITY=high|low: an experiment (the path kernels' waves ahead of / behind the fill kernel's at dispatch)
-      const char *pr = getenv("PM_DP_PATH_PRIORITY");
-      if(pr && (pr[0] == 'h' || pr[0] == 'l')) {
-        int least = 0, greatest = 0;
-        PM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        PM_HIP(hipStreamCreateWithPriority(&h->path_stream, hipStreamNonBlocking, pr[0] == 'h' ? greatest : least));
-      }
-      else {
-        PM_HIP(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking));
-      }
+    if(!h->path_stream) { // (at the highest or the lowest priority: measured, within the run-to-run spread, profiles/r03_c2_chunks_priority.txt)
+      PM_HIP(hipStreamCreateWithFlags(&h->path_stream, hipStreamNonBlocking));
     }
-    if(!getenv("PM_DP_ONE_FILL_STREAM")) {
-      while((int)h->fill_streams.size() < h->n_slots - 1) {
-        hipStream_t st = nullptr;
-        PM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        h->fill_streams.push_back(st);
-      }
-      if(!h->ev_begin) {
-        PM_HIP(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
-      }
+    while((int)h->fill_streams.size() < h->n_slots - 1) {
+      hipStream_t st = nullptr;
+      PM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      h->fill_streams.push_back(st);
+    }
+    if(!h->ev_begin) {
+      PM_HIP(hipEventCreateWithFlags(&h->ev_begin, hipEventDisableTiming));
     }
     while(h->ev_fill.size() < h->chunk_tb.size()) {
       hipEvent_t a = nullptr, b = nullptr;
@@ -1165,11 +1195,13 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // enough for dp_launch_fill to give them 8 and 4 wavefronts each (a third launch of the next 1 024 pairs, at 4 wavefronts each,
   // was the last to finish: 14.2 ms beside 11.6 for the rest).  Uniform batches have no such pairs.  PM_DP_NO_TIERS=1: not.
   h->chunk_tiers.assign(h->chunk_tb.size(), std::vector<i64>());
-  if(h->seg_first.empty() && !staged && !getenv("PM_DP_NO_TIERS") && !getenv("PM_DP_KEEP_ORDER") && h->waves_override == 0) {
+  if(h->seg_first.empty() && !staged && !h->opt.no_tiers && !h->opt.keep_order && h->waves_override == 0) {
     bool any = false;
     for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
       const i64 c_lo = h->chunk_first[c], c_hi = h->chunk_first[c + 1], n = c_hi - c_lo;
-      if(n < 4096) {
+      // (the wavefronts an evenly loaded chip runs side by side: 4 096; the fuzzer lowers the mark so that tiny batches get tiers too)
+      const i64 W = h->opt.tier_min_pairs > 0 ? h->opt.tier_min_pairs : 4096;
+      if(n < W) {
         continue; // dp_launch_fill already gives such a launch several wavefronts per pair
       }
       auto cost_at = [&](i64 q) {
@@ -1185,12 +1217,12 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       // longest pair finishes with the others up to a ratio of about three (measured on the ragged stand-in: ratio 3.9 at
       // 12 500 pairs, 1 877 -> 2 625 GCUPS with the tiers; 1.9 at 25 000 pairs, 3 550 -> 3 386: the launches of several
       // wavefronts per pair are the less efficient ones)
-      if((double)cost_at(c_lo) < 3.0 * total / 4096.0) {
+      if((double)cost_at(c_lo) < 3.0 * total / (double)W) {
         continue;
       }
-      const double limit = total / 4096.0 / 2.0;
+      const double limit = total / (double)W / 2.0;
       i64 heavy = 0; // the order is longest first: the heavy pairs are a prefix
-      while(heavy < n && heavy < 768 && (double)cost_at(c_lo + heavy) > limit) {
+      while(heavy < n && heavy < std::max<i64>(3 * W / 16, 1) && (double)cost_at(c_lo + heavy) > limit) {
         ++heavy;
       }
       if(heavy == 0 || heavy * 2 > n) {
@@ -1198,7 +1230,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       }
       std::vector<i64> &cuts = h->chunk_tiers[c];
       i64 at = 0;
-      for(i64 size : {(i64)256, (i64)512}) {
+      for(i64 size : {std::max<i64>(W / 16, 1), std::max<i64>(W / 8, 1)}) {
         if(at >= heavy) {
           break;
         }
@@ -1308,8 +1340,25 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
 
 extern "C" {
 
+int pm_dp_set_default_options(const pm_dp_options_t *options) {
+  std::lock_guard<std::mutex> hold(pm::g_default_options_lock);
+  if(options) {
+    pm::g_default_options = *options;
+  }
+  else {
+    pm::g_default_options = pm_dp_options_t{};
+  }
+  return PM_OK;
+}
+
 int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
                        const pm_dp_params_t *params, int64_t tb_budget_bytes, int device, pm_dp_batch_t **out) {
+  return pm_dp_batch_create_opt(cols_a, off_a, cols_b, off_b, n_pairs, params, nullptr, tb_budget_bytes, device, out);
+}
+
+int pm_dp_batch_create_opt(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
+                           const pm_dp_params_t *params, const pm_dp_options_t *options, int64_t tb_budget_bytes, int device,
+                           pm_dp_batch_t **out) {
   if(!out) {
     return fail(PM_E_INVALID, "pm_dp_batch_create: null out");
   }
@@ -1326,7 +1375,7 @@ int pm_dp_batch_create(const uint8_t *cols_a, const int64_t *off_a, const uint8_
   if(!h) {
     return fail(PM_E_INVALID, "out of host memory");
   }
-  int rc = dp_batch_init(h, params, tb_budget_bytes, device);
+  int rc = dp_batch_init(h, params, tb_budget_bytes, device, options);
   if(!rc) {
     rc = dp_batch_load(h, cols_a, off_a, cols_b, off_b, n_pairs, nullptr);
   }
@@ -1365,7 +1414,7 @@ __global__ void dp_gate_kernel(const int *__restrict__ started, int total) {
 // The fill kernel of chunk c into workspace `tbw`.  started: the chunk's counter of started workgroups, or null; *groups: the launch's
 // workgroups.
 static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int traceback, hipStream_t stream, int *started = nullptr,
-                          i64 *groups = nullptr, bool allow_groups = true) {
+                          i64 *groups = nullptr) {
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
   // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
@@ -1398,9 +1447,9 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
       hipDeviceProp_t prop;
       return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
     }();
-    // (allow_groups false: the launch may run beside another fill launch of this batch -- dp_run's fill streams -- and several
-    // workgroups per pair need every workgroup of the launch resident, and the batch's one set of progress words to themselves)
-    const int groups_env = !allow_groups ? 1 : (getenv("PM_DP_GROUPS") ? atoi(getenv("PM_DP_GROUPS")) : -1); // 1: never; 2, 4, ..: that many
+    // (also for a launch that runs beside another fill launch of this batch -- dp_run's fill streams, the tiers: every launch has
+    // progress words of its own, and the tickets make the order in which workgroups start irrelevant)
+    const int groups_env = h->opt.groups_per_pair ? h->opt.groups_per_pair : -1; // 1: never; 2, 4, ..: that many; -1: chosen here
     if(fits && groups_env > 1 && h->waves_override >= 2 && n * groups_env <= cus) { // both forced (tests)
       ng = groups_env;
     }
@@ -1422,17 +1471,27 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
       }
     }
   }
+  int *gprog = nullptr;
   if(ng > 1) {
-    // one progress word per wave of the launch, then the ticket counter the workgroups draw their places from
-    PM_TRY(grow(h->gprog, (size_t)(n * ng * nw + 1) * sizeof(int)));
-    PM_HIP(hipMemsetAsync(h->gprog.p, 0, (size_t)(n * ng * nw + 1) * sizeof(int), stream));
+    // one progress word per wave of the launch, then the ticket counter the workgroups draw their places from: this launch's own
+    // piece of the arena dp_run has sized for all the launches of a pass (two launches of a pass may overlap on their streams)
+    const size_t words = (size_t)(n * ng * nw + 1);
+    if(h->gprog_used + words > h->gprog.bytes / sizeof(int)) {
+      ng = 1; // (cannot happen: DP_GPROG_WORDS_PER_LAUNCH bounds n * ng * nw + 1)
+      nw = std::min(nw, 16);
+    }
+    else {
+      gprog = (int *)h->gprog.p + h->gprog_used;
+      h->gprog_used += words;
+      PM_HIP(hipMemsetAsync(gprog, 0, words * sizeof(int), stream));
+    }
   }
 #define DP_LAUNCH_FILL(CC, TR, D4, NWV, UN)                                                                                                  \
   dp_fill_kernel<CC, TR, D4, NWV, UN><<<(unsigned)(n * ng), 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,    \
                                                                                    (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p,    \
                                                                                    order, tb_off, tbw, (int2 *)h->bnd.p, (int *)h->scores.p, \
-                                                                                   (int *)h->pipe_error.p, h->params, ng, (int *)h->gprog.p, \
-                                                                                   started, h->tail ? 1 : 0)
+                                                                                   (int *)h->pipe_error.p, h->params, ng, gprog, started, \
+                                                                                   h->tail ? 1 : 0)
 #define DP_LAUNCH_FILL_D4(CC, TR, NWV)         \
   if(h->dot4 && h->uni) {                      \
     DP_LAUNCH_FILL(CC, TR, true, NWV, true);   \
@@ -1491,9 +1550,12 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
   return PM_OK;
 }
 
-// The path kernel of chunk c from workspace `tbw`: the checkpoint walk, or the walk over stored decision bits.
-static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStream_t stream) {
-  const i64 first = h->chunk_first[c], n = h->chunk_first[c + 1] - first;
+// The path kernel of the pairs at positions [first, first + n) (of one chunk) from the chunk's workspace `tbw`: the checkpoint walk,
+// or the walk over stored decision bits.
+static int dp_launch_path(pm_dp_batch *h, i64 first, i64 n, const unsigned *tbw, hipStream_t stream, bool urgent = false) {
+  if(n <= 0) {
+    return PM_OK;
+  }
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
   if(h->ckpt) {
@@ -1507,7 +1569,7 @@ static int dp_launch_path(pm_dp_batch *h, size_t c, const unsigned *tbw, hipStre
     }
     return dp_launch_walk(h->cols_per_lane, lpp, h->dot4, (const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
                           (const i64 *)h->d_off_b.p, order, n, tb_off, tbw, (unsigned char *)h->ops.p, (int *)h->n_ops.p, h->params, band,
-                          h->tail ? 1 : 0, stream);
+                          h->tail ? 1 : 0, urgent ? 1 : 0, stream);
   }
   if(h->cols_per_lane == 16) {
     dp_traceback_kernel<16><<<(unsigned)n, 64, 0, stream>>>((const i64 *)h->d_off_a.p, (const i64 *)h->d_off_b.p, order, tb_off, tbw,
@@ -1559,6 +1621,19 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
   // of the workspace, not by the fill kernel of the chunk before it
   const int K = h->n_slots;
   const bool two_fills = pipelined && (int)h->fill_streams.size() >= K - 1 && h->ev_begin && h->seg_first.empty();
+  // progress words for every launch of the pass that may ask for several workgroups per pair (dp_launch_fill takes a piece each):
+  // n * ng <= CUs and at most 16 waves per workgroup bound a launch's
+  {
+    size_t launches = 0;
+    for(size_t c = 0; c < nc; ++c) {
+      launches += 1 + (c < h->chunk_tiers.size() ? h->chunk_tiers[c].size() : 0) + (h->seg_first.empty() ? 0 : h->seg_first.size());
+    }
+    const size_t per_launch = 1024 * 16 + 1; // (an MI355X has 256 CUs; room for four times as many)
+    if(h->gprog.bytes < launches * per_launch * sizeof(int)) {
+      PM_TRY(h->gprog.alloc(launches * per_launch * sizeof(int))); // (hipFree of the old arena waits for the device: no launch of an earlier pass still uses it)
+    }
+    h->gprog_used = 0;
+  }
   int *started = nullptr;
   if(two_fills) {
     PM_TRY(grow(h->fill_started, nc * sizeof(int)));
@@ -1570,9 +1645,11 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       PM_HIP(hipStreamWaitEvent(h->fill_streams[(size_t)k], h->ev_begin, 0));
     }
   }
-  const bool gate_on = getenv("PM_DP_NO_GATE") == nullptr;
+  const bool gate_on = !h->opt.no_gate;
   long prev_chunk = -1; // the last chunk that had pairs
   hipStream_t caller_stream = stream;
+  i64 tiers_end = 0;       // the current chunk: the position behind its tiers (their path kernels ride on their own streams)
+  size_t tiers_joined = 0; // and how many tier streams its end has to wait for
   for(size_t c = 0; c < nc; ++c) {
     if(h->chunk_first[c + 1] - h->chunk_first[c] <= 0) {
       continue;
@@ -1595,6 +1672,8 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
     {
       const i64 c_lo = h->chunk_first[c], c_hi = h->chunk_first[c + 1];
       i64 at = c_lo;
+      tiers_end = c_lo;
+      tiers_joined = 0;
       for(size_t sg = 0; sg + 1 < h->seg_first.size() && at < c_hi; ++sg) {
         const i64 s_hi = std::min(h->seg_first[sg + 1], c_hi);
         if(s_hi <= at) {
@@ -1609,25 +1688,49 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       // the chunk's longest pairs in small launches of their own, on side streams, beside the launch of the rest
       if(at == c_lo && c < h->chunk_tiers.size() && !h->chunk_tiers[c].empty() && h->tier_streams.size() >= h->chunk_tiers[c].size() &&
          !h->tier_events.empty()) {
+        // A tier's path kernel follows its fill kernel on the tier's own stream: the walk of the longest pair is a chain of a few
+        // hundred blocks of about 15 us each -- milliseconds, whatever else the chip does -- and has to start as early as it can (the
+        // ragged eighth's one path kernel after everything: 5.3 ms, of which the rest of its pairs needed 2).
+        // The launch of the rest is held back (dp_gate_kernel) until every workgroup of the tiers has STARTED: when all of them become
+        // ready at once -- the passes of a caller that does not wait in between -- whichever the dispatcher takes first fills the chip,
+        // and the tiers, the launches the step waits for, got what the 11 700 workgroups of the rest left over (measured: a pass
+        // 15.1 ms with a wait in between, 20.0 without; the trace showed the rest starting 12 us ahead of the tiers).
         const std::vector<i64> &cuts = h->chunk_tiers[c];
+        PM_TRY(grow(h->tier_started, nc * sizeof(int)));
+        int *tier_started = (int *)h->tier_started.p + c;
+        PM_HIP(hipMemsetAsync(tier_started, 0, sizeof(int), stream));
         PM_HIP(hipEventRecord(h->tier_events[0], stream)); // whatever this chunk's fill waits for, the side streams wait for too
+        i64 tier_groups = 0;
         for(size_t tier = 0; tier < cuts.size(); ++tier) {
           hipStream_t ts = h->tier_streams[tier];
           PM_HIP(hipStreamWaitEvent(ts, h->tier_events[0], 0));
-          PM_TRY(dp_launch_fill(h, at, cuts[tier] - at, tbw, traceback, ts, nullptr, nullptr, false));
+          i64 groups = 0;
+          PM_TRY(dp_launch_fill(h, at, cuts[tier] - at, tbw, traceback, ts, tier_started, &groups));
+          tier_groups += groups;
+          if(traceback) {
+            PM_TRY(dp_launch_path(h, at, cuts[tier] - at, tbw, ts, true));
+          }
           PM_HIP(hipEventRecord(h->tier_events[1 + tier], ts));
           at = cuts[tier];
         }
-        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, nullptr, nullptr, false));
-        for(size_t tier = 0; tier < cuts.size(); ++tier) {
-          PM_HIP(hipStreamWaitEvent(stream, h->tier_events[1 + tier], 0));
+        tiers_end = at; // the chunk's own path kernel starts here
+        if(gate_on && tier_groups > 0) {
+          dp_gate_kernel<<<1, 64, 0, stream>>>(tier_started, (int)std::min<i64>(tier_groups, 0x7fffffff));
+          PM_HIP(hipGetLastError());
+        }
+        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream));
+        tiers_joined = cuts.size();
+        if(!traceback) { // no path kernel to wait for them: the chunk's fill stream does
+          for(size_t tier = 0; tier < cuts.size(); ++tier) {
+            PM_HIP(hipStreamWaitEvent(stream, h->tier_events[1 + tier], 0));
+          }
         }
         at = c_hi;
       }
       if(at < c_hi) {
         const bool whole = at == c_lo; // one launch for the chunk: the next chunk's gate can count its workgroups
         i64 groups = 0;
-        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, two_fills && whole ? started + c : nullptr, &groups, !two_fills));
+        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, two_fills && whole ? started + c : nullptr, &groups));
         if(two_fills && whole) {
           h->chunk_groups[c] = groups;
         }
@@ -1645,9 +1748,12 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       if(timed) {
         PM_HIP(hipEventRecord(h->tv_path0[c], ps));
       }
-      PM_TRY(dp_launch_path(h, c, tbw, ps));
+      PM_TRY(dp_launch_path(h, tiers_end, h->chunk_first[c + 1] - tiers_end, tbw, ps));
       if(timed) {
         PM_HIP(hipEventRecord(h->tv_path1[c], ps));
+      }
+      for(size_t tier = 0; tier < tiers_joined; ++tier) { // the chunk is done when its tiers' kernels are, too
+        PM_HIP(hipStreamWaitEvent(ps, h->tier_events[1 + tier], 0));
       }
       if(pipelined) {
         PM_HIP(hipEventRecord(h->ev_path[c], ps));

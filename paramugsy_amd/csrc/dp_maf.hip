@@ -802,6 +802,9 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
   }
   const bool timing = getenv("PM_TIMING") != nullptr;
   if(n == 0) {
+    if(before_write) {
+      PM_TRY(before_write());
+    }
     return out.write(blob.data(), blob.size()) ? (int)PM_OK : fail(PM_E_IO, "write failed");
   }
   // the slice's part of either mapped file: from its first row's text to the start of the row after its last (the lines' other

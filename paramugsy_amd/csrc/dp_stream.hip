@@ -71,6 +71,11 @@ void pm_dp_host_free(void *ptr) {
 }
 
 int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t workspace_bytes, int device, pm_dp_stream_t **out) {
+  return pm_dp_stream_create_opt(params, nullptr, segments, workspace_bytes, device, out);
+}
+
+int pm_dp_stream_create_opt(const pm_dp_params_t *params, const pm_dp_options_t *options, int32_t segments, int64_t workspace_bytes, int device,
+                            pm_dp_stream_t **out) {
   if(!out) {
     return fail(PM_E_INVALID, "pm_dp_stream_create: null out");
   }
@@ -102,7 +107,7 @@ int pm_dp_stream_create(const pm_dp_params_t *params, int32_t segments, int64_t 
     rc = fail(PM_E_INVALID, "out of host memory");
   }
   if(!rc) {
-    rc = dp_batch_init(s->b, params, workspace_bytes, device);
+    rc = dp_batch_init(s->b, params, workspace_bytes, device, options);
   }
   if(rc) {
     delete s;

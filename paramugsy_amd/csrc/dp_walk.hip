@@ -47,12 +47,19 @@ template <bool DOT4> struct RowWord { typedef int4 type; };
 template <> struct RowWord<true> { typedef int2 type; };
 
 template <int C, int LPP, bool DOT4>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C == 16 && LPP == 16 && DOT4 ? 4 : 1)))
 dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b, const i64 *__restrict__ off_b,
                const int *__restrict__ order, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
-               int *__restrict__ n_ops, DpParamsD P, DpBand band, int band_mode, int ablate, int tail) {
+               int *__restrict__ n_ops, DpParamsD P, DpBand band, int band_mode, int tail, int urgent) {
   // band_mode 0: the walk, every block recomputed; 1: no walk, the band's blocks computed and stored (work items = the band's
   // (pair, column group) list); 2: the walk, blocks inside the band read back, the others recomputed
+  // A walk is a chain of blocks, each waiting for the one before.  The walk of a tier -- a few hundred long pairs beside the fill
+  // kernel of the rest, and the step waits for its longest chain -- goes first at issue (`urgent`).  Not every walk: the path kernel
+  // of a chunk beside the next chunk's fill kernel is throughput work like that one (12 500 pairs of 8 x 4 096 in two chunks:
+  // 42.2 ms a step, 42.6 with the walk ahead at issue).
+  if(urgent) {
+    __builtin_amdgcn_s_setprio(3);
+  }
   constexpr int R = DP_CK_R;
   constexpr int BW = C * DP_CK_W; // columns of a block
   constexpr int C2 = BW / LPP;    // columns per lane inside a block
@@ -167,7 +174,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       dp_column_weights<DOT4>(in ? B[jc] : 0ull, in, P, w0[c], w1[c], w2[c]);
     }
     // ---- top edge: the state of the lane's columns after row i0 - 1 (the group's row checkpoint k - 1)
-    const bool has_top = comp && k * R - l0 >= 1 && !(ablate & 2);
+    const bool has_top = comp && k * R - l0 >= 1;
     if(has_top) {
 #pragma unroll
       for(int c = 0; c < C2; ++c) {
@@ -208,7 +215,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       for(int rr = q; rr <= nrows; rr += LPP) {
         const int row = i0 - 1 + rr; // row of A; -1 is the DP's row 0
         int2 v;
-        if(gg == 0 || (ablate & 2)) {
+        if(gg == 0) {
           v = make_int2(row < 0 ? -gop : -2 * gop, DP_NEG_INF); // H~[row + 1][0] - gop
         }
         else if(row < 0) {
@@ -231,11 +238,6 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     if(LPP != 16 && q == 0) {
       diag_in = lrow[-1].x;
     }
-    if(ablate & 1) { // timing experiments only (PM_DP_WALK_ABLATE): no recomputation, every decision reads "diagonal"
-      for(int r = q; r < R * LPP; r += LPP) {
-        (&sh_bits[grp][0][0])[r] = 0;
-      }
-    }
     // steps of this block: the longest of the wavefront's groups (rows it recomputes + its lanes' skew), a scalar
     int trip = 0;
     {
@@ -243,9 +245,6 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
 #pragma unroll
       for(int g = 0; g < G; ++g) {
         trip = max(trip, __builtin_amdgcn_readlane(need, g * LPP));
-      }
-      if(ablate & 1) {
-        trip = 0;
       }
     }
     const unsigned rows_mine = mine ? (unsigned)nrows : 0u; // (unsigned)r < rows_mine: this lane is on one of its rows
@@ -395,26 +394,25 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
 
 template <int C, int LPP, bool DOT4>
 static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b, const int *order, i64 n, const i64 *tb_off,
-                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, const DpBand &band, int tail, hipStream_t stream) {
+                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, const DpBand &band, int tail, int urgent, hipStream_t stream) {
   constexpr int G = 64 / LPP;
   const unsigned blocks = (unsigned)((n + G - 1) / G);
-  static const int ablate = getenv("PM_DP_WALK_ABLATE") ? atoi(getenv("PM_DP_WALK_ABLATE")) : 0;
   const bool with_band = band.work != nullptr && band.n_work > 0;
   if(with_band) {
     const unsigned bblocks = (unsigned)((band.n_work + G - 1) / G);
     dp_walk_kernel<C, LPP, DOT4><<<bblocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, band.n_work, tb_off, ck, ops, n_ops, P, band, 1,
-                                                             ablate, tail);
+                                                             tail, urgent);
     PM_HIP(hipGetLastError());
   }
   dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, with_band ? 2 : 0,
-                                                          ablate, tail);
+                                                          tail, urgent);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
 
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
-                   const DpBand &band, int tail, hipStream_t stream) {
+                   const DpBand &band, int tail, int urgent, hipStream_t stream) {
   if(n <= 0) {
     return PM_OK;
   }
@@ -422,8 +420,8 @@ int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *
 #define WALK(CC, LL)                                                                                                        \
   if constexpr((CC * DP_CK_W) % LL == 0 && (CC * DP_CK_W) / LL >= 1 && (CC * DP_CK_W) / LL <= 8 && CC % ((CC * DP_CK_W) / LL) == 0) { \
     if(lanes_per_pair == LL) {                                                                                              \
-      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, stream) \
-                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, stream); \
+      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, urgent, stream) \
+                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, urgent, stream); \
     }                                                                                                                       \
   }
   if(cols_per_lane == 16) {

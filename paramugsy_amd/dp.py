@@ -24,6 +24,52 @@ class PmDpParams(C.Structure):
     _fields_ = [("sub", C.c_int32 * 25), ("gap_open", C.c_int32), ("gap_extend", C.c_int32)]
 
 
+class PmDpOptions(C.Structure):
+    """pm_dp_options_t (include/paramugsy_amd.h): every field 0 = chosen per batch by the library."""
+    _fields_ = [("path_mode", C.c_int32), ("cols_per_lane", C.c_int32), ("waves_per_pair", C.c_int32), ("groups_per_pair", C.c_int32),
+                ("band", C.c_int32), ("walk_lanes", C.c_int32), ("int16_weights", C.c_int32), ("no_uniform_depth", C.c_int32),
+                ("keep_order", C.c_int32), ("no_tiers", C.c_int32), ("tier_min_pairs", C.c_int32), ("full_stripes", C.c_int32),
+                ("slots", C.c_int32), ("split", C.c_int32), ("no_gate", C.c_int32), ("reserved", C.c_int32), ("segment_cells", C.c_int64)]
+
+
+def options(**fields) -> PmDpOptions:
+    """pm_dp_options_t with the given fields set, e.g. options(path_mode=1, waves_per_pair=4)."""
+    o = PmDpOptions()
+    for k, v in fields.items():
+        if k not in dict(PmDpOptions._fields_):
+            raise KeyError("pm_dp_options_t has no field %r" % k)
+        setattr(o, k, int(v))
+    return o
+
+
+# The PM_DP_* switches of earlier rounds, kept for the tests and the tools as a way to SPELL options -- read here, in the Python
+# binding, and handed to the library as an explicit pm_dp_options_t; the library itself reads no environment variable.
+_ENV_FIELDS = {
+    "PM_DP_MODE": ("path_mode", {"bits": 1, "ckpt": 2}), "PM_DP_COLS": ("cols_per_lane", None), "PM_DP_WAVES": ("waves_per_pair", None),
+    "PM_DP_GROUPS": ("groups_per_pair", None), "PM_DP_BAND": ("band", {"0": 1, "1": 2}), "PM_DP_WALK_LANES": ("walk_lanes", None),
+    "PM_DP_DOT4": ("int16_weights", {"0": 1, "1": 0}), "PM_DP_UNI": ("no_uniform_depth", {"0": 1, "1": 0}), "PM_DP_KEEP_ORDER": ("keep_order", None),
+    "PM_DP_NO_TIERS": ("no_tiers", None), "PM_DP_TIER_MIN_PAIRS": ("tier_min_pairs", None), "PM_DP_TAIL": ("full_stripes", {"0": 1, "1": 0}),
+    "PM_DP_SLOTS": ("slots", None), "PM_DP_SPLIT": ("split", None), "PM_DP_NO_GATE": ("no_gate", None),
+    "PM_DP_SEGMENT_CELLS": ("segment_cells", None),
+}
+
+
+def options_from_env(env=None) -> PmDpOptions:
+    env = os.environ if env is None else env
+    o = PmDpOptions()
+    for name, (field, table) in _ENV_FIELDS.items():
+        v = env.get(name)
+        if v is None or v == "":
+            continue
+        setattr(o, field, table.get(v, 0) if table is not None else int(float(v)))
+    return o
+
+
+def set_default_options(opt: PmDpOptions = None) -> None:
+    """The options of batches the library makes itself (pm_dp_align_*, pm_dp_stream_create without options); None: all chosen."""
+    capi.check(_lib().pm_dp_set_default_options(C.byref(opt) if opt is not None else None))
+
+
 def make_params(rows_a: int, rows_b: int, match: int = 5, mismatch: int = -4, base_gap: int = -3,
                 open_per_pair: int = 8, extend_per_pair: int = 2) -> PmDpParams:
     """Sum-of-pairs scoring: 5x5 matrix over A,C,G,T,gap and gap penalties scaled by the number of row pairs."""
@@ -70,6 +116,10 @@ def _lib():
     if not getattr(l, "_dp_bound", False):
         l.pm_dp_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(PmDpParams), C.c_int64,
                                          C.c_int, C.POINTER(C.c_void_p)]
+        l.pm_dp_batch_create_opt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(PmDpParams),
+                                             C.POINTER(PmDpOptions), C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        l.pm_dp_set_default_options.argtypes = [C.POINTER(PmDpOptions)]
+        l.pm_dp_stream_create_opt.argtypes = [C.POINTER(PmDpParams), C.POINTER(PmDpOptions), C.c_int32, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
         l.pm_dp_batch_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         l.pm_dp_batch_run_profiled.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.pm_dp_batch_fill_busy_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -123,16 +173,18 @@ class DpInputs:
 class DpBatch:
     """A batch of profile pairs resident in HBM (pm_dp_batch_*)."""
 
-    def __init__(self, inputs: DpInputs, params: PmDpParams, device: int = 0, tb_budget_bytes: int = 0):
+    def __init__(self, inputs: DpInputs, params: PmDpParams, device: int = 0, tb_budget_bytes: int = 0, options: PmDpOptions = None):
+        """options None: what the PM_DP_* environment spells (options_from_env; nothing set = everything chosen by the library)."""
         l = _lib()
+        opt = options if options is not None else options_from_env()
         self.inputs = inputs
         ca = np.ascontiguousarray(inputs.cols_a, dtype=np.uint8)
         cb = np.ascontiguousarray(inputs.cols_b, dtype=np.uint8)
         oa = np.ascontiguousarray(inputs.off_a, dtype=np.int64)
         ob = np.ascontiguousarray(inputs.off_b, dtype=np.int64)
         h = C.c_void_p()
-        capi.check(l.pm_dp_batch_create(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, len(oa) - 1, C.byref(params),
-                                        tb_budget_bytes, device, C.byref(h)))
+        capi.check(l.pm_dp_batch_create_opt(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, len(oa) - 1, C.byref(params),
+                                            C.byref(opt), tb_budget_bytes, device, C.byref(h)))
         self._h = h
         self._oa, self._ob = oa, ob
 
@@ -203,37 +255,52 @@ class DpBatch:
 
 # ---------------------------------------------------------------- the DP fed from host memory (pm_dp_stream_*)
 
-class PinnedArray:
-    """A numpy array over pinned host memory from pm_dp_host_alloc (copies from / to it are asynchronous).  Keep the object alive
-    while `.a` is in use; close() frees the memory."""
+class _PinnedAllocation:
+    """Frees a pm_dp_host_alloc allocation when the last reference to it goes."""
 
-    def __init__(self, shape, dtype):
-        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        self._p = C.c_void_p()
-        capi.check(_lib().pm_dp_host_alloc(C.byref(self._p), n))
-        buf = (C.c_uint8 * max(n, 1)).from_address(self._p.value)
-        self.a = np.frombuffer(buf, dtype=np.uint8, count=n).view(dtype).reshape(shape)
-
-    def close(self):
-        if self._p:
-            self.a = None
-            _lib().pm_dp_host_free(self._p)
-            self._p = None
+    def __init__(self, ptr):
+        self._p = ptr
 
     def __del__(self):
         try:
-            self.close()
+            if self._p:
+                _lib().pm_dp_host_free(self._p)
+                self._p = None
         except Exception:
             pass
+
+
+class PinnedArray:
+    """A numpy array over pinned host memory from pm_dp_host_alloc (copies from / to it are asynchronous).
+
+    `.a` OWNS the allocation: the memory is freed when the last array that views it is gone (the ctypes buffer at the bottom of
+    every view's `.base` chain holds the allocation), not when this object is -- round 3 freed it with the PinnedArray, and a
+    copy engine that was still reading `.a` of a collected PinnedArray took a GPU memory access fault.  close() only drops this
+    object's own reference."""
+
+    def __init__(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        capi.check(_lib().pm_dp_host_alloc(C.byref(p), n))
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        buf._pm_allocation = _PinnedAllocation(p)  # lives as long as the buffer, i.e. as long as any view of it
+        self.a = np.frombuffer(buf, dtype=np.uint8, count=n).view(dtype).reshape(shape)
+
+    def close(self):
+        self.a = None
+
+    def __del__(self):
+        self.a = None
 
 
 class DpStream:
     """A batch from host memory: uploaded in segments while the fill kernel already runs on those that have arrived; results
     back on a third stream (pm_dp_stream_*)."""
 
-    def __init__(self, params: PmDpParams, segments: int = 4, workspace_bytes: int = 0, device: int = 0):
+    def __init__(self, params: PmDpParams, segments: int = 4, workspace_bytes: int = 0, device: int = 0, options: PmDpOptions = None):
         h = C.c_void_p()
-        capi.check(_lib().pm_dp_stream_create(C.byref(params), segments, workspace_bytes, device, C.byref(h)))
+        opt = options if options is not None else options_from_env()
+        capi.check(_lib().pm_dp_stream_create_opt(C.byref(params), C.byref(opt), segments, workspace_bytes, device, C.byref(h)))
         self._h = h
 
     def align(self, inputs: DpInputs, scores: np.ndarray = None, ops: np.ndarray = None, n_ops: np.ndarray = None, with_paths: bool = True):

@@ -34,6 +34,38 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.PmUnits) == 4 * 8
 
 
+def test_dp_options_layout_and_the_environment_spelling(monkeypatch):
+    """pm_dp_options_t: 16 int32 + one int64 (include/paramugsy_amd.h); the PM_DP_* switches are read by the Python binding only and
+    become explicit fields (the library itself reads no environment variable: no getenv of a PM_DP_ name is left in its sources)."""
+    from paramugsy_amd import dp
+    assert C.sizeof(dp.PmDpOptions) == 16 * 4 + 8
+    header = open(os.path.join(ROOT, "include", "paramugsy_amd.h")).read()
+    body = header[header.index("typedef struct pm_dp_options {"):header.index("} pm_dp_options_t;")]
+    declared = re.findall(r"int(?:32|64)_t\s+([a-z0-9_]+);", body)
+    assert declared == [f for f, _ in dp.PmDpOptions._fields_]
+    for name in list(os.environ):
+        if name.startswith("PM_DP_"):
+            monkeypatch.delenv(name)
+    o = dp.options_from_env()
+    assert all(getattr(o, f) == 0 for f, _ in dp.PmDpOptions._fields_)
+    for k, v in {"PM_DP_MODE": "bits", "PM_DP_COLS": "8", "PM_DP_WAVES": "4", "PM_DP_BAND": "0", "PM_DP_UNI": "0", "PM_DP_DOT4": "0",
+                 "PM_DP_TAIL": "0", "PM_DP_SEGMENT_CELLS": "2e6", "PM_DP_TIER_MIN_PAIRS": "8"}.items():
+        monkeypatch.setenv(k, v)
+    o = dp.options_from_env()
+    assert (o.path_mode, o.cols_per_lane, o.waves_per_pair, o.band, o.no_uniform_depth, o.int16_weights, o.full_stripes, o.segment_cells,
+            o.tier_min_pairs) == (1, 8, 4, 1, 1, 1, 1, 2000000, 8)
+    monkeypatch.setenv("PM_DP_MODE", "ckpt")
+    monkeypatch.setenv("PM_DP_BAND", "1")
+    o = dp.options_from_env()
+    assert (o.path_mode, o.band) == (2, 2)
+    with pytest.raises(KeyError):
+        dp.options(no_such_field=1)
+    csrc = os.path.join(ROOT, "paramugsy_amd", "csrc")
+    for fn in os.listdir(csrc):
+        text = open(os.path.join(csrc, fn)).read()
+        assert not re.search(r'getenv\("PM_DP_', text), fn
+
+
 def test_no_cpu_fallback_without_device(hip_lib):
     if hip_lib.pm_device_count() > 0:
         pytest.skip("a HIP device is present")

@@ -187,6 +187,44 @@ def test_align_maf_files_end_to_end(oracle_build, tmp_path):
 
 
 @pytest.mark.gpu
+def test_a_failed_call_leaves_an_existing_output_alone(tmp_path):
+    """pm_dp_align_maf empties its output file only when it is about to write: a missing input, unequal block counts or a block of
+    more than 255 rows leave a file that is already there as it was, and an output that is one of the (mapped) inputs is refused."""
+    from paramugsy_amd import capi
+    pa, pb, po = str(tmp_path / "a.maf"), str(tmp_path / "b.maf"), str(tmp_path / "out.maf")
+    keep = b"precious bytes\n" * 100
+    params = dp.make_params(1, 1)
+
+    def two(path, n):
+        with open(path, "wb") as f:
+            for k in range(n):
+                f.write(b"a score=0\ns g.%d 0 4 + 100 ACGT\n\n" % k)
+    for make_inputs in (lambda: (two(pa, 2), os.remove(pb) if os.path.exists(pb) else None),  # an input is missing
+                        lambda: (two(pa, 2), two(pb, 3)),                                      # unequal block counts
+                        lambda: (two(pb, 1), open(pa, "wb").write(b"a score=0\n" + b"".join(b"s r%d 0 1 + 9 A\n" % r for r in range(300))))):
+        make_inputs()
+        with open(po, "wb") as f:
+            f.write(keep)
+        with pytest.raises(capi.PmError):
+            dp.align_maf_files(pa, pb, params, po)
+        assert open(po, "rb").read() == keep
+    two(pa, 2)
+    two(pb, 2)
+    before = open(pa, "rb").read()
+    with pytest.raises(capi.PmError, match="one of the input files"):
+        dp.align_maf_files(pa, pb, params, pa)
+    assert open(pa, "rb").read() == before
+    with pytest.raises(capi.PmError, match="one of the input files"):
+        dp.align_maf_files(pa, pb, params, pb, devices=[0, 0])
+    # and a good call over a longer old file leaves no tail of it behind
+    with open(po, "wb") as f:
+        f.write(keep * 50)
+    dp.align_maf_files(pa, pb, params, po)
+    out = open(po, "rb").read()
+    assert out.startswith(b"##maf") and b"precious" not in out and len(ora.parse_maf(po)) == 2
+
+
+@pytest.mark.gpu
 def test_score_less_a_lines_open_blocks(oracle_build, tmp_path):
     """The score after `a` is optional in MAF: a line that is just `a` (also with a trailing CR) starts a block, so the rows
     that follow are not appended to the block before it and block k of A still meets block k of B."""

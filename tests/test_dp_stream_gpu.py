@@ -141,6 +141,34 @@ def test_row_texts_in_equal_packed_columns_in(segments, oracle_build, monkeypatc
     st.close()
 
 
+def test_pinned_array_outlives_its_wrapper(oracle_build):
+    """dp.PinnedArray's `.a` owns the allocation: dropping the wrapper (round 3: that freed the memory under a copy engine that was
+    still reading it -- a GPU memory access fault) leaves the array, and every view of it, usable for the upload."""
+    import gc
+    import pyoracle
+    rows, n, L = 3, 40, 700
+    src = dp.synth_pairs_fast(77, n, rows, L)
+    params = dp.make_params(rows, rows)
+
+    def pinned_copy(x):
+        t = dp.PinnedArray(x.shape, x.dtype)
+        t.a[...] = x
+        return t.a  # the wrapper dies here
+
+    ca, cb = pinned_copy(src.cols_a), pinned_copy(src.cols_b)
+    gc.collect()
+    junk = [dp.PinnedArray((1 << 20,), np.uint8) for _ in range(4)]  # would reuse freed pinned memory
+    for j in junk:
+        j.a[...] = 0xff
+    inputs = dp.DpInputs(ca, src.off_a, cb[:], src.off_b)
+    st = dp.DpStream(params, 2)
+    scores, ops, n_ops = st.align(inputs)
+    st.close()
+    o_scores, o_paths = pyoracle.dp_align(src, params)
+    assert np.array_equal(scores, o_scores)
+    assert all(np.array_equal(p, q) for p, q in zip(dp.paths_of(src, ops, n_ops), o_paths))
+
+
 def test_row_texts_from_pinned_memory_large_batch(oracle_build):
     """BASELINE configs[1]'s shape through the text entry from pinned buffers: 2-row x 1 kbp pairs, 2 bytes per column up instead
     of 8; a sample under the oracle."""

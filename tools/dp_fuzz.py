@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzz of the DP on the GPU box: random batches (pair count, lengths, depth, related or unrelated profiles, scoring)
-under random kernel choices (path mode, columns per lane, waves and workgroups per pair, band, walk lanes), every score and every
-path against oracle/dp_oracle.c.  python tools/dp_fuzz.py [seconds] [first seed]; prints one line per case, stops at the
+under random kernel choices (path mode, columns per lane, waves and workgroups per pair, band, walk lanes, chunks, tiers, stripe
+widths: spelt as PM_DP_* variables, which dp.options_from_env turns into the pm_dp_options_t the library is given), every score and
+every path against oracle/dp_oracle.c.  python tools/dp_fuzz.py [seconds] [first seed]; prints one line per case, stops at the
 first mismatch with the environment that reproduces it."""
 import os
 import sys
@@ -23,8 +24,11 @@ KNOBS = {"PM_DP_MODE": ["ckpt", "ckpt", "bits", None], "PM_DP_COLS": ["8", "16",
          # the chunk pipeline (these matter for the resident batch when the case draws a small workspace budget, below): parts of the
          # workspace, the fill kernels of every part on a stream of their own or not, the gate kernel in front of them or not, a batch
          # that fits cut into chunks all the same
-         "PM_DP_SLOTS": ["2", "3", "4", None, None], "PM_DP_ONE_FILL_STREAM": ["1", None, None, None], "PM_DP_NO_GATE": ["1", None, None],
-         "PM_DP_SPLIT": ["2", "3", "5", None, None, None]}
+         "PM_DP_SLOTS": ["2", "3", "4", None, None], "PM_DP_NO_GATE": ["1", None, None],
+         "PM_DP_SPLIT": ["2", "3", "5", None, None, None],
+         # the tiers (a chunk's longest pairs in launches of their own, with their own path kernels) for chunks of 8 or 16 pairs already;
+         # full-width last stripes instead of the narrow ones
+         "PM_DP_TIER_MIN_PAIRS": ["8", "8", "16", None], "PM_DP_NO_TIERS": ["1", None, None, None, None], "PM_DP_TAIL": ["0", None, None]}
 
 
 def random_case(rng):
@@ -97,6 +101,7 @@ while time.time() < t_end:
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
+    dp.set_default_options(dp.options_from_env())  # for the batches the library makes itself (the device-list entry)
     # engines: the resident batch; the host-fed engine (upload segments, variant re-check) with packed columns or with the rows'
     # texts; the device-list entry with two to four workers on the one GPU
     draw = rng.random()

@@ -31,17 +31,39 @@ def make(spec):
 
 
 def main():
+    if sys.argv[1] == "--trace":  # two passes of one shape and nothing else (tools/trace_once.sh)
+        inputs, rows = make(sys.argv[2])
+        b = dp.DpBatch(inputs, dp.make_params(rows, rows))
+        if os.environ.get("PROBE_SYNC", "1") == "1":
+            for _ in range(2):
+                b.run(True)
+                torch.cuda.synchronize()
+                time.sleep(0.01)
+        else:  # passes back to back, as bench.py's timed region issues them
+            b.run(True)
+            torch.cuda.synchronize()
+            time.sleep(0.01)
+            for _ in range(3):
+                b.run(True)
+            torch.cuda.synchronize()
+        b.fetch(with_paths=False)
+        b.close()
+        return
     reps = int(os.environ.get("PROBE_REPS", "5"))
     print("%-16s %8s %9s %9s %9s %10s %6s  %s" % ("spec", "GCUPS", "ms/step", "fill ms", "path ms", "scores ms", "chunks", "variant"))
+    own_stream = torch.cuda.Stream() if os.environ.get("PROBE_STREAM") else None  # else the null stream
+    stream = own_stream.cuda_stream if own_stream else 0
     for spec in sys.argv[1:]:
         inputs, rows = make(spec)
         b = dp.DpBatch(inputs, dp.make_params(rows, rows))
         for _ in range(2):
-            b.run(True)
+            b.run(True, stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            b.run(True)
+            b.run(True, stream)
+            if os.environ.get("PROBE_SYNC"):  # one pass at a time
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
         prof = [b.run_profiled(True) for _ in range(3)]
