@@ -357,6 +357,10 @@ def dp_inputs_for(cfg_name, cfg, rank, world, scaling, device):
         lb = la
     else:
         la, lb = dpm.ragged_lengths(seed, n_total)
+        if scaling == "strong":  # ragged pairs are partitioned by cells, not by count (shard.partition_weighted: the rule of the C ABI's
+            from paramugsy_amd.shard import pair_weights, partition_weighted  # pm_partition_weighted behind pm_dp_align_*_multi)
+            cuts = partition_weighted(pair_weights(la, lb).tolist(), world)
+            lo, hi = cuts[rank], cuts[rank + 1]
     # a slice of a seeded batch: seed the slice by its position so that no rank has to draw the whole batch
     inputs = synth_batch_device(seed * 1000003 + lo, la[lo:hi], lb[lo:hi], rows, rows, device=device)
     return inputs, (n_total if scaling == "strong" else n_total * world)

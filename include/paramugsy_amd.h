@@ -352,14 +352,19 @@ int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_a, int64_t 
 /* ------------------------------------------------------------------------------------------------------
  * Several devices of one node behind one call (csrc/multi.hpp).  The host north_star names (OCaml behind a C ABI, or the CLI)
  * cannot run one torch.distributed process per GPU; these entries take a device list instead: the job's independent items --
- * pairs, blocks, delta files -- are cut into n_devices contiguous slices (pm_partition: the first n % parts slices hold one item
- * more), one host thread and one HIP context per device run the single-device path on their slice, there is NO collective, and
+ * pairs, blocks, delta files -- are cut into n_devices contiguous slices (delta files by count, pm_partition: the first n % parts
+ * slices hold one item more; pairs and blocks by cells, pm_partition_weighted), one host thread and one HIP context per device run the single-device path on their slice, there is NO collective, and
  * the outputs are gathered on the host in input order.  What this replaces in the reference: the chunked pair lists of
  * lib/base/pm_job.ml:43-57,83-91 run as `run_size` concurrent OS processes (lib/base/queued_task_server.ml:57-66), whose outputs
  * the order-sensitive writer concatenates (lib/profiles_lib/m_delta_stream_writer.hh:62-67).  The same device may be named more
  * than once (its workers share it).  Results are byte for byte those of the single-device call.  If a worker fails the call
  * fails with the error of the first failing slice (pm_last_error names the device).  New surface. */
 int pm_partition(int64_t n_items, int n_parts, int part, int64_t *lo, int64_t *hi);
+/* The same for items of unequal cost: contiguous slices cut where the running sum of `weights` (>= 0) comes closest to k / n_parts
+ * of the total; cuts[0 .. n_parts] = the slices' bounds (cuts[0] = 0, cuts[n_parts] = n_items).  Equal weights: pm_partition's
+ * slices.  The pm_dp_align_*_multi entries cut their pairs so, by cells: weight = La x Lb + La + Lb + 1 (a pair of MAF blocks: the
+ * columns of its blocks' first rows), so that the slices of a ragged batch hold equal work, not equal counts.  Host only. */
+int pm_partition_weighted(const int64_t *weights, int64_t n_items, int n_parts, int64_t *cuts);
 /* pm_translate_files over a device list: every worker parses and translates its slice of the delta-file list against the two
  * sides (loaded once); the texts are joined in list order with the writer's header rule re-applied at the seams (a `>` line is
  * printed only when the name pair changes).  On a failure the output holds what the reference had written when it died: the

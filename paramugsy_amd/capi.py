@@ -58,7 +58,7 @@ EXPORTS = [
     "pm_dp_set_default_options", "pm_dp_batch_create", "pm_dp_batch_create_opt", "pm_dp_batch_run", "pm_dp_batch_run_profiled", "pm_dp_batch_fill_busy_ms", "pm_dp_batch_fetch", "pm_dp_batch_info", "pm_dp_batch_chunks", "pm_dp_batch_variant", "pm_dp_batch_path_mode", "pm_dp_batch_destroy",
     "pm_dp_host_alloc", "pm_dp_host_free", "pm_dp_stream_create", "pm_dp_stream_create_opt", "pm_dp_stream_align", "pm_dp_stream_align_text", "pm_dp_stream_destroy",
     "pm_dp_pack_maf", "pm_dp_emit_maf", "pm_dp_align_maf", "pm_dp_align_blocks",
-    "pm_partition", "pm_delta_join_files", "pm_translate_files_multi", "pm_dp_align_multi", "pm_dp_align_blocks_multi", "pm_dp_align_maf_multi",
+    "pm_partition", "pm_partition_weighted", "pm_delta_join_files", "pm_translate_files_multi", "pm_dp_align_multi", "pm_dp_align_blocks_multi", "pm_dp_align_maf_multi",
 ]
 
 

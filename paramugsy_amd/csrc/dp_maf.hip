@@ -1131,22 +1131,35 @@ extern "C" int pm_dp_align_blocks(const uint8_t *text_a, const int64_t *row_off_
 
 // ------------------------------------------------------------------ several devices (multi.hpp)
 
+// The slices of a list of block pairs over n_devices workers, cut by cells (multi.hpp): a block has as many columns as its first row
+// has bytes.
+static void block_pair_cuts(const int64_t *row_off_a, const int64_t *block_row_a, const int64_t *row_off_b, const int64_t *block_row_b, int64_t n,
+                            int n_devices, std::vector<int64_t> &cuts) {
+  std::vector<int64_t> weight((size_t)n);
+  for(int64_t k = 0; k < n; ++k) {
+    const int64_t ra = block_row_a[k], rb = block_row_b[k];
+    const int64_t la = ra < block_row_a[k + 1] ? row_off_a[ra + 1] - row_off_a[ra] : 0, lb = rb < block_row_b[k + 1] ? row_off_b[rb + 1] - row_off_b[rb] : 0;
+    weight[(size_t)k] = pair_weight(la, lb);
+  }
+  partition_weighted(weight.data(), n, n_devices, cuts);
+}
+
 // pack -> DP -> expansion of the pairs' contiguous slices on their devices; worker w's merged texts stay in merged[w], its scores
 // and merged widths go to their places in the whole job's arrays, part_off[w] = the slice's own text offsets (n_w + 1 values).
 static int align_blocks_multi_core(const uint8_t *text_a, const int64_t *row_off_a, int64_t n_rows_a, const int64_t *block_row_a,
                                    const uint8_t *text_b, const int64_t *row_off_b, int64_t n_rows_b, const int64_t *block_row_b, int64_t n,
                                    const pm_dp_params_t *params, const int *devices, int n_devices, std::vector<int32_t> &scores,
                                    std::vector<int32_t> &n_ops, std::vector<std::vector<uint8_t> > &merged,
-                                   std::vector<std::vector<int64_t> > &part_off) {
+                                   std::vector<std::vector<int64_t> > &part_off, std::vector<int64_t> &cuts) {
   PM_TRY(check_blocks(row_off_a, n_rows_a, block_row_a, n, "pm_dp_align (A)"));
   PM_TRY(check_blocks(row_off_b, n_rows_b, block_row_b, n, "pm_dp_align (B)"));
   scores.assign((size_t)n, 0);
   n_ops.assign((size_t)n, 0);
   merged.assign((size_t)n_devices, std::vector<uint8_t>());
   part_off.assign((size_t)n_devices, std::vector<int64_t>(1, 0));
+  block_pair_cuts(row_off_a, block_row_a, row_off_b, block_row_b, n, n_devices, cuts);
   return run_on_devices(devices, n_devices, [&](int w, int device) {
-    int64_t lo, hi;
-    partition(n, n_devices, w, lo, hi);
+    const int64_t lo = cuts[(size_t)w], hi = cuts[(size_t)w + 1];
     if(hi <= lo) {
       return (int)PM_OK;
     }
@@ -1173,13 +1186,13 @@ extern "C" int pm_dp_align_blocks_multi(const uint8_t *text_a, const int64_t *ro
   std::vector<int32_t> s, m;
   std::vector<std::vector<uint8_t> > merged;
   std::vector<std::vector<int64_t> > part_off;
+  std::vector<int64_t> cuts;
   PM_TRY(align_blocks_multi_core(text_a, row_off_a, n_rows_a, block_row_a, text_b, row_off_b, n_rows_b, block_row_b, n_pairs, params, devices,
-                                 n_devices, s, m, merged, part_off));
+                                 n_devices, s, m, merged, part_off, cuts));
   // the host-side gather: the slices' texts back to back, in pair order
   out_off[0] = 0;
   for(int w = 0; w < n_devices; ++w) {
-    int64_t lo, hi;
-    partition(n_pairs, n_devices, w, lo, hi);
+    const int64_t lo = cuts[(size_t)w], hi = cuts[(size_t)w + 1];
     for(int64_t k = lo; k < hi; ++k) {
       out_off[k + 1] = out_off[lo] + part_off[(size_t)w][(size_t)(k - lo) + 1];
     }
@@ -1193,8 +1206,7 @@ extern "C" int pm_dp_align_blocks_multi(const uint8_t *text_a, const int64_t *ro
                                   std::to_string(out_off[n_pairs]));
   }
   for(int w = 0; w < n_devices; ++w) {
-    int64_t lo, hi;
-    partition(n_pairs, n_devices, w, lo, hi);
+    const int64_t lo = cuts[(size_t)w], hi = cuts[(size_t)w + 1];
     const int64_t bytes = out_off[hi] - out_off[lo];
     if(bytes > 0) {
       memcpy(out_text + out_off[lo], merged[(size_t)w].data(), (size_t)bytes);
@@ -1218,9 +1230,17 @@ extern "C" int pm_dp_align_maf_multi(const char *maf_a, const char *maf_b, const
   // every worker assembles the file bytes of its slice's merged blocks on its device and brings them to a buffer of its own; the
   // host-side gather is writing the buffers in pair order
   std::vector<std::string> part((size_t)n_devices);
+  std::vector<int64_t> cuts; // by cells: a block has as many columns as its first row has bytes (row_len)
+  {
+    std::vector<int64_t> weight((size_t)n);
+    for(int64_t k = 0; k < n; ++k) {
+      const int64_t ra = A.block_row[(size_t)k], rb = B.block_row[(size_t)k];
+      weight[(size_t)k] = pair_weight(ra < A.block_row[(size_t)k + 1] ? A.row_len[(size_t)ra] : 0, rb < B.block_row[(size_t)k + 1] ? B.row_len[(size_t)rb] : 0);
+    }
+    partition_weighted(weight.data(), n, n_devices, cuts);
+  }
   PM_TRY(run_on_devices(devices, n_devices, [&](int w, int device) {
-    int64_t lo, hi;
-    partition(n, n_devices, w, lo, hi);
+    const int64_t lo = cuts[(size_t)w], hi = cuts[(size_t)w + 1];
     return align_maf_to_sink(A, B, lo, hi, params, device, w == 0, OutSink(&part[(size_t)w]), [](const char *) {});
   }));
   FILE *f = fopen(out_maf, "wb");

@@ -324,9 +324,19 @@ int pm_dp_align_multi(const uint8_t *cols_a, const int64_t *off_a, const uint8_t
   }
   PM_TRY(check_devices(devices, n_devices, "pm_dp_align_multi"));
   PM_TRY(dp_batch_check_params(params));
+  std::vector<int64_t> cuts; // slices of equal cells, not of equal counts (multi.hpp)
+  {
+    std::vector<int64_t> weight((size_t)n_pairs);
+    for(int64_t k = 0; k < n_pairs; ++k) {
+      if(off_a[k + 1] < off_a[k] || off_b[k + 1] < off_b[k]) {
+        return fail(PM_E_INVALID, "pm_dp_align_multi: bad profile length");
+      }
+      weight[(size_t)k] = pair_weight(off_a[k + 1] - off_a[k], off_b[k + 1] - off_b[k]);
+    }
+    partition_weighted(weight.data(), n_pairs, n_devices, cuts);
+  }
   return run_on_devices(devices, n_devices, [&](int w, int device) {
-    int64_t lo, hi;
-    partition(n_pairs, n_devices, w, lo, hi);
+    const int64_t lo = cuts[(size_t)w], hi = cuts[(size_t)w + 1];
     if(hi <= lo) {
       return (int)PM_OK;
     }

@@ -20,6 +20,47 @@ inline void partition(int64_t n, int parts, int k, int64_t &lo, int64_t &hi) {
   hi = lo + base + (k < extra ? 1 : 0);
 }
 
+// The same for items of unequal cost (a pair's cells, La x Lb): contiguous slices cut where the running sum of the weights comes
+// closest to k / parts of the total -- a slice of a ragged batch cut by COUNT is bounded by its longest pair and the slices differ
+// in cells (round 3: north_star says "statically pair-partitioned", not "by count").  cuts: parts + 1 positions, cuts[0] = 0,
+// cuts[parts] = n, never decreasing.  Items of one and the same weight (and a total of 0): exactly partition()'s slices.  Still
+// static -- a function of the lengths alone -- and contiguous, so the ordered host-side gather is unchanged.
+inline void partition_weighted(const int64_t *weight, int64_t n, int parts, std::vector<int64_t> &cuts) {
+  cuts.assign((size_t)parts + 1, 0);
+  bool uniform = true;
+  __int128 total = 0;
+  for(int64_t k = 0; k < n; ++k) {
+    uniform = uniform && weight[k] == weight[0];
+    total += weight[k] > 0 ? weight[k] : 0;
+  }
+  if(uniform || total <= 0) {
+    for(int k = 0; k < parts; ++k) {
+      int64_t lo, hi;
+      partition(n, parts, k, lo, hi);
+      cuts[(size_t)k] = lo;
+      cuts[(size_t)k + 1] = hi;
+    }
+    return;
+  }
+  __int128 run = 0; // exact: (run + w) / total against k / parts, cross-multiplied
+  int64_t at = 0;
+  for(int k = 1; k < parts; ++k) {
+    while(at < n) { // take item `at` while that brings the running sum no further from the target than it is
+      const __int128 w = weight[at] > 0 ? weight[at] : 0;
+      if((run + w) * parts - total * k > total * k - run * parts) {
+        break;
+      }
+      run += w;
+      ++at;
+    }
+    cuts[(size_t)k] = at;
+  }
+  cuts[(size_t)parts] = n;
+}
+
+// a pair's weight: its cells, plus its columns so that empty profiles still count for something
+inline int64_t pair_weight(int64_t la, int64_t lb) { return la * lb + la + lb + 1; }
+
 inline int check_devices(const int *devices, int n_devices, const char *who) {
   if(!devices || n_devices < 1) {
     return fail(PM_E_INVALID, std::string(who) + ": needs at least one device");

@@ -1406,6 +1406,25 @@ extern "C" int pm_delta_join_files(const char *const *part_paths, int n_parts, c
   });
 }
 
+extern "C" int pm_partition_weighted(const int64_t *weights, int64_t n_items, int n_parts, int64_t *cuts) {
+  return pm::guarded("pm_partition_weighted", [&]() -> int {
+    if(n_items < 0 || n_parts < 1 || !cuts || (n_items > 0 && !weights)) {
+      return pm::fail(PM_E_INVALID, "pm_partition_weighted: bad argument");
+    }
+    for(int64_t k = 0; k < n_items; ++k) {
+      if(weights[k] < 0) {
+        return pm::fail(PM_E_INVALID, "pm_partition_weighted: negative weight");
+      }
+    }
+    std::vector<int64_t> c;
+    pm::partition_weighted(weights, n_items, n_parts, c);
+    for(int k = 0; k <= n_parts; ++k) {
+      cuts[k] = c[(size_t)k];
+    }
+    return PM_OK;
+  });
+}
+
 extern "C" int pm_partition(int64_t n_items, int n_parts, int part, int64_t *lo, int64_t *hi) {
   if(n_items < 0 || n_parts < 1 || part < 0 || part >= n_parts || !lo || !hi) {
     return pm::fail(PM_E_INVALID, "pm_partition: bad argument");

@@ -23,6 +23,35 @@ def partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def partition_weighted(weights: Sequence[int], world: int) -> List[int]:
+    """Contiguous slices of items of unequal cost, cut where the running sum of the weights comes closest to k / world of the total:
+    world + 1 positions (cuts[0] = 0, cuts[world] = len(weights)); rank r holds [cuts[r], cuts[r + 1]).  Equal weights: partition()'s
+    slices.  The rule of csrc/multi.hpp::partition_weighted (pm_partition_weighted), restated for the ranks of a torch.distributed
+    job: a ragged batch cut by count leaves slices of very different cell counts."""
+    n = len(weights)
+    w = [max(int(x), 0) for x in weights]
+    total = sum(w)
+    if n == 0 or total <= 0 or all(x == w[0] for x in w):
+        return [partition(n, world, r)[0] for r in range(world)] + [n]
+    cuts, run, at = [0], 0, 0
+    for k in range(1, world):
+        # exact rational comparison (the C side uses long double; the tests compare the two on random inputs)
+        while at < n and (run + w[at]) * world - total * k <= total * k - run * world:
+            run += w[at]
+            at += 1
+        cuts.append(at)
+    cuts.append(n)
+    return cuts
+
+
+def pair_weights(la, lb):
+    """The weight of a profile pair in the DP's partition: its cells, plus its columns (empty profiles still count)."""
+    import numpy as np
+    la = np.asarray(la, dtype=np.int64)
+    lb = np.asarray(lb, dtype=np.int64)
+    return la * lb + la + lb + 1
+
+
 def split_header(delta_text: bytes) -> Tuple[bytes, bytes]:
     """(the two file header lines of m_translate_main.cc:35-39, the rest)."""
     a = delta_text.find(b"\n")
@@ -180,11 +209,14 @@ def slice_pairs(inputs, lo: int, hi: int):
 
 
 def align_sharded(inputs, params, rank: int, world: int, dist=None, device: int = 0, align_fn=None):
-    """DP over a static pair partition: rank r aligns the contiguous slice partition(n_pairs, world, r) on its GPU,
-    rank 0 receives every shard's scores and paths in rank order (host-side gather, no data-path collective).
+    """DP over a static pair partition: rank r aligns its contiguous slice of the pairs -- cut by cells, partition_weighted over
+    pair_weights, so that the slices of a ragged batch hold equal work -- on its GPU, rank 0 receives every shard's scores and
+    paths in rank order (host-side gather, no data-path collective).
     align_fn(sub_inputs, params) -> (scores, paths) replaces the HIP path in the CPU tests (the oracle).  If the alignment
     fails on any rank, every rank raises."""
-    lo, hi = partition(inputs.n_pairs, world, rank)
+    import numpy as np
+    cuts = partition_weighted(pair_weights(np.diff(inputs.off_a), np.diff(inputs.off_b)), world)
+    lo, hi = cuts[rank], cuts[rank + 1]
     sub = slice_pairs(inputs, lo, hi)
     scores, paths, err = None, None, None
     try:
@@ -216,7 +248,8 @@ def align_blocks_sharded(blocks_a, blocks_b, params, rank: int, world: int, dist
     (scores, rows and columns per merged block, all row texts back to back).
     block_fn(sub_a, sub_b, params) -> (scores, merged blocks) replaces the HIP path in the CPU tests (the oracle)."""
     import numpy as np
-    lo, hi = partition(len(blocks_a), world, rank)
+    cuts = partition_weighted(pair_weights([len(b[0]) if b else 0 for b in blocks_a], [len(b[0]) if b else 0 for b in blocks_b]), world)
+    lo, hi = cuts[rank], cuts[rank + 1]
     sub_a, sub_b = blocks_a[lo:hi], blocks_b[lo:hi]
     scores, merged, err = None, None, None
     try:

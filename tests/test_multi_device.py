@@ -31,6 +31,50 @@ def test_partition_is_shard_pys_rule():
     assert capi.lib().pm_partition(5, 2, 2, C.byref(lo), C.byref(hi)) == capi.PM_E_INVALID
 
 
+def test_weighted_partition_cuts_at_equal_cells_and_is_shard_pys_rule():
+    """pm_partition_weighted (csrc/multi.hpp) and shard.partition_weighted are one rule: contiguous slices, cut where the running sum
+    of the weights comes closest to k / parts of the total; equal weights give pm_partition's slices.  On the ragged stand-in for
+    BASELINE configs[2]/[3] (100 000 pairs, eight slices) every slice is within 2 % of an eighth of the cells -- by count the slices
+    hold equal numbers of pairs, whatever their lengths."""
+    from paramugsy_amd import dp
+    lib = capi.lib()
+    lib.pm_partition_weighted.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+
+    def c_cuts(w, parts):
+        w = np.ascontiguousarray(w, dtype=np.int64)
+        cuts = np.zeros(parts + 1, dtype=np.int64)
+        capi.check(lib.pm_partition_weighted(w.ctypes.data, len(w), parts, cuts.ctypes.data))
+        return cuts.tolist()
+    rng = np.random.default_rng(8)
+    for trial in range(300):
+        n = int(rng.integers(0, 60))
+        parts = int(rng.integers(1, 9))
+        kind = trial % 4
+        w = (rng.integers(0, 5, n) if kind == 0 else rng.integers(1, 10**6, n) if kind == 1 else np.full(n, int(rng.integers(0, 9)))
+             if kind == 2 else rng.integers(0, 2**62 // max(n, 1), n))
+        cuts = c_cuts(w, parts)
+        assert cuts == shard.partition_weighted(w.tolist(), parts)
+        assert cuts[0] == 0 and cuts[-1] == n and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        if kind == 2:
+            assert cuts == [shard.partition(n, parts, r)[0] for r in range(parts)] + [n]
+    la, lb = dp.ragged_lengths(20261003, 100000)
+    w = shard.pair_weights(la, lb)
+    cuts = c_cuts(w, 8)
+    assert cuts == shard.partition_weighted(w.tolist(), 8)
+    cells = np.array([int((la[a:b] * lb[a:b]).sum()) for a, b in zip(cuts, cuts[1:])], dtype=np.float64)
+    assert np.all(np.abs(cells / cells.mean() - 1) < 0.02), cells / cells.mean()
+    by_count = np.array([int((la[a:b] * lb[a:b]).sum()) for a, b in (shard.partition(100000, 8, r) for r in range(8))], dtype=np.float64)
+    assert np.abs(by_count / by_count.mean() - 1).max() < 0.05  # (a seeded i.i.d. batch is balanced by count, too: the rule matters for sorted or clustered lists)
+    # a list sorted by length, as a producer that groups its segments would hand over: by count the first slice has 4 x the cells of the last
+    order = np.argsort(-(la * lb), kind="stable")
+    ws = w[order]
+    cs = c_cuts(ws, 8)
+    cells_sorted = np.array([int((la[order][a:b] * lb[order][a:b]).sum()) for a, b in zip(cs, cs[1:])], dtype=np.float64)
+    assert np.all(np.abs(cells_sorted / cells_sorted.mean() - 1) < 0.02)
+    assert lib.pm_partition_weighted(None, 3, 2, np.zeros(3, dtype=np.int64).ctypes.data) == capi.PM_E_INVALID
+    assert lib.pm_partition_weighted(np.array([1, -1], dtype=np.int64).ctypes.data, 2, 2, np.zeros(3, dtype=np.int64).ctypes.data) == capi.PM_E_INVALID
+
+
 def test_join_drops_a_repeated_header_at_a_seam(tmp_path):
     head = b"l/sequences.fasta r/sequences.fasta\nNUCMER\n"
     texts = [head + b">x y 10 10\n1 2 3 4 1 2 3\n0\n",
