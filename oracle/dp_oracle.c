@@ -225,6 +225,21 @@ int dp_oracle_score_of_path(const uint8_t *cols_a, int32_t la, const uint8_t *co
   return 0;
 }
 
+/* Every path of a batch in pm_dp_batch_fetch's layout (pair k's path: the LAST n_ops[k] bytes of its slot at off_a[k] + off_b[k])
+ * re-scored under the specification: rc[k] != 0 when the path does not span its pair, else scores[k] = what it scores.  The
+ * full-size GPU tests run this over slices of a 100 000-pair batch on every host core. */
+void dp_oracle_score_of_paths(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t first, int64_t end,
+                              const dp_params_t *p, const uint8_t *ops, const int32_t *n_ops, int32_t *rc, int32_t *scores) {
+  for(int64_t k = first; k < end; ++k) {
+    const int32_t la = (int32_t)(off_a[k + 1] - off_a[k]), lb = (int32_t)(off_b[k + 1] - off_b[k]);
+    const int64_t slot_end = off_a[k + 1] + off_b[k + 1];
+    scores[k] = 0;
+    rc[k] = n_ops[k] < 0 || n_ops[k] > la + lb
+                ? -1
+                : dp_oracle_score_of_path(cols_a + off_a[k] * 8, la, cols_b + off_b[k] * 8, lb, p, ops + slot_end - n_ops[k], n_ops[k], &scores[k]);
+  }
+}
+
 int dp_oracle_align_batch(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,
                           const dp_params_t *p, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
   for(int64_t k = 0; k < n_pairs; ++k) {

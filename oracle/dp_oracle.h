@@ -44,6 +44,9 @@ int32_t dp_oracle_score(const uint8_t *cols_a, int32_t la, const uint8_t *cols_b
  * reported score).  Returns 0 and the score, or -1 when the path does not span (0,0)-(La,Lb). */
 int dp_oracle_score_of_path(const uint8_t *cols_a, int32_t la, const uint8_t *cols_b, int32_t lb, const dp_params_t *p,
                             const uint8_t *ops, int32_t n_ops, int32_t *score);
+/* the same for pairs [first, end) of a batch in the product's fetch layout (path k = the last n_ops[k] bytes of its slot) */
+void dp_oracle_score_of_paths(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t first, int64_t end,
+                              const dp_params_t *p, const uint8_t *ops, const int32_t *n_ops, int32_t *rc, int32_t *scores);
 /* A batch of pairs in the product's layout (cols_*: concatenated columns, off_*: n_pairs+1 column offsets).
  * ops_off[k] .. : each pair owns la+lb bytes at ops + (off_a[k] + off_b[k]). */
 int dp_oracle_align_batch(const uint8_t *cols_a, const int64_t *off_a, const uint8_t *cols_b, const int64_t *off_b, int64_t n_pairs,

@@ -117,6 +117,9 @@ def dp_lib() -> C.CDLL:
         o.dp_oracle_score_batch.restype = None
         o.dp_oracle_score_of_path.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(PmDpParams), C.c_void_p, C.c_int32,
                                               C.POINTER(C.c_int32)]
+        o.dp_oracle_score_of_paths.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(PmDpParams),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        o.dp_oracle_score_of_paths.restype = None
         _dp = o
     return _dp
 
@@ -162,6 +165,70 @@ def dp_score_of_path(inputs, params, k, path):
     s = C.c_int32()
     rc = o.dp_oracle_score_of_path(a.ctypes.data, len(a), b.ctypes.data, len(b), C.byref(params), p.ctypes.data, len(p), C.byref(s))
     return rc, s.value
+
+
+def host_threads() -> int:
+    try:
+        return max(1, min(len(os.sched_getaffinity(0)), 16))  # a one-GPU box's CPU share is 16
+    except Exception:
+        return max(1, min(os.cpu_count() or 1, 16))
+
+
+def _slices_by_cells(inputs, n_slices, multiple=16):
+    """Contiguous slices of about equal cells, cut at multiples of `multiple` pairs (dp_tuned.c runs 16 pairs of one shape per vector)."""
+    n = inputs.n_pairs
+    cells = np.cumsum(np.diff(inputs.off_a).astype(np.float64) * np.diff(inputs.off_b) + 1.0)
+    cuts = [0]
+    for k in range(1, n_slices):
+        at = int(np.searchsorted(cells, cells[-1] * k / n_slices)) if n else 0
+        at = min(n, (at + multiple - 1) // multiple * multiple)
+        if at > cuts[-1]:
+            cuts.append(at)
+    if n > cuts[-1]:
+        cuts.append(n)
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+def dp_check_batch_exhaustively(inputs, params, scores, ops, n_ops):
+    """EVERY score of a batch against the tuned CPU scorer (dp_tuned.c, itself held to dp_oracle.c by tests/test_dp_oracle.py) and
+    EVERY path re-scored under the specification and checked to span its pair -- on all host cores (threads: the C calls release
+    the GIL and share the batch's arrays).  Returns (pairs whose score differs, pairs whose path fails) as index arrays."""
+    from concurrent.futures import ThreadPoolExecutor
+    from paramugsy_amd.shard import slice_pairs
+    o = dp_lib()
+    dp_tuned_lib()
+    n = inputs.n_pairs
+    ca, cb = np.ascontiguousarray(inputs.cols_a), np.ascontiguousarray(inputs.cols_b)
+    oa, ob = np.ascontiguousarray(inputs.off_a, dtype=np.int64), np.ascontiguousarray(inputs.off_b, dtype=np.int64)
+    scores = np.ascontiguousarray(scores, dtype=np.int32)
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    n_ops = np.ascontiguousarray(n_ops, dtype=np.int32)
+    t_scores = np.zeros(n, dtype=np.int32)
+    p_rc = np.zeros(n, dtype=np.int32)
+    p_scores = np.zeros(n, dtype=np.int32)
+    threads = host_threads()
+
+    def one(sl):
+        lo, hi = sl
+        t_scores[lo:hi] = dp_scores_tuned(slice_pairs(inputs, lo, hi), params)
+        o.dp_oracle_score_of_paths(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, lo, hi, C.byref(params), ops.ctypes.data,
+                                   n_ops.ctypes.data, p_rc.ctypes.data, p_scores.ctypes.data)
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(one, _slices_by_cells(inputs, threads * 8)))
+    return np.nonzero(t_scores != scores)[0], np.nonzero((p_rc != 0) | (p_scores != scores))[0]
+
+
+def dp_align_pairs(inputs, params, pairs):
+    """The scalar oracle's (score, path) of the given pairs, one pair per task on all host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from paramugsy_amd.shard import slice_pairs
+    dp_lib()
+
+    def one(k):
+        s, p = dp_align(slice_pairs(inputs, int(k), int(k) + 1), params)
+        return int(s[0]), p[0]
+    with ThreadPoolExecutor(host_threads()) as pool:
+        return list(pool.map(one, pairs))
 
 
 # ---------------------------------------------------------------- tuned CPU scorer (oracle/dp_tuned.c): bench.py's cpu_baseline.tuned

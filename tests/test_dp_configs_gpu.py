@@ -96,17 +96,14 @@ def test_pairs_split_over_workgroups_repeat_exactly(n_pairs, rows, L, oracle_bui
         batch.close()
 
 
-@pytest.mark.parametrize("n,budget_gib", [(12500, 0), (20000, 8), (100000, 0), (100000, 96)])
+@pytest.mark.parametrize("n,budget_gib", [(20000, 8), (100000, 96)])
 def test_ragged_segment_batch_stand_in_for_config_2(n, budget_gib, oracle_build):
     """Stand-in for BASELINE.json configs[2] ("~100 k segment profile alignments"; nucmer is not in the image): ragged 4-row
-    pairs, lengths log-normal (median 1 500, sigma 0.6, clipped to [200, 8 000]), lb = la * (1 + N(0, 0.05)) -- at the full
-    100 000 pairs with the default workspace budget (what bench.py's `c2` runs: 139 GB of checkpoints, ONE chunk in the default
-    60 % of the device's memory; the columns are drawn on the GPU, paramugsy_amd/synth_device.py), the same batch with 96 GiB
-    (chunks of a third of that, their fill kernels overlapping on three streams), 20 000 pairs with 8 GiB, and 12 500 pairs -- one
-    GPU's eighth of the batch, configs[3]'s per-GPU share: a launch its longest pair bounds, so the longest pairs run in small
-    launches of several wavefronts per pair beside the rest (dp_batch_plan's tiers; the sample holds pairs of every tier).  With a budget
-    given the batch is cut into at least three workspace chunks and the sample holds the pairs either side of every chunk
-    border."""
+    pairs, lengths log-normal (median 1 500, sigma 0.6, clipped to [200, 8 000]), lb = la * (1 + N(0, 0.05)) -- the full 100 000
+    pairs with a 96 GiB workspace (chunks of a third of that, their fill kernels overlapping on three streams) and 20 000 pairs
+    with 8 GiB; the batch at its default budget and one GPU's eighth of it (the tiers) are checked exhaustively in
+    tests/test_dp_full_gpu.py.  The batch is cut into at least three workspace chunks and the sample holds the pairs either side of
+    every chunk border."""
     rows = 4
     la, lb = dp.ragged_lengths(20261003, n)
     if n > 20000:
@@ -132,28 +129,6 @@ def test_ragged_segment_batch_stand_in_for_config_2(n, budget_gib, oracle_build)
     # every path spans its pair: as many ops as consume la columns of A and lb of B
     for k in range(0, n, max(1, n // 500)):
         assert (paths[k] != 1).sum() == la[k] and (paths[k] != 2).sum() == lb[k]
-    batch.close()
-
-
-def test_headline_batch_100k_pairs_of_8_rows_by_4096(oracle_build):
-    """The batch the north-star target is quoted on, whole, on one GPU: 100 000 pairs of 8 rows x 4 096 columns (6.5 GB of packed
-    columns, drawn on the GPU; the path workspace is cut into chunks).  Scores of a sample against the oracle's scorer, the
-    sampled paths re-scored under the specification, two of them against the oracle's own path op for op."""
-    from paramugsy_amd.synth_device import synth_batch_device
-    n, rows, L = 100000, 8, 4096
-    inputs = synth_batch_device(20261003 * 1000003, np.full(n, L), np.full(n, L), rows, rows, device="cuda")
-    params = dp.make_params(rows, rows)
-    batch = dp.DpBatch(inputs, params)
-    chunks, order = batch.chunks()
-    assert len(chunks) - 1 >= 3
-    batch.run(traceback=True)
-    scores, ops, n_ops = batch.fetch()
-    paths = dp.paths_of(inputs, ops, n_ops)
-    sample = [0, n - 1]
-    for c in range(len(chunks) - 1):
-        sample += [order[chunks[c]], order[chunks[c + 1] - 1]]
-    check_sample(inputs, params, scores, paths, sample, full_paths_for=[order[chunks[1] - 1], order[chunks[1]]])
-    assert (n_ops >= L).all() and (n_ops <= 2 * L).all()
     batch.close()
 
 

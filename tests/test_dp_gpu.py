@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from paramugsy_amd import dp
+from paramugsy_amd.shard import slice_pairs
 
 pytestmark = pytest.mark.gpu
 
@@ -403,20 +404,19 @@ def test_general_substitution_matrix_and_zero_penalties(oracle_build):
 
 
 def test_full_size_properties_baseline_config_1(oracle_build):
-    """BASELINE.json configs[1] at a reduced pair count but full shape (2 rows x 1 kbp): scores equal the oracle's
-    two-row scorer on every pair; every reported path re-scores to the reported score and spans the pair."""
+    """BASELINE.json configs[1] at its stated 10 000 pairs of 2 rows x 1 kbp: every score equals the tuned CPU scorer's, every
+    reported path re-scores to the reported score and spans its pair (the same batch with the oracle's paths op for op:
+    tests/test_dp_full_gpu.py)."""
     import pyoracle
-    inputs = dp.synth_pairs_fast(20261003, 512, 2, 1000)
+    inputs = dp.synth_pairs_fast(20261003, 10000, 2, 1000)
     params = dp.make_params(2, 2)
     batch = dp.DpBatch(inputs, params)
     batch.run(traceback=True)
     scores, ops, n_ops = batch.fetch()
-    assert np.array_equal(scores, pyoracle.dp_scores(inputs, params))
-    paths = batch.paths(ops, n_ops)
-    for k in range(0, inputs.n_pairs, 7):
-        rc, s = pyoracle.dp_score_of_path(inputs, params, k, paths[k])
-        assert rc == 0 and s == scores[k]
     batch.close()
+    bad_scores, bad_paths = pyoracle.dp_check_batch_exhaustively(inputs, params, scores, ops, n_ops)
+    assert len(bad_scores) == 0 and len(bad_paths) == 0
+    assert np.array_equal(scores[:300], pyoracle.dp_scores(slice_pairs(inputs, 0, 300), params))  # and the scalar oracle on the first 300
 
 
 def test_big_profiles_8_rows_4k_columns(oracle_build):
