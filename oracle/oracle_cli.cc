@@ -6,6 +6,7 @@
  */
 #include "pm_oracle.hh"
 
+#include <fstream>
 #include <iostream>
 #include <sstream>
 
@@ -66,6 +67,15 @@ static pmo::Gaps read_gaps(std::istringstream &iss) {
   return g;
 }
 
+static void print_record(pmo::Profile const &p) {
+  std::cout << "PREC " << p.major_name << ' ' << p.minor_name << ' ' << p.seq_name << ' ' << p.range.s << ' ' << p.range.e << ' ' << p.length << ' '
+            << p.src_size << ' ' << p.gaps.size();
+  for(size_t k = 0; k < p.gaps.size(); ++k) {
+    std::cout << ' ' << p.gaps[k].s << ' ' << p.gaps[k].e;
+  }
+  std::cout << ' ' << (p.text.empty() ? std::string("-") : p.text) << '\n';
+}
+
 static void print_gaps(pmo::Gaps const &g) {
   std::cout << ' ' << g.size();
   for(size_t k = 0; k < g.size(); ++k) {
@@ -81,6 +91,7 @@ int main() {
   cur.src_size = 0;
   pmo::DeltaEntry cur_d;
   cur_d.ref = cur_d.query = pmo::Range{1, 1};
+  const char *parse_error_name = "exception";
   std::string line;
   while(std::getline(std::cin, line)) {
     std::istringstream iss(line);
@@ -89,6 +100,7 @@ int main() {
       continue;
     }
     try {
+      parse_error_name = cmd == "mafread" ? "Maf_parse_error" : "Profile_read_error";
       if(cmd == "profile") {
         long s, e, len;
         iss >> s >> e >> len;
@@ -166,6 +178,55 @@ int main() {
         print_gaps(r.query_gaps);
         std::cout << '\n';
       }
+      else if(cmd == "ofmaf") {
+        long start, size, src_size;
+        std::string strand;
+        iss >> start >> size >> src_size >> strand;
+        pmo::Range r = pmo::range_of_maf(start, size, src_size, strand == "+");
+        std::cout << "RANGE " << r.s << ' ' << r.e << '\n';
+      }
+      else if(cmd == "mafread") {
+        std::string path;
+        iss >> path;
+        std::ifstream in(path.c_str());
+        pmo::MafBlock b;
+        while(pmo::read_maf_block(in, &b)) {
+          std::cout << "ENTRY " << b.score << ' ' << b.label << ' ' << b.rows.size() << '\n';
+          for(size_t r = 0; r < b.rows.size(); ++r) {
+            pmo::MafRow const &a = b.rows[r];
+            std::cout << "ALN " << a.genome << ' ' << a.start << ' ' << a.size << ' ' << a.src_size << ' ' << a.range.s << ' ' << a.range.e << ' '
+                      << a.text << '\n';
+          }
+        }
+        std::cout << "END\n";
+      }
+      else if(cmd == "profread" || cmd == "profpick") {
+        std::string path;
+        long arg = 0;
+        iss >> path >> arg;
+        std::ifstream in(path.c_str());
+        pmo::Profile p;
+        long k = 0;
+        bool picked = false;
+        for(; pmo::read_profile(in, cmd == "profread" && arg != 0, &p); ++k) {
+          if(cmd == "profread") {
+            cur = p;
+            print_record(cur);
+          }
+          else if(k == arg) {
+            cur = p;
+            print_record(cur);
+            picked = true;
+            break;
+          }
+        }
+        if(cmd == "profread") {
+          std::cout << "END\n";
+        }
+        else if(!picked) {
+          std::cout << "NONE\n";
+        }
+      }
       else if(cmd == "d2o") {
         std::vector<long> o = pmo::offsets_of_gaps(cur_d);
         std::cout << "OFFSETS";
@@ -188,6 +249,9 @@ int main() {
         break;
       case pmo::IS_NONE:
         std::cout << "EXC Is_none_error\n";
+        break;
+      case pmo::PARSE_ERROR:
+        std::cout << "EXC " << parse_error_name << "\n";
         break;
       default:
         std::cout << "EXC exception\n";

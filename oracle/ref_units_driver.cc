@@ -20,8 +20,17 @@
  *   d2o                    deltas_of_gaps              (m_delta_stream_writer.hh:14-53)
  *   dparse <rs> <re> <qs> <qe> {<offset>}*   M_delta_stream::next + _split_gaps (m_delta.cc:148-220,14-68)
  *                          on a one-entry delta text built from the arguments; sets the current delta entry
- * Every command prints exactly one line.
+ *   ofmaf <start> <size> <src_size> <+|->   of_maf  (m_range.hh:106-115): the range of a MAF `s` line
+ *   mafread <path>         Maf_read_stream::next until it returns none (maf_read_stream.cc:7-45, the `s` lines through
+ *                          Maf_entry_alignment's constructor, maf_read_stream.hh:20-45): one line ENTRY <score> <label> <rows> per
+ *                          block, one line ALN <genome> <start> <size> <src_size> <range start> <range end> <text> per row, then END
+ *   profread <path> <lite 0|1>   read_profile_file until none (m_profile.cc:15-85): one line
+ *                          PREC <major> <minor> <seq> <start> <end> <length> <src_size> <ngaps> {<gs> <ge>}* <text or -> per record
+ *                          (the record becomes the current profile: p2s / s2p / sub work on the last one read), then END
+ *   profpick <path> <k>    the same file again, the k-th record (0-based) becomes the current profile; prints its PREC line
+ * Every command but mafread / profread prints exactly one line.
  */
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -32,6 +41,7 @@
 #include <m_profile.hh>
 #include <m_delta.hh>
 #include <m_delta_stream_writer.hh>
+#include <maf_read_stream.hh>
 
 using namespace Para_mugsy;
 
@@ -43,6 +53,15 @@ static void print_profile(M_profile const &p) {
     std::cout << ' ' << i->get_start() << ' ' << i->get_end();
   }
   std::cout << '\n';
+}
+
+static void print_record(M_profile const &p) {
+  std::cout << "PREC " << p.p_major_name << ' ' << p.p_minor_name << ' ' << p.p_seq_name << ' ' << p.p_range.get_start() << ' '
+            << p.p_range.get_end() << ' ' << p.p_length << ' ' << p.p_src_size << ' ' << p.p_gaps.size();
+  for(gaps_t::const_iterator i = p.p_gaps.begin(); i != p.p_gaps.end(); ++i) {
+    std::cout << ' ' << i->get_start() << ' ' << i->get_end();
+  }
+  std::cout << ' ' << (p.p_seq_text.empty() ? std::string("-") : p.p_seq_text) << '\n';
 }
 
 static gaps_t read_gaps(std::istringstream &iss) {
@@ -155,6 +174,62 @@ int main() {
         }
         std::cout << '\n';
       }
+      else if(cmd == "ofmaf") {
+        long start, size, src_size;
+        std::string strand;
+        iss >> start >> size >> src_size >> strand;
+        M_range<long> r = of_maf(start, size, src_size, strand == "+" ? D_FORWARD : D_REVERSE);
+        std::cout << "RANGE " << r.get_start() << ' ' << r.get_end() << '\n';
+      }
+      else if(cmd == "mafread") {
+        std::string path;
+        iss >> path;
+        std::ifstream in(path.c_str());
+        Maf_read_stream mrs(in);
+        for(;;) { // (M_option has no assignment)
+          M_option<Maf_entry> e = mrs.next();
+          if(!e) {
+            break;
+          }
+          Maf_entry const &me = e.value();
+          std::cout << "ENTRY " << me.score() << ' ' << me.label() << ' ' << (me.alignments_end() - me.alignments_begin()) << '\n';
+          for(std::vector<Maf_entry_alignment>::const_iterator a = me.alignments_begin(); a != me.alignments_end(); ++a) {
+            std::cout << "ALN " << a->genome_name() << ' ' << a->start() << ' ' << a->size() << ' ' << a->src_size() << ' '
+                      << a->range().get_start() << ' ' << a->range().get_end() << ' ' << a->text() << '\n';
+          }
+        }
+        std::cout << "END\n";
+      }
+      else if(cmd == "profread" || cmd == "profpick") {
+        std::string path;
+        long arg = 0;
+        iss >> path >> arg;
+        std::ifstream in(path.c_str());
+        long k = 0;
+        bool picked = false;
+        for(;; ++k) {
+          M_option<M_profile> p = read_profile_file(cmd == "profread" && arg != 0, in);
+          if(!p) {
+            break;
+          }
+          if(cmd == "profread") {
+            cur = p.value();
+            print_record(cur);
+          }
+          else if(k == arg) {
+            cur = p.value();
+            print_record(cur);
+            picked = true;
+            break;
+          }
+        }
+        if(cmd == "profread") {
+          std::cout << "END\n";
+        }
+        else if(!picked) {
+          std::cout << "NONE\n";
+        }
+      }
       else if(cmd == "d2o") {
         std::vector<long> o = deltas_of_gaps(cur_d);
         std::cout << "OFFSETS";
@@ -166,6 +241,12 @@ int main() {
       else {
         std::cout << "BADCMD\n";
       }
+    }
+    catch(Maf_parse_error const &) {
+      std::cout << "EXC Maf_parse_error\n";
+    }
+    catch(Profile_read_error const &) {
+      std::cout << "EXC Profile_read_error\n";
     }
     catch(Seq_idx_out_of_range const &) {
       std::cout << "EXC Seq_idx_out_of_range\n";

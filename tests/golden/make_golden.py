@@ -11,6 +11,13 @@ seeded synthetic inputs (paramugsy_amd/synth.py) and the bytes the reference bin
   sort_<name>.delta / sort_<name>.expected      = oracle/_ref/m_sort_delta < in > expected
   maf_<name>.maf / maf_<name>.expected          = oracle/_ref/maf_analyzer in > expected
   units_cmds.txt / units_expected.txt           = oracle/_ref/ref_units < cmds > expected
+  stage_pin/          what the reference's compiled C++ says about the inputs and outputs of the two OCaml stages around the path
+                      (round 4; tests/test_stage_pins.py): side_l.maf, side_r.maf (seeded synthetic sides), l/profiles, r/profiles
+                      (what `mugsy_profiles make` writes for them -- oracle/make_oracle.py's bytes, the HIP path must print the same),
+                      in.maf (a fake mugsyWGA output over column ranges of those profiles), cmds.txt / expected.txt =
+                      oracle/_ref/ref_units < cmds > expected (run with cwd = tests/golden): Maf_read_stream and of_maf over the
+                      sides, read_profile_file over the profiles, profile_idx_of_seq_idx for the bases of every row,
+                      subset_profile and seq_idx_of_profile_idx for every (row profile, column range) untranslate asks for
 """
 import os
 import shutil
@@ -152,10 +159,100 @@ def make_unit_cases() -> None:
     print("units: %d commands" % len(lines))
 
 
+def stage_pin_commands(case: str) -> str:
+    """The command list of the stage pin (paths relative to tests/golden).  Deterministic in the fixture's files, so that the test can
+    rebuild it and hold the committed cmds.txt to it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import untranslate_oracle as uo
+    rel = os.path.relpath(case, HERE)
+    lines = []
+    records = {}
+    for side in ("l", "r"):
+        lines.append("mafread %s/side_%s.maf" % (rel, side))
+        lines.append("profread %s/%s/profiles 0" % (rel, side))
+        profs = uo.read_profiles(open(os.path.join(case, side, "profiles")).read())
+        records[side] = profs
+        for k, p in enumerate(profs):
+            lines.append("profpick %s/%s/profiles %d" % (rel, side, k))
+            fwd = p.range[0] <= p.range[1]
+            n_bases = abs(p.range[0] - p.range[1]) + 1 if p.length - sum(b - a + 1 for a, b in p.gaps) > 0 else 0
+            step = max(1, n_bases // 12)
+            for j in list(range(0, n_bases, step)) + ([n_bases - 1] if n_bases else []):
+                lines.append("p2s %d" % (p.range[0] + j if fwd else p.range[0] - j))  # the j-th base of the row
+    # every (row profile, column range) the untranslate of in.maf asks for
+    by_block = {}
+    for side in ("l", "r"):
+        for k, p in enumerate(records[side]):
+            by_block.setdefault(p.major, []).append((side, k, p))
+    for l in open(os.path.join(case, "in.maf")).read().split("\n"):
+        if not l.startswith("s "):
+            continue
+        _, name, start, size, d, src_size, _text = [t for t in l.split(" ") if t != ""]
+        lines.append("ofmaf %s %s %s %s" % (start, size, src_size, d))
+        ov = uo.of_maf(int(start), int(size), int(src_size), d)
+        s_, e_ = min(ov), max(ov)
+        for side, k, p in by_block[name]:
+            lines.append("profpick %s/%s/profiles %d" % (rel, side, k))
+            lines.append("sub %d %d" % (s_, e_))
+            lines.append("s2p %d" % s_)
+            lines.append("s2p %d" % e_)
+    return "\n".join(lines) + "\n"
+
+
+def make_stage_pin() -> None:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_oracle
+    case = os.path.join(HERE, "stage_pin")
+    shutil.rmtree(case, ignore_errors=True)
+    os.makedirs(case)
+    rng = np.random.default_rng(20261004)
+    sides = {}
+    for side, genomes in (("l", ["L0.c", "L1.c", "L2.c"]), ("r", ["R0.c", "R1.c"])):
+        blocks = synth.gen_side(rng, genomes, 6000, 14, mean_cols=70, gap_rate=0.06, mean_gap=3.0, edge_gap_prob=0.5, rev_prob=0.4)
+        maf = synth.side_to_maf_text(blocks)
+        with open(os.path.join(case, "side_%s.maf" % side), "w") as f:
+            f.write(maf)
+        prof, fasta = make_oracle.make(maf, side)
+        os.makedirs(os.path.join(case, side))
+        with open(os.path.join(case, side, "profiles"), "w") as f:
+            f.write(prof)
+        with open(os.path.join(case, side, "sequences.fasta"), "w") as f:
+            f.write(fasta)
+        sides[side] = blocks
+    lines = ["##maf version=1 scoring=mugsy", "# a fake mugsyWGA output over column ranges of the two sides' profiles"]
+    for _ in range(40):
+        lines.append("a score=%d label=1 mult=2" % int(rng.integers(0, 999)))
+        for _r in range(int(rng.integers(1, 4))):
+            side = "lr"[int(rng.integers(0, 2))]
+            blocks = sides[side]
+            b = int(rng.integers(0, len(blocks)))
+            cols = len(blocks[b].rows[0].text)
+            size = int(rng.integers(1, cols + 1))
+            start = int(rng.integers(0, cols - size + 1))
+            text = list("ACGT"[int(x)] for x in rng.integers(0, 4, size=size))
+            for _g in range(int(rng.integers(0, 3))):
+                text.insert(int(rng.integers(0, len(text) + 1)), "-")
+            lines.append("s %s.%s_%04d %d %d %s %d %s" % (side, side, b, start, size, "+" if rng.random() < 0.6 else "-", cols, "".join(text)))
+        lines.append("")
+    with open(os.path.join(case, "in.maf"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    cmds = stage_pin_commands(case)
+    with open(os.path.join(case, "cmds.txt"), "w") as f:
+        f.write(cmds)
+    r = subprocess.run([os.path.join(REF, "ref_units")], input=cmds.encode(), capture_output=True, check=True, cwd=HERE)
+    with open(os.path.join(case, "expected.txt"), "wb") as f:
+        f.write(r.stdout)
+    print("stage_pin: %d commands, %d bytes expected" % (cmds.count("\n"), len(r.stdout)))
+
+
 if __name__ == "__main__":
     if not os.path.exists(os.path.join(REF, "m_translate")):
         sys.exit("oracle/_ref missing: run `make -C oracle ref` where /root/reference exists")
+    if len(sys.argv) > 1 and sys.argv[1] == "stage_pin":
+        make_stage_pin()
+        sys.exit(0)
     make_translate_cases()
     make_sort_cases()
     make_maf_cases()
     make_unit_cases()
+    make_stage_pin()
