@@ -40,9 +40,10 @@ bin/m_sort_delta bin/maf_analyzer: $(CSRC)/side_tools_main.cc $(LIB)
 	$(HIPCC) -O2 -std=c++17 -DPM_TOOL_SORT_DELTA -o bin/m_sort_delta $(CSRC)/side_tools_main.cc -Lparamugsy_amd -lparamugsy_amd -Wl,-rpath,'$$ORIGIN/../paramugsy_amd'
 	$(HIPCC) -O2 -std=c++17 -DPM_TOOL_MAF_ANALYZER -o bin/maf_analyzer $(CSRC)/side_tools_main.cc -Lparamugsy_amd -lparamugsy_amd -Wl,-rpath,'$$ORIGIN/../paramugsy_amd'
 
+# the drop-in links nothing of HIP: it asks a resident worker first and loads the library only when nobody listens (m_translate_main.cc)
 bin/m_translate: $(CSRC)/m_translate_main.cc $(LIB)
 	mkdir -p bin
-	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/m_translate_main.cc -Lparamugsy_amd -lparamugsy_amd -Wl,-rpath,'$$ORIGIN/../paramugsy_amd'
+	g++ -O2 -std=c++17 -Wall -o $@ $(CSRC)/m_translate_main.cc -ldl
 
 oracle:
 	$(MAKE) -C oracle oracle

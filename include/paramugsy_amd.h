@@ -181,6 +181,12 @@ void pm_workload_destroy(pm_workload_t *w);
  * delta_paths: n_paths NUL-terminated strings.  Output bytes equal the reference's. */
 int pm_translate_files(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                        const char *out_path, int device);
+/* The same with the two directory names of the output's first line (m_translate_main.cc:35-39 prints its argv strings) given apart
+ * from the paths the files are opened by, and a device list (n_devices > 1: pm_translate_files_multi's split).  What the resident
+ * worker (`mugsy_profiles serve -socket`) runs for an m_translate client in another working directory: the client's relative paths
+ * are resolved against ITS directory, the output holds the strings it was started with.  New surface. */
+int pm_translate_files_as(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths, const char *out_path,
+                          const char *left_name, const char *right_name, const int *devices, int n_devices);
 
 /* The two tools of lib/profiles_cpp that compile upstream (nothing in the reference invokes them).
  * pm_sort_delta   == m_sort_delta (lib/profiles_cpp/m_sort_delta.cc:58-91): delta text in, the same entries sorted by

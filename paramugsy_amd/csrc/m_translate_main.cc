@@ -1,15 +1,108 @@
 // m_translate_main.cc -- the drop-in executable.  Same argv, same exit behaviour and same output bytes as
 // the reference's lib/m_translate/m_translate_main.cc:19-46; the work runs on the GPU through the C ABI.
-// Optional: PARAMUGSY_DEVICE=<n> selects the HIP device (default 0); PARAMUGSY_DEVICES=0,1,... spreads the delta-file list over
-// several devices of the node (pm_translate_files_multi; the argv stays the reference's).
+//
+// A fresh process pays 0.05-0.19 s for a HIP runtime of its own before the 0.05 s job (round 3: the drop-in lost to the reference
+// run as sixteen processes).  So this executable links NOTHING of HIP: it first asks a resident worker -- `mugsy_profiles serve -socket
+// <path>`, one per GPU, started once per node by whoever owns the node -- over a UNIX socket (PARAMUGSY_SERVE_SOCKET, default
+// /tmp/paramugsy-serve-<uid>.sock) and prints what the worker says; only when nobody listens does it load libparamugsy_amd.so
+// (dlopen, from ../paramugsy_amd beside this file) and run the job in this process, as before.  The orchestrator's task script
+// (lib/base/mugsy_profiles_task.ml:53-58) needs no change either way.
+// Optional: PARAMUGSY_DEVICE=<n> selects the HIP device (default 0; with a worker: the worker's); PARAMUGSY_DEVICES=0,1,... spreads the
+// delta-file list over several devices of the node (pm_translate_files_multi; the argv stays the reference's).
+#include <cerrno>
 #include <cstdio>
-#include <unistd.h>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <string>
 #include <vector>
 
-#include "../../include/paramugsy_amd.h"
+#include <dlfcn.h>
+#include <sys/socket.h>
+#include <sys/un.h>
+#include <unistd.h>
+
+typedef int (*translate_as_fn)(const char *, const char *, const char *const *, int, const char *, const char *, const char *, const int *, int);
+typedef const char *(*last_error_fn)(void);
+
+static bool plain(const std::string &s) { return s.find('\t') == std::string::npos && s.find('\n') == std::string::npos; }
+
+// The job through a resident worker: 1 when it ran there (rc and message set), 0 when nobody listens (or the request cannot be put
+// on one line): then it runs here.
+static int ask_worker(char **argv, const std::vector<std::string> &paths, const char *devices, int &rc, std::string &message) {
+  std::string sock;
+  if(const char *e = getenv("PARAMUGSY_SERVE_SOCKET")) {
+    sock = e;
+  }
+  else {
+    sock = "/tmp/paramugsy-serve-" + std::to_string((long)getuid()) + ".sock";
+  }
+  if(sock.empty() || sock == "none") {
+    return 0;
+  }
+  sockaddr_un addr;
+  memset(&addr, 0, sizeof addr);
+  addr.sun_family = AF_UNIX;
+  if(sock.size() >= sizeof addr.sun_path) {
+    return 0;
+  }
+  memcpy(addr.sun_path, sock.c_str(), sock.size() + 1);
+  char cwd[4096];
+  if(!getcwd(cwd, sizeof cwd)) {
+    return 0;
+  }
+  std::string req = std::string("translate\t") + cwd + "\t" + argv[1] + "\t" + argv[2] + "\t" + argv[4] + "\t" + (devices && *devices ? devices : "-") +
+                    "\t" + std::to_string(paths.size());
+  if(!plain(cwd) || !plain(argv[1]) || !plain(argv[2]) || !plain(argv[4])) {
+    return 0;
+  }
+  for(size_t k = 0; k < paths.size(); ++k) {
+    if(!plain(paths[k])) {
+      return 0;
+    }
+    req += "\t" + paths[k];
+  }
+  req += "\n";
+  const int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+  if(fd < 0) {
+    return 0;
+  }
+  if(connect(fd, (sockaddr *)&addr, sizeof addr) != 0) {
+    close(fd);
+    return 0;
+  }
+  size_t at = 0;
+  while(at < req.size()) {
+    const ssize_t n = send(fd, req.data() + at, req.size() - at, MSG_NOSIGNAL);
+    if(n <= 0) {
+      close(fd);
+      return 0; // nothing has run yet
+    }
+    at += (size_t)n;
+  }
+  std::string reply;
+  char buf[4096];
+  for(;;) {
+    const ssize_t n = read(fd, buf, sizeof buf);
+    if(n <= 0) {
+      break;
+    }
+    reply.append(buf, (size_t)n);
+  }
+  close(fd);
+  if(reply.compare(0, 5, "done ") != 0) { // the worker died on the job: what it wrote is on the stream, as the reference's would be
+    rc = -1;
+    message = "the resident worker went away";
+    return 1;
+  }
+  rc = atoi(reply.c_str() + 5);
+  const size_t nl = reply.find('\n');
+  message = nl == std::string::npos ? "" : reply.substr(nl + 1);
+  while(!message.empty() && message[message.size() - 1] == '\n') {
+    message.erase(message.size() - 1);
+  }
+  return 1;
+}
 
 int main(int argc, char **argv) {
   if(argc < 5) {
@@ -24,28 +117,59 @@ int main(int argc, char **argv) {
       paths.push_back(line);
     }
   }
-  std::vector<const char *> cpaths;
-  for(size_t k = 0; k < paths.size(); ++k) {
-    cpaths.push_back(paths[k].c_str());
-  }
-  const char *dev_env = getenv("PARAMUGSY_DEVICE");
-  int device = dev_env ? atoi(dev_env) : 0;
-  std::vector<int> devs;
-  if(const char *list = getenv("PARAMUGSY_DEVICES")) {
-    for(const char *p = list; *p;) {
-      char *end = nullptr;
-      long v = strtol(p, &end, 10);
-      if(end == p) {
-        break;
+  const char *devices_env = getenv("PARAMUGSY_DEVICES");
+  int rc = 0;
+  std::string message;
+  if(!ask_worker(argv, paths, devices_env, rc, message)) {
+    // nobody listens: the library, and the job in this process
+    std::string lib;
+    {
+      char exe[4096];
+      const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+      if(n > 0) {
+        exe[n] = 0;
+        lib = exe;
+        lib = lib.substr(0, lib.rfind('/')); // bin
+        lib = lib.substr(0, lib.rfind('/')) + "/paramugsy_amd/libparamugsy_amd.so";
       }
-      devs.push_back((int)v);
-      p = *end == ',' ? end + 1 : end;
+    }
+    void *h = lib.empty() ? nullptr : dlopen(lib.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if(!h) {
+      h = dlopen("libparamugsy_amd.so", RTLD_NOW | RTLD_GLOBAL);
+    }
+    translate_as_fn run = h ? (translate_as_fn)dlsym(h, "pm_translate_files_as") : nullptr;
+    last_error_fn last_error = h ? (last_error_fn)dlsym(h, "pm_last_error") : nullptr;
+    if(!run || !last_error) {
+      fprintf(stderr, "m_translate: cannot load libparamugsy_amd.so (%s): %s\n", lib.c_str(), dlerror());
+      return 134;
+    }
+    std::vector<const char *> cpaths;
+    for(size_t k = 0; k < paths.size(); ++k) {
+      cpaths.push_back(paths[k].c_str());
+    }
+    const char *dev_env = getenv("PARAMUGSY_DEVICE");
+    std::vector<int> devs;
+    if(devices_env) {
+      for(const char *p = devices_env; *p;) {
+        char *end = nullptr;
+        long v = strtol(p, &end, 10);
+        if(end == p) {
+          break;
+        }
+        devs.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+      }
+    }
+    if(devs.empty()) {
+      devs.push_back(dev_env ? atoi(dev_env) : 0);
+    }
+    rc = run(argv[1], argv[2], cpaths.data(), (int)cpaths.size(), argv[4], argv[1], argv[2], devs.data(), (int)devs.size());
+    if(rc) {
+      message = last_error();
     }
   }
-  int rc = devs.size() > 1 ? pm_translate_files_multi(argv[1], argv[2], cpaths.data(), (int)cpaths.size(), argv[4], devs.data(), (int)devs.size())
-                           : pm_translate_files(argv[1], argv[2], cpaths.data(), (int)cpaths.size(), argv[4], devs.size() == 1 ? devs[0] : device);
-  if(rc != PM_OK) {
-    fprintf(stderr, "m_translate: error %d: %s\n", rc, pm_last_error());
+  if(rc != 0) {
+    fprintf(stderr, "m_translate: error %d: %s\n", rc, message.c_str());
     // the reference ends in SIGABRT (uncaught exception / assert) on every failure past argument checking
     return 134;
   }

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <unistd.h>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -16,7 +17,10 @@
 #include <string>
 #include <vector>
 
+#include <signal.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
+#include <sys/un.h>
 
 #include "../../include/paramugsy_amd.h"
 
@@ -181,6 +185,135 @@ static int run_command(const std::string &cmd, std::map<std::string, std::string
   return 0;
 }
 
+// ---- `serve -socket <path>`: the resident worker behind the drop-in m_translate (bin/m_translate asks it before it would bring a HIP
+// runtime of its own up, csrc/m_translate_main.cc).  One request per connection, one line, TAB-separated:
+//   translate <cwd> <left_dir> <right_dir> <out_path> <devices or -> <n> <delta path> x n       (paths as the client's argv / list had them)
+//   quit
+// answered by `done <exit code>\n` and, after a failure, the message the client prints.  Relative paths are the CLIENT's: they are
+// resolved against its working directory; the output's first line holds the strings it was started with (pm_translate_files_as).
+// Requests are served one after the other (a second client waits in the listen queue): a node's job is 0.05 s of a GPU.
+static std::string client_path(const std::string &cwd, const std::string &p) { return !p.empty() && p[0] == '/' ? p : cwd + "/" + p; }
+
+static bool read_line(int fd, std::string &line, size_t limit = (size_t)64 << 20) {
+  line.clear();
+  char buf[4096];
+  for(;;) {
+    const ssize_t n = read(fd, buf, sizeof buf);
+    if(n <= 0) {
+      return false;
+    }
+    for(ssize_t k = 0; k < n; ++k) {
+      if(buf[k] == '\n') {
+        line.append(buf, (size_t)k);
+        return true;
+      }
+    }
+    line.append(buf, (size_t)n);
+    if(line.size() > limit) {
+      return false;
+    }
+  }
+}
+
+static void write_all(int fd, const std::string &text) {
+  size_t at = 0;
+  while(at < text.size()) {
+    const ssize_t n = write(fd, text.data() + at, text.size() - at);
+    if(n <= 0) {
+      return;
+    }
+    at += (size_t)n;
+  }
+}
+
+static int serve_socket(const std::string &path, int device) {
+  signal(SIGPIPE, SIG_IGN); // a client that went away must not take the worker with it
+  const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+  sockaddr_un addr;
+  memset(&addr, 0, sizeof addr);
+  addr.sun_family = AF_UNIX;
+  if(ls < 0 || path.size() >= sizeof addr.sun_path) {
+    fprintf(stderr, "mugsy_profiles serve: cannot make a socket at %s\n", path.c_str());
+    return 2;
+  }
+  memcpy(addr.sun_path, path.c_str(), path.size() + 1);
+  // a socket file left behind by a worker that is gone is replaced; one that answers is somebody else's worker
+  {
+    const int probe = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+    if(probe >= 0 && connect(probe, (sockaddr *)&addr, sizeof addr) == 0) {
+      close(probe);
+      fprintf(stderr, "mugsy_profiles serve: a worker is already listening at %s\n", path.c_str());
+      return 2;
+    }
+    if(probe >= 0) {
+      close(probe);
+    }
+    unlink(path.c_str());
+  }
+  const mode_t old = umask(0077); // the socket is its owner's alone
+  const int rc_bind = bind(ls, (sockaddr *)&addr, sizeof addr);
+  umask(old);
+  if(rc_bind != 0 || listen(ls, 64) != 0) {
+    fprintf(stderr, "mugsy_profiles serve: cannot listen at %s: %s\n", path.c_str(), strerror(errno));
+    return 2;
+  }
+  (void)pm_device_count(); // bring the runtime up before the first request
+  bool running = true;
+  while(running) {
+    const int fd = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
+    if(fd < 0) {
+      if(errno == EINTR) {
+        continue;
+      }
+      break;
+    }
+    std::string line;
+    if(read_line(fd, line)) {
+      std::vector<std::string> tok;
+      size_t at = 0;
+      while(at <= line.size()) {
+        size_t e = line.find('\t', at);
+        if(e == std::string::npos) {
+          e = line.size();
+        }
+        tok.push_back(line.substr(at, e - at));
+        at = e + 1;
+      }
+      if(tok[0] == "quit") {
+        write_all(fd, "done 0\n");
+        running = false;
+      }
+      else if(tok[0] == "translate" && tok.size() >= 7 && (size_t)atol(tok[6].c_str()) + 7 == tok.size()) {
+        const std::string &cwd = tok[1];
+        std::vector<std::string> paths;
+        for(size_t k = 7; k < tok.size(); ++k) {
+          paths.push_back(client_path(cwd, tok[k]));
+        }
+        std::vector<const char *> cpaths;
+        for(size_t k = 0; k < paths.size(); ++k) {
+          cpaths.push_back(paths[k].c_str());
+        }
+        std::vector<int> devs = tok[5] == "-" ? std::vector<int>() : parse_devices(tok[5]);
+        if(devs.empty()) {
+          devs.push_back(device);
+        }
+        const int rc = pm_translate_files_as(client_path(cwd, tok[2]).c_str(), client_path(cwd, tok[3]).c_str(), cpaths.data(), (int)cpaths.size(),
+                                             client_path(cwd, tok[4]).c_str(), tok[2].c_str(), tok[3].c_str(), devs.data(), (int)devs.size());
+        char head[64];
+        snprintf(head, sizeof head, "done %d\n", rc);
+        write_all(fd, std::string(head) + (rc ? std::string(pm_last_error()) + "\n" : std::string()));
+      }
+      else {
+        write_all(fd, "done -1\nmugsy_profiles serve: bad request\n");
+      }
+    }
+    close(fd);
+  }
+  close(ls);
+  unlink(path.c_str());
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if(argc < 2) {
     fprintf(stderr, "usage: mugsy_profiles {make|translate|untranslate|stage|align|serve} <flags>\n");
@@ -190,7 +323,10 @@ int main(int argc, char **argv) {
   const char *dev_env = getenv("PARAMUGSY_DEVICE");
   int device = dev_env ? atoi(dev_env) : 0;
   int code;
-  if(cmd == "serve") {
+  if(cmd == "serve" && argc >= 4 && std::string(argv[2]) == "-socket") {
+    code = serve_socket(argv[3], device);
+  }
+  else if(cmd == "serve") {
     // new in this build: a resident worker.  The orchestrator starts one short process per tree node
     // (lib/base/job_processor.ml:184-211) and each pays the HIP runtime's start-up; a worker pays it once.  Protocol: one
     // command per line on stdin, TAB-separated (`stage<TAB>-left_maf<TAB>path<TAB>...`), answered by `done <exit code>` on stdout;

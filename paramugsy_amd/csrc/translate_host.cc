@@ -1311,8 +1311,39 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
 
 extern "C" int pm_translate_files(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                                   const char *out_path, int device) {
+  return pm_translate_files_as(left_dir, right_dir, delta_paths, n_paths, out_path, left_dir, right_dir, &device, 1);
+}
+
+extern "C" int pm_translate_files_as(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
+                                     const char *out_path, const char *left_name, const char *right_name, const int *devices, int n_devices) {
+  if(devices && n_devices > 1) {
+    return pm::guarded("pm_translate_files_as", [&]() -> int {
+      if(!left_dir || !right_dir || !out_path || !left_name || !right_name || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
+        return pm::fail(PM_E_INVALID, "pm_translate_files_as: null argument");
+      }
+      PM_TRY(pm::check_devices(devices, n_devices, "pm_translate_files_as"));
+      std::vector<std::string> paths;
+      for(int k = 0; k < n_paths; ++k) {
+        if(!delta_paths[k]) {
+          return pm::fail(PM_E_INVALID, "pm_translate_files_as: null path");
+        }
+        paths.push_back(delta_paths[k]);
+      }
+      FILE *f = fopen(out_path, "wb");
+      if(!f) {
+        return pm::fail(PM_E_IO, std::string("cannot open ") + out_path);
+      }
+      fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_name, right_name); // m_translate_main.cc:35-39
+      int rc = pm::translate_to_file_multi(left_dir, right_dir, paths, f, devices, n_devices);
+      if(fclose(f) != 0 && !rc) {
+        rc = pm::fail(PM_E_IO, "close failed");
+      }
+      return rc;
+    });
+  }
+  const int device = devices && n_devices == 1 ? devices[0] : 0;
   return pm::guarded("pm_translate_files", [&]() -> int {
-  if(!left_dir || !right_dir || !out_path || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
+  if(!left_dir || !right_dir || !out_path || !left_name || !right_name || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
     return pm::fail(PM_E_INVALID, "pm_translate_files: null argument");
   }
   int rc = PM_OK;
@@ -1327,8 +1358,8 @@ extern "C" int pm_translate_files(const char *left_dir, const char *right_dir, c
   if(!f) {
     return pm::fail(PM_E_IO, std::string("cannot open ") + out_path);
   }
-  // m_translate_main.cc:35-39
-  fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_dir, right_dir);
+  // m_translate_main.cc:35-39 (the names as the caller's argv had them, whatever paths the files are opened by)
+  fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_name, right_name);
   rc = pm::translate_to_file(left_dir, right_dir, paths, f, device);
   if(fclose(f) != 0 && !rc) {
     rc = pm::fail(PM_E_IO, "close failed");

@@ -1,0 +1,147 @@
+"""The drop-in m_translate and the resident worker behind it: bin/m_translate links nothing of HIP, asks
+`mugsy_profiles serve -socket <path>` over a UNIX socket first and runs the job in its own process only when nobody listens.
+
+CPU part: the shim's side of the protocol against a stand-in worker written here (what it sends for which argv, what it does with
+the reply, two clients at once, the fall-back when the socket is dead).  GPU part (-m gpu): the real worker -- two concurrent
+clients started in another directory with relative paths get the reference's bytes (tests/golden/translate_*)."""
+import os
+import shutil
+import socket
+import subprocess
+import threading
+import time
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+EXE = os.path.join(ROOT, "bin", "m_translate")
+WORKER = os.path.join(ROOT, "bin", "mugsy_profiles")
+
+
+def test_the_drop_in_does_not_link_the_hip_runtime():
+    needed = subprocess.run(["ldd", EXE], capture_output=True, text=True, check=True).stdout
+    assert "amdhip" not in needed and "paramugsy" not in needed and "hsa" not in needed, needed
+
+
+class StandInWorker(threading.Thread):
+    """Speaks the worker's side of the protocol (csrc/mugsy_profiles_main.cc, serve_socket): records the requests, writes a marker into
+    the requested output, answers `done <rc>` (and a message after a failure)."""
+
+    def __init__(self, path, rc=0, message="", delay=0.0):
+        super().__init__(daemon=True)
+        self.path, self.rc, self.message, self.delay = path, rc, message, delay
+        self.requests = []
+        self.sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        self.sock.bind(path)
+        self.sock.listen(8)
+
+    def run(self):
+        while True:
+            try:
+                c, _ = self.sock.accept()
+            except OSError:
+                return
+            data = b""
+            while not data.endswith(b"\n"):
+                chunk = c.recv(65536)
+                if not chunk:
+                    break
+                data += chunk
+            f = data.decode().rstrip("\n").split("\t")
+            self.requests.append(f)
+            time.sleep(self.delay)
+            if f[0] == "translate":
+                out = f[4] if f[4].startswith("/") else os.path.join(f[1], f[4])
+                with open(out, "w") as o:
+                    o.write("%s/sequences.fasta %s/sequences.fasta\nNUCMER\nfrom the stand-in: %s\n" % (f[2], f[3], " ".join(f[7:])))
+            c.sendall(("done %d\n%s" % (self.rc, self.message + "\n" if self.rc else "")).encode())
+            c.close()
+
+    def stop(self):
+        self.sock.close()
+
+
+def test_the_shim_sends_its_argv_and_directory_and_prints_the_workers_verdict(tmp_path):
+    sock = str(tmp_path / "w.sock")
+    w = StandInWorker(sock)
+    w.start()
+    job = tmp_path / "job"
+    job.mkdir()
+    (job / "nucmer.list").write_text("a.delta\nsub/b.delta\n")
+    env = dict(os.environ, PARAMUGSY_SERVE_SOCKET=sock)
+    r = subprocess.run([EXE, "profiles-l", "../r dir", "nucmer.list", "out.delta"], cwd=str(job), env=env, capture_output=True)
+    assert r.returncode == 0 and r.stderr == b""
+    assert w.requests == [["translate", str(job), "profiles-l", "../r dir", "out.delta", "-", "2", "a.delta", "sub/b.delta"]]
+    assert (job / "out.delta").read_text().startswith("profiles-l/sequences.fasta ../r dir/sequences.fasta\nNUCMER\n")
+    # a device list rides along; two clients at once are both served
+    w.delay = 0.2
+    env2 = dict(env, PARAMUGSY_DEVICES="0,1")
+    ps = [subprocess.Popen([EXE, "l", "r", "nucmer.list", "o%d.delta" % k], cwd=str(job), env=env2) for k in range(2)]
+    assert [p.wait() for p in ps] == [0, 0]
+    assert sorted(q[4] for q in w.requests[1:]) == ["o0.delta", "o1.delta"] and all(q[5] == "0,1" for q in w.requests[1:])
+    # a failed job: the reference's exit behaviour (SIGABRT's 134) and the worker's message
+    w.rc, w.message, w.delay = 7, "work unit 3 failed with status 2", 0.0
+    r = subprocess.run([EXE, "l", "r", "nucmer.list", "o.delta"], cwd=str(job), env=env, capture_output=True)
+    assert r.returncode == 134 and b"error 7: work unit 3 failed with status 2" in r.stderr
+    w.stop()
+    # usage error: before anybody is asked (m_translate_main.cc:22-25)
+    r = subprocess.run([EXE, "l"], env=env, capture_output=True)
+    assert r.returncode == 1 and b"Usage: m_translate" in r.stderr
+
+
+def test_nobody_listening_means_the_job_runs_in_the_process(tmp_path, hip_lib):
+    """A socket file nobody answers at (and no socket at all): the library is loaded and the job runs here -- on a machine without a
+    GPU that is the loud refusal of the C ABI (no CPU path), with a GPU the in-process path every other CLI test runs."""
+    if hip_lib.pm_device_count() > 0:
+        pytest.skip("a HIP device is present: the in-process path is tests/test_translate_gpu.py's")
+    dead = str(tmp_path / "dead.sock")
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.bind(dead)
+    s.close()  # the file stays, nobody listens
+    (tmp_path / "nucmer.list").write_text("")
+    for sock in (dead, str(tmp_path / "none.sock"), "none"):
+        r = subprocess.run([EXE, "l", "r", "nucmer.list", "o.delta"], cwd=str(tmp_path), env=dict(os.environ, PARAMUGSY_SERVE_SOCKET=sock),
+                           capture_output=True)
+        assert r.returncode == 134 and b"no CPU path" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_two_clients_of_the_resident_worker_get_the_references_bytes(tmp_path):
+    sock = str(tmp_path / "serve.sock")
+    worker = subprocess.Popen([WORKER, "serve", "-socket", sock])
+    try:
+        for _ in range(600):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        assert os.path.exists(sock)
+        env = dict(os.environ, PARAMUGSY_SERVE_SOCKET=sock)
+        jobs = []
+        for name in ("typical", "gappy", "reverse", "tiny_blocks"):
+            case = str(tmp_path / name)
+            shutil.copytree(os.path.join(GOLDEN, "translate_" + name), case)
+            os.remove(os.path.join(case, "expected.delta"))
+            jobs.append((name, case))
+        for round_ in range(2):  # the second round meets a warm worker
+            ps = [(name, case, subprocess.Popen([EXE, "profiles-l", "profiles-r", "nucmer.list", "out%d.delta" % round_], cwd=case, env=env))
+                  for name, case in jobs]  # four clients at once, each in its own directory with relative paths
+            for name, case, p in ps:
+                assert p.wait() == 0
+                got = open(os.path.join(case, "out%d.delta" % round_), "rb").read()
+                assert got == open(os.path.join(GOLDEN, "translate_" + name, "expected.delta"), "rb").read(), name
+        # a failing job comes back as the reference's SIGABRT exit, and the worker lives on
+        r = subprocess.run([EXE, "profiles-l", "no-such-dir", "nucmer.list", "bad.delta"], cwd=jobs[0][1], env=env, capture_output=True)
+        assert r.returncode == 134
+        r = subprocess.run([EXE, "profiles-l", "profiles-r", "nucmer.list", "again.delta"], cwd=jobs[0][1], env=env)
+        assert r.returncode == 0
+        c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        c.connect(sock)
+        c.sendall(b"quit\n")
+        assert c.recv(64).startswith(b"done 0")
+        c.close()
+        assert worker.wait(timeout=30) == 0
+        assert not os.path.exists(sock)
+    finally:
+        if worker.poll() is None:
+            worker.kill()
