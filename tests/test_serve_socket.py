@@ -131,8 +131,12 @@ def test_two_clients_of_the_resident_worker_get_the_references_bytes(tmp_path):
                 got = open(os.path.join(case, "out%d.delta" % round_), "rb").read()
                 assert got == open(os.path.join(GOLDEN, "translate_" + name, "expected.delta"), "rb").read(), name
         # a failing job comes back as the reference's SIGABRT exit, and the worker lives on
-        r = subprocess.run([EXE, "profiles-l", "no-such-dir", "nucmer.list", "bad.delta"], cwd=jobs[0][1], env=env, capture_output=True)
-        assert r.returncode == 134
+        with open(os.path.join(jobs[0][1], "junk.delta"), "w") as f:  # (m_delta.cc:72-92: Delta_stream_parse_error, uncaught upstream)
+            f.write("l/sequences.fasta r/sequences.fasta\nNUCMER\n>a b 10 10\n1 2 three 4 0 0 0\n0\n")
+        with open(os.path.join(jobs[0][1], "bad.list"), "w") as f:
+            f.write("junk.delta\n")
+        r = subprocess.run([EXE, "profiles-l", "profiles-r", "bad.list", "bad.delta"], cwd=jobs[0][1], env=env, capture_output=True)
+        assert r.returncode == 134 and b"m_translate: error" in r.stderr
         r = subprocess.run([EXE, "profiles-l", "profiles-r", "nucmer.list", "again.delta"], cwd=jobs[0][1], env=env)
         assert r.returncode == 0
         c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
