@@ -478,10 +478,14 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
     cells = info["cells"]
     cells_all = sum_over_ranks(torch, dist, cells)
     variant = batch.variant()
-    # algorithmic bytes per pass of the fill kernel: what it must write for the path (checkpoint mode: the
-    # column and row checkpoints; bits mode: 0.5 byte of decisions per cell) + the packed columns it reads (B once, A once
-    # per stripe) + the scores
-    alg_bytes = info["traceback_bytes"] + info["input_bytes"] + n * 4
+    # ALGORITHMIC bytes per pass of the fill kernel, SURVEY.md 8(d): what the path needs per USEFUL cell (checkpoint mode: a quarter
+    # of a byte -- 8 bytes per row and 64 columns, 8 per column and 64 rows; bits mode: half a byte of decisions) + the packed columns
+    # read once + the scores.  What the kernel moves by its design is more and is reported beside it (`bytes_by_design`): the
+    # checkpoints of the cells its stripes pad B's columns with, A's columns once per stripe.
+    geom = batch.geometry()
+    per_cell = 0.25 if variant.get("checkpoints") else 0.5
+    alg_bytes = int(cells * per_cell) + 8 * int(inputs.off_a[-1] + inputs.off_b[-1]) + n * 4
+    design_bytes = info["traceback_bytes"] + info["input_bytes"] + n * 4
     # int32 VALU peak: the half-rate class (v_max_i32, v_dot*, v_max3, v_alignbit...) issues at 4 cycles per wave64
     # instruction per SIMD (tools/ubench/valu_rates2.hip, profiles/r02_valu_rates2.txt) -> 16 lanes/clk x 4 SIMDs x 256 CUs x 2.4 GHz
     valu_peak = 256 * 4 * 16 * 2.4e9
@@ -515,6 +519,10 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
                      "avg_launch_ms": ms_fill_sum / launches,
                      "launch_concurrency": ms_fill_sum / ms_fill if ms_fill > 0 else 1.0,
                      "algorithmic_bytes_per_launch": alg_bytes // launches,
+                     "bytes_by_design_per_launch": design_bytes // launches,
+                     "padded_over_useful_cells": geom["padded_cells"] / cells if cells else 1.0,
+                     "narrow_last_stripes": geom["narrow_last_stripes"],
+                     "fill_launches_per_step_with_tiers": geom["fill_launches"],
                      "achieved_per_launch": (alg_bytes / launches) / (ms_fill_sum / launches * 1e-3) / 1e9,
                      "how": "achieved = the step's algorithmic bytes / the time during which a fill kernel ran (HIP events around every "
                             "launch on its stream, the union of the intervals).  With one launch per step that is bytes per launch / the "

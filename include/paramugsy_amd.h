@@ -290,6 +290,10 @@ int pm_dp_batch_chunks(pm_dp_batch_t *batch, int64_t *first_position, int32_t ca
 /* Which kernel variant the batch runs: columns of B per lane (8/16); *dot4 bit 0 = the int8 dot4 path applies, bit 1 = uniform
  * depth (every column of A holds the same number of symbols, so the gap row of the score is folded into the base weights and a
  * per-column constant); and the VALU instructions per DP cell of that variant (for roofline accounting). */
+/* What a pass computes and launches: the cells the fill kernel's stripes cover (>= the pairs' La x Lb: a stripe is 64 lanes x 16, 8
+ * or 4 columns wide whatever is left of B), whether the last stripes are the narrow ones, and the fill launches of a pass (one per
+ * workspace chunk and one per tier of long pairs).  Any pointer may be NULL. */
+int pm_dp_batch_geometry(pm_dp_batch_t *batch, int64_t *padded_cells, int32_t *narrow_last_stripes, int64_t *fill_launches);
 int pm_dp_batch_variant(pm_dp_batch_t *batch, int32_t *cols_per_lane, int32_t *dot4, int32_t *valu_ops_per_cell);
 /* How the batch gets its paths: checkpoints != 0 -> the fill kernel computes scores only and leaves row/column checkpoints,
  * and the walk re-runs the recurrence inside the block_rows x block_columns blocks the path crosses (the default);

@@ -55,7 +55,7 @@ EXPORTS = [
     "pm_rows_profile_idx_of_seq_idx_batch", "pm_rows_seq_idx_of_profile_idx_batch",
     "pm_workload_load", "pm_workload_tables", "pm_workload_row_name", "pm_workload_destroy", "pm_job_create_from_workload", "pm_job_units",
     "pm_translate_files", "pm_translate_files_as", "pm_sort_delta", "pm_maf_analyzer", "pm_profiles_make", "pm_stage_files", "pm_untranslate",
-    "pm_dp_set_default_options", "pm_dp_batch_create", "pm_dp_batch_create_opt", "pm_dp_batch_run", "pm_dp_batch_run_profiled", "pm_dp_batch_fill_busy_ms", "pm_dp_batch_fetch", "pm_dp_batch_info", "pm_dp_batch_chunks", "pm_dp_batch_variant", "pm_dp_batch_path_mode", "pm_dp_batch_destroy",
+    "pm_dp_set_default_options", "pm_dp_batch_create", "pm_dp_batch_create_opt", "pm_dp_batch_run", "pm_dp_batch_run_profiled", "pm_dp_batch_fill_busy_ms", "pm_dp_batch_fetch", "pm_dp_batch_info", "pm_dp_batch_chunks", "pm_dp_batch_variant", "pm_dp_batch_geometry", "pm_dp_batch_path_mode", "pm_dp_batch_destroy",
     "pm_dp_host_alloc", "pm_dp_host_free", "pm_dp_stream_create", "pm_dp_stream_create_opt", "pm_dp_stream_align", "pm_dp_stream_align_text", "pm_dp_stream_destroy",
     "pm_dp_pack_maf", "pm_dp_emit_maf", "pm_dp_align_maf", "pm_dp_align_blocks",
     "pm_partition", "pm_partition_weighted", "pm_delta_join_files", "pm_translate_files_multi", "pm_dp_align_multi", "pm_dp_align_blocks_multi", "pm_dp_align_maf_multi",

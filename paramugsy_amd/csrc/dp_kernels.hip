@@ -1083,18 +1083,19 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // the workspace is allocated to what the chunks need; if the device cannot give that much (other allocations beside this
   // batch) the budget is halved and the batch cut into more chunks, down to 256 MiB
   // A batch that fits is one chunk -- one fill launch, one path launch -- unless its path kernel is worth hiding: a batch of
-  // at least 4 096 pairs whose fill takes 20 ms or more and whose walk would add 8 % or more to it is cut in two chunks of about equal
-  // workspace, each with a part of its own, the path kernel of the first beside the fill kernel of the second (nothing is lost at
-  // the cut: dp_gate_kernel).  Measured on one MI355X: 12 500 pairs of 8 x 4 096 (one GPU's eighth of the headline batch) 43.9 -> 42.2 ms
+  // at least 8 192 pairs whose fill takes 20 ms or more and whose walk would add 8 % or more to it is cut in two chunks, each with a
+  // part of the workspace of its own, the path kernel of the first beside the fill kernel of the second (nothing is lost at the
+  // cut: dp_gate_kernel).  Measured on one MI355X: 12 500 pairs of 8 x 4 096 (one GPU's eighth of the headline batch) 43.9 -> 42.2 ms
   // (profiles/r04_dp_shares.txt); 25 000 pairs +0.4 %; the ragged 100 k-pair batch 109.6 -> 108.1 ms.  Not for smaller work: the path
   // kernel is real work for the same SIMDs, and launches of a few milliseconds lose more at their ends than the overlap gains (10 k
   // pairs of 2 x 1 kbp: 2.88 ms whole, 3.28 in two; more than two chunks: 12 500 pairs 44.7 ms in four).  opt.split fixes the number.
   i64 split = 1;
   bool uneven = false;
+  double first_share = 0.5;
   if(h->opt.split >= 1) {
     split = !staged ? std::min<i64>(h->opt.split, std::max<i64>(n_pairs, 1)) : 1;
   }
-  else if(h->ckpt && !staged && h->seg_first.empty() && n_pairs >= 4096) {
+  else if(h->ckpt && !staged && h->seg_first.empty() && n_pairs >= 2 * 4096) {
     double padded_cells = 0, walk_cells = 0;
     for(i64 k = 0; k < n_pairs; ++k) {
       const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
@@ -1104,17 +1105,18 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     const double fill_s = padded_cells / 5.6e12, walk_s = walk_cells / 1.2e12; // measured rates of the two kernels, each alone
     if(fill_s >= 0.020 && walk_s >= 0.08 * (fill_s + walk_s)) {
       split = 2;
-      // three quarters and a quarter, so that the path kernel left alone at the end is the short one (the first has the second chunk's
-      // fill kernel to run beside: a quarter of the fill is still twice the first chunk's walk) -- where a quarter is still a launch
-      // of one wavefront per pair (25 000 pairs of 8 x 4 096: 79.0 ms in halves, 76.7 so; 12 500: 42.2 in halves, 43.9 so -- its
-      // quarter, 3 125 pairs, is a launch of two wavefronts per pair)
-      uneven = n_pairs >= 4 * 4096;
+      // The second chunk is the smaller one -- a quarter of the workspace, but no fewer than 4 096 pairs' worth -- so that the path
+      // kernel left alone at the end is the short one; the first has the second chunk's fill kernel to run beside (a quarter of the
+      // fill is still twice the first chunk's walk).  4 096 pairs: below that a launch is one of two wavefronts per pair (25 000 pairs
+      // of 8 x 4 096: 79.0 ms in halves, 76.7 at 3 : 1; 12 500: 42.2 in halves, 43.9 at 3 : 1 -- 3 125 pairs in the second).
+      uneven = true;
+      first_share = 1.0 - std::max(0.25, 4096.0 / (double)n_pairs);
     }
   }
   bool pipelined = false;
   for(i64 budget = h->tb_budget_bytes;; budget /= 2) {
     const bool one_chunk = total_words <= budget / 4;
-    i64 budget_words = one_chunk ? (uneven ? total_words / 4 * 3 : (total_words + split - 1) / split) + 64 : budget / (4 * h->n_slots);
+    i64 budget_words = one_chunk ? (uneven ? (i64)((double)total_words * first_share) : (total_words + split - 1) / split) + 64 : budget / (4 * h->n_slots);
     h->slot_reuse = !one_chunk;
     // chunk_first: positions in `order`; chunk_tb: the word offset of every position's pair inside its chunk's workspace
     h->chunk_first.assign(1, 0);
@@ -1915,6 +1917,31 @@ int pm_dp_batch_info(pm_dp_batch_t *h, int64_t *cells, int64_t *traceback_bytes_
   }
   if(n_chunks) {
     *n_chunks = (int32_t)h->chunk_tb.size();
+  }
+  return PM_OK;
+}
+
+int pm_dp_batch_geometry(pm_dp_batch_t *h, int64_t *padded_cells, int32_t *narrow_last_stripes, int64_t *fill_launches) {
+  if(!h) {
+    return fail(PM_E_INVALID, "pm_dp_batch_geometry: null batch");
+  }
+  if(padded_cells) { // what the fill kernel computes: the columns its stripes cover x the rows of A
+    i64 cells = 0;
+    for(i64 k = 0; k < h->n_pairs; ++k) {
+      const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+      cells += la > 0 && lb > 0 ? la * dp_padded_cols(lb, h->cols_per_lane, h->tail) : 0;
+    }
+    *padded_cells = cells;
+  }
+  if(narrow_last_stripes) {
+    *narrow_last_stripes = h->tail ? 1 : 0;
+  }
+  if(fill_launches) { // per pass: one per chunk and one per tier of a chunk
+    i64 n = 0;
+    for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
+      n += 1 + (c < h->chunk_tiers.size() ? (i64)h->chunk_tiers[c].size() : 0);
+    }
+    *fill_launches = n;
   }
   return PM_OK;
 }

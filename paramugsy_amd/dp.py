@@ -125,6 +125,7 @@ def _lib():
         l.pm_dp_batch_fill_busy_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.pm_dp_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.pm_dp_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        l.pm_dp_batch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         l.pm_dp_batch_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.pm_dp_batch_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         l.pm_dp_batch_path_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -214,6 +215,12 @@ class DpBatch:
         order = np.zeros(len(self._oa) - 1, dtype=np.int32)
         capi.check(_lib().pm_dp_batch_chunks(self._h, first.ctypes.data, n + 1, order.ctypes.data))
         return first, order
+
+    def geometry(self):
+        """{"padded_cells": the cells the fill kernel's stripes cover, "narrow_last_stripes": bool, "fill_launches": per pass}."""
+        c, t, n = C.c_int64(), C.c_int32(), C.c_int64()
+        capi.check(_lib().pm_dp_batch_geometry(self._h, C.byref(c), C.byref(t), C.byref(n)))
+        return {"padded_cells": c.value, "narrow_last_stripes": bool(t.value), "fill_launches": n.value}
 
     def variant(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()

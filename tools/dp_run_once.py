@@ -9,7 +9,8 @@ n, rows, L = (int(x) for x in sys.argv[1].split(":"))
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 inputs = dp.synth_pairs_fast(20261003, n, rows, L) if n * L <= 20000000 else dp.synth_batch(20261003, [L] * n, [L] * n, rows, rows)
 b = dp.DpBatch(inputs, dp.make_params(rows, rows))
+paths = os.environ.get("RUN_ONCE_SCORES_ONLY") != "1"  # RUN_ONCE_SCORES_ONLY=1: passes without the path (no checkpoints written)
 for _ in range(reps):
-    b.run(True)
+    b.run(paths)
 b.fetch()
 b.close()
