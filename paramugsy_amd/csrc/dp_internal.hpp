@@ -56,6 +56,8 @@ struct DpStripe {
   int jb; // first column of B (0-based)
   int cs; // columns per lane
 };
+// (cs is 16, 8 or 4: shifts, not the division a variable divisor compiles to)
+__host__ __device__ inline int dp_cs_shift(int cs) { return cs == 16 ? 4 : (cs == 8 ? 3 : 2); }
 __host__ __device__ inline int dp_tail_quarters(i64 lb, int C, int tail) { // quarters of a full stripe the remainder needs; 0: none
   const i64 rem = lb % (64 * C);
   return !tail || C != 16 || rem == 0 ? 0 : (int)((rem + 16 * C - 1) / (16 * C));
@@ -126,12 +128,12 @@ __host__ __device__ inline i64 dp_ck_col_word(i64 la, i64 g, i64 t) { return (g 
 // its own, 8 bytes at a time -- HBM bytes are the same, L2 write requests four times as many, and those are what the fill kernel
 // runs short of (round 4: 2 048 -> 320 requests per wavefront and 64 steps, with the column checkpoints' staging below)
 __host__ __device__ inline i64 dp_ck_row_word(i64 la, i64 lb, int C, int tail, DpStripe st, i64 m, i64 j) {
-  const int r = (int)(j - st.jb), sh = st.cs == 16 ? 4 : (st.cs == 8 ? 3 : 2);
+  const int r = (int)(j - st.jb), sh = dp_cs_shift(st.cs);
   return dp_ck_groups(lb, C, tail) * dp_ck_steps(la) * 2 + ((i64)st.jb * dp_ck_nck(la) + m * 64 * st.cs + (r & (st.cs - 1)) * 64 + (r >> sh)) * 2;
 }
 // the first fill lane of column group g (in the stripe it lies in), and the lanes of a group there
-__host__ __device__ inline int dp_group_lane0(int C, DpStripe st, i64 g) { return (int)((g * DP_CK_W * C - st.jb) / st.cs); }
-__host__ __device__ inline int dp_group_lanes(int C, DpStripe st) { return DP_CK_W * C / st.cs; }
+__host__ __device__ inline int dp_group_lane0(int C, DpStripe st, i64 g) { return ((int)g * DP_CK_W * C - st.jb) >> dp_cs_shift(st.cs); }
+__host__ __device__ inline int dp_group_lanes(int C, DpStripe st) { return (DP_CK_W * C) >> dp_cs_shift(st.cs); }
 // bytes the fill kernel writes for one pair in checkpoint mode (rows of A it is on, not steps)
 __host__ __device__ inline i64 dp_ck_bytes_written(i64 la, i64 lb, int C, int tail) {
   return (dp_ck_groups(lb, C, tail) * la * 2 + dp_ck_nck(la) * dp_padded_cols(lb, C, tail) * 2) * 4;

@@ -925,11 +925,16 @@ int dp_batch_plan(pm_dp_batch *h, hipStream_t stream) {
   return dp_batch_plan_with(h, h->pinned ? (const int *)((char *)h->pinned + h->pinned_bytes - 32) : h->host_stats, stream);
 }
 
-// lanes per pair of the checkpoint walk for a launch of n pairs: as few as still give the launch about two wavefronts per SIMD
-// (1 024 SIMDs) -- but at least as many as leave a lane four columns of a block: with eight columns per lane a block's decisions
-// are 4-byte words, the workgroup's LDS 24 KB, and a CU holds six wavefronts of a kernel that lives on hiding latency (the ragged
-// 100 k-pair batch's walk, alone on the chip: 18.8 ms with 8 lanes per pair, 15.0 with 16; the headline batch 329 -> 312 ms per step)
-static int dp_walk_lanes_for(const pm_dp_batch *h, i64 n) {
+// lanes per pair of the checkpoint walk for the launch of the n pairs at positions [first, first + n): as few as still give the launch
+// about two wavefronts per SIMD (1 024 SIMDs) -- but at least as many as leave a lane four columns of a block: with eight columns
+// per lane a block's decisions are 4-byte words, the workgroup's LDS 24 KB, and a CU holds six wavefronts of a kernel that lives on
+// hiding latency (the ragged 100 k-pair batch's walk, alone on the chip: 18.8 ms with 8 lanes per pair, 15.0 with 16).  And 32 lanes
+// (two columns a lane: 6 KB of LDS and 96 VGPRs, five wavefronts per SIMD where 16 lanes leave three) for LONG pairs: their walk is
+// a chain of a hundred blocks and more, bound by latency, and more resident wavefronts hide it, although a block then costs 1.46 x
+// the instructions (95 steps of 2 cells against 79 of 4).  Measured (profiles/r04_walk_lanes.txt; 8 / 16 / 32 lanes): 12 500 pairs of
+// 8 x 4 096 44.5 / 42.3 / 41.4 ms a step; the ragged eighth 19.8 / 15.0 / 14.5; 10 000 pairs of 2 x 1 000, whose walk is a third of the
+// step and bound by issue, 3.40 / 3.13 / 3.23: 32 lanes from a mean La + Lb of 3 000 columns on.
+static int dp_walk_lanes_rule(const pm_dp_batch *h, i64 n, double mean_columns) { // mean_columns: La + Lb averaged over the launch's pairs
   int lpp = h->walk_lanes;
   if(lpp == 0) {
     lpp = 2;
@@ -939,11 +944,19 @@ static int dp_walk_lanes_for(const pm_dp_batch *h, i64 n) {
     while(lpp < 32 && h->cols_per_lane * DP_CK_W / lpp > 4 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2)) {
       lpp *= 2;
     }
-    while(lpp < 32 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && n * lpp <= 2 * 1024 * 64) {
+    while(lpp < 32 && dp_walk_lanes_ok(h->cols_per_lane, lpp * 2) && (n * lpp <= 2 * 1024 * 64 || mean_columns >= 3000.0)) {
       lpp *= 2;
     }
   }
   return lpp;
+}
+static int dp_walk_lanes_for(const pm_dp_batch *h, i64 first, i64 n) { // positions [first, first + n) of the processing order
+  double columns = 0;
+  for(i64 q = first; q < first + n; ++q) {
+    const i64 k = h->order[(size_t)q];
+    columns += (double)(h->off_a[k + 1] - h->off_a[k] + h->off_b[k + 1] - h->off_b[k]);
+  }
+  return dp_walk_lanes_rule(h, n, n > 0 ? columns / (double)n : 0.0);
 }
 
 int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
@@ -1046,7 +1059,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     }
     const double fill_saved_s = std::max(cells * (1.0 / 2.3e12 - 1.0 / 5.2e12), 0.55 * lone_fill_s);
     // a block of the chain: ~15 us recomputed; ~4 us read back from the band, whose kernel costs a launch more (~30 us)
-    const bool band_likely = !staged && band_env != 0 && (band_env > 0 || band_pays(n_pairs, dp_walk_lanes_for(h, n_pairs)));
+    const bool band_likely = !staged && band_env != 0 && (band_env > 0 || band_pays(n_pairs, dp_walk_lanes_rule(h, n_pairs, n_pairs > 0 ? (double)(h->total_a + h->total_b) / (double)n_pairs : 0.0)));
     h->ckpt = fill_saved_s > (band_likely ? 30e-6 + chain_blocks * 4e-6 : chain_blocks * 15e-6);
   }
   // the narrow last stripes (dp_internal.hpp): wherever the path comes from checkpoints and a lane has 16 columns
@@ -1285,7 +1298,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     // slice from pinned staging (dp_stream.hip): its tables would have to follow every slice.
     h->band_work_items = 0;
     if(h->ckpt && !staged && h->chunk_tb.size() == 1 && n_pairs > 0 && band_env != 0) {
-      const int lpp = dp_walk_lanes_for(h, n_pairs);
+      const int lpp = dp_walk_lanes_for(h, 0, n_pairs);
       const i64 bw = (i64)h->cols_per_lane * DP_CK_W;
       const i64 block_bytes = dp_band_block_bytes(h->cols_per_lane, lpp);
       i64 items = 0;
@@ -1561,7 +1574,7 @@ static int dp_launch_path(pm_dp_batch *h, i64 first, i64 n, const unsigned *tbw,
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
   if(h->ckpt) {
-    const int lpp = dp_walk_lanes_for(h, n);
+    const int lpp = dp_walk_lanes_for(h, first, n);
     DpBand band = {nullptr, 0, nullptr, nullptr};
     if(h->band_work_items > 0 && h->band_lanes == lpp) {
       band.work = (const int *)h->d_band_work.p;

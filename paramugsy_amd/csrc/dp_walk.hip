@@ -47,7 +47,7 @@ template <bool DOT4> struct RowWord { typedef int4 type; };
 template <> struct RowWord<true> { typedef int2 type; };
 
 template <int C, int LPP, bool DOT4>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C == 16 && LPP == 16 && DOT4 ? 4 : 1)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C == 16 && LPP == 32 ? 5 : (C == 16 && LPP == 16 && DOT4 ? 4 : 1))))
 dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b, const i64 *__restrict__ off_b,
                const int *__restrict__ order, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
                int *__restrict__ n_ops, DpParamsD P, DpBand band, int band_mode, int tail, int urgent) {
@@ -211,7 +211,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       }
       // the lane left of the group: the last lane of the group to the left, in the stripe that group lies in
       const DpStripe stl = dp_stripe_of_col(lb, C, tail, gg > 0 ? (i64)gg * BW - 1 : 0);
-      const int ll = gg > 0 ? (gg * BW - 1 - stl.jb) / stl.cs : 0;
+      const int ll = gg > 0 ? (gg * BW - 1 - stl.jb) >> dp_cs_shift(stl.cs) : 0;
       for(int rr = q; rr <= nrows; rr += LPP) {
         const int row = i0 - 1 + rr; // row of A; -1 is the DP's row 0
         int2 v;
