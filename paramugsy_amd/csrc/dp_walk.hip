@@ -66,9 +66,12 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   constexpr int G = 64 / LPP;     // pairs per wavefront
   static_assert(C2 >= 1 && C2 <= 8 && C % C2 == 0 && C2 * LPP == BW, "a lane's columns lie in one lane of the fill kernel");
   typedef typename BitsWord<C2>::type bits_t;
-  typedef typename RowWord<DOT4>::type arow_t;
-  __shared__ arow_t sh_a[G][R]; // A's rows of the block, expanded as the cell reads them (the int8 path reads 8 bytes of the 16)
-  __shared__ int2 sh_left[G][R + 1];
+  // per group: A's rows of the block, expanded as the cell reads them (the int8 path reads 8 bytes of the 16), then the block's left
+  // edge row by row -- one array, so that a step's two reads share an address register (the left edge at a constant distance); the
+  // left edge of the row ABOVE the block apart
+  constexpr int AW = DOT4 ? 1 : 2; // int2 per row of A
+  __shared__ int2 sh_al[G][(AW + 1) * R];
+  __shared__ int2 sh_top[G];
   __shared__ bits_t sh_bits[G][R][LPP];
   const int grp = threadIdx.x / LPP, q = threadIdx.x % LPP;
   constexpr int BLOCK_WORDS = R * LPP * (int)sizeof(bits_t) / 4;
@@ -203,10 +206,10 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       for(int r = q; r < nrows; r += LPP) {
         const int4 v = dp_expand_row<DOT4>(A[i0 + r]);
         if constexpr(DOT4) {
-          sh_a[grp][r] = make_int2(v.x, v.y);
+          sh_al[grp][r] = make_int2(v.x, v.y);
         }
         else {
-          sh_a[grp][r] = v;
+          *reinterpret_cast<int4 *>(&sh_al[grp][2 * r]) = v;
         }
       }
       // the lane left of the group: the last lane of the group to the left, in the stripe that group lies in
@@ -224,19 +227,23 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         else {
           v = *reinterpret_cast<const int2 *>(ckp + dp_ck_col_word(la, gg - 1, (i64)row + ll));
         }
-        sh_left[grp][rr] = v;
+        if(rr == 0) {
+          sh_top[grp] = v;
+        }
+        else {
+          sh_al[grp][AW * R + rr - 1] = v;
+        }
       }
     }
     __syncthreads();
     // ---- the block's cells, anti-diagonal over the group's lanes: at step u lane q is on row r = u - q of the block
     int e = DP_NEG_INF;
-    const arow_t *arow = &sh_a[grp][0];
-    const int2 *lrow = &sh_left[grp][1]; // [x]: the left edge of block row x; [-1]: of the row above the block
     bits_t *brow = &sh_bits[grp][0][q];
     // H~ - gop above-left of the lane's first column
-    int diag_in = LPP == 16 ? from_left_in_row(lrow[-1].x, hop[C2 - 1]) : from_left_lane(hop[C2 - 1]);
+    const int2 top = sh_top[grp];
+    int diag_in = LPP == 16 ? from_left_in_row(top.x, hop[C2 - 1]) : from_left_lane(hop[C2 - 1]);
     if(LPP != 16 && q == 0) {
-      diag_in = lrow[-1].x;
+      diag_in = top.x;
     }
     // steps of this block: the longest of the wavefront's groups (rows it recomputes + its lanes' skew), a scalar
     int trip = 0;
@@ -246,29 +253,28 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
       for(int g = 0; g < G; ++g) {
         trip = max(trip, __builtin_amdgcn_readlane(need, g * LPP));
       }
+      trip = __builtin_amdgcn_readfirstlane(trip); // (the loop counter on the scalar unit)
     }
     const unsigned rows_mine = mine ? (unsigned)nrows : 0u; // (unsigned)r < rows_mine: this lane is on one of its rows
     // A's row and the left edge are read one step ahead, so that the reads' latency is not on the step's path; the row index
     // wraps instead of being clamped or predicated (a row that is read and not used costs nothing), and every lane reads the
-    // left edge although only the group's first uses it (no exec juggling)
+    // left edge although only the group's first uses it (no exec juggling).  Two steps per iteration (an odd trip count runs one step
+    // more: no lane is on a row in it), so that "this step's" and "next step's" registers swap roles instead of being copied.
     int r = -q;
-    int4 a_nx = make_int4(0, 0, 0, 0);
-    int2 l_nx;
-    {
-      const int slot = r & (R - 1);
+    const char *const rows = reinterpret_cast<const char *>(&sh_al[grp][0]);
+    unsigned off = (unsigned)(r & (R - 1)) * 8u; // byte offset of the lane's row among the block's R
+    auto fetch = [&](int4 &a_to, int2 &l_to) __attribute__((always_inline)) {
       if constexpr(DOT4) {
-        const int2 t2 = arow[slot];
-        a_nx.x = t2.x;
-        a_nx.y = t2.y;
+        const int2 t2 = *reinterpret_cast<const int2 *>(rows + off);
+        a_to.x = t2.x;
+        a_to.y = t2.y;
       }
       else {
-        a_nx = arow[slot];
+        a_to = *reinterpret_cast<const int4 *>(rows + 2 * off);
       }
-      l_nx = lrow[slot];
-    }
-    for(int u = 0; u < trip; ++u, ++r) {
-      const int4 a = a_nx;
-      const int2 lb_ = l_nx;
+      l_to = *reinterpret_cast<const int2 *>(rows + AW * R * 8 + off);
+    };
+    auto step = [&](const int4 &a, const int2 &lb_, int4 &a_to, int2 &l_to) __attribute__((always_inline)) {
       int ho_in, e_in;
       if(LPP == 16) { // a DPP row is a group: its first lane keeps the `old` operand, the left edge
         ho_in = from_left_in_row(lb_.x, hop[C2 - 1]);
@@ -282,18 +288,8 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           e_in = lb_.y;
         }
       }
-      {
-        const int slot = (r + 1) & (R - 1);
-        if constexpr(DOT4) {
-          const int2 t2 = arow[slot];
-          a_nx.x = t2.x;
-          a_nx.y = t2.y;
-        }
-        else {
-          a_nx = arow[slot];
-        }
-        l_nx = lrow[slot];
-      }
+      off = (off + 8u) & (unsigned)(R * 8 - 1);
+      fetch(a_to, l_to);
       if((unsigned)r < rows_mine) {
         const int ax = a.x, ay = a.y, az = DOT4 ? 0 : a.z;
         unsigned acc;
@@ -316,6 +312,14 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         diag_in = ho_in;
         brow[r * LPP] = (bits_t)acc;
       }
+      ++r;
+    };
+    int4 row_a = make_int4(0, 0, 0, 0), row_b = make_int4(0, 0, 0, 0);
+    int2 left_a, left_b;
+    fetch(row_a, left_a);
+    for(int u = 0; u < trip; u += 2) {
+      step(row_a, left_a, row_b, left_b);
+      step(row_b, left_b, row_a, left_a);
     }
     __syncthreads();
     if(band_mode == 1) {
