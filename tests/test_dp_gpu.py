@@ -464,3 +464,55 @@ def test_random_shapes_random_scoring(seed, oracle_build, monkeypatch):
     p.gap_open = int(rng.integers(0, 40)) * rows
     p.gap_extend = int(rng.integers(0, 6)) * rows
     run_and_compare(inputs, p)
+
+
+def test_options_at_creation_and_as_process_defaults_and_the_geometry_of_a_pass(oracle_build):
+    """pm_dp_options_t given to pm_dp_batch_create_opt, and the process's defaults (pm_dp_set_default_options) for batches created
+    without options; pm_dp_batch_geometry: the cells the stripes cover, narrow last stripes on or off, the fill launches of a pass.
+    Every variant gives the oracle's scores and paths."""
+    import ctypes as C
+    import pyoracle
+    from paramugsy_amd import capi
+    la = [700, 1300, 90, 2100, 1024, 300]
+    lb = [650, 1290, 100, 2300, 1025, 257]
+    inputs = dp.synth_batch(5, la, lb, 3, 3)
+    params = dp.make_params(3, 3)
+    o_scores, o_paths = pyoracle.dp_align(inputs, params)
+    cells = inputs.cells
+
+    def check(batch):
+        batch.run(True)
+        scores, ops, n_ops = batch.fetch()
+        assert np.array_equal(scores, o_scores)
+        assert all(np.array_equal(p, q) for p, q in zip(batch.paths(ops, n_ops), o_paths))
+    narrow = dp.DpBatch(inputs, params, options=dp.options(path_mode=2, cols_per_lane=16))
+    full = dp.DpBatch(inputs, params, options=dp.options(path_mode=2, cols_per_lane=16, full_stripes=1))
+    g_n, g_f = narrow.geometry(), full.geometry()
+    assert g_n["narrow_last_stripes"] and not g_f["narrow_last_stripes"] and g_n["fill_launches"] == g_f["fill_launches"] == 1
+    padded = lambda w: sum(a * ((b + w - 1) // w) * w for a, b in zip(la, lb))  # noqa: E731
+    assert g_f["padded_cells"] == padded(1024) and cells <= g_n["padded_cells"] <= padded(256) < g_f["padded_cells"]
+    check(narrow)
+    check(full)
+    narrow.close()
+    full.close()
+    with pytest.raises(capi.PmError):
+        dp.DpBatch(inputs, params, options=dp.options(cols_per_lane=12))
+    # the defaults of batches created without options: stored bits, then everything chosen again
+    lib = capi.lib()
+    ca, cb = np.ascontiguousarray(inputs.cols_a), np.ascontiguousarray(inputs.cols_b)
+    oa, ob = np.ascontiguousarray(inputs.off_a, dtype=np.int64), np.ascontiguousarray(inputs.off_b, dtype=np.int64)
+
+    def plain_create():
+        h = C.c_void_p()
+        capi.check(lib.pm_dp_batch_create(ca.ctypes.data, oa.ctypes.data, cb.ctypes.data, ob.ctypes.data, len(la), C.byref(params), 0, 0, C.byref(h)))
+        ck = C.c_int32()
+        capi.check(lib.pm_dp_batch_path_mode(h, C.byref(ck), None, None))
+        lib.pm_dp_batch_destroy(h)
+        return bool(ck.value)
+    try:
+        dp.set_default_options(dp.options(path_mode=2))
+        assert plain_create() is True
+        dp.set_default_options(dp.options(path_mode=1))
+        assert plain_create() is False
+    finally:
+        dp.set_default_options(None)
