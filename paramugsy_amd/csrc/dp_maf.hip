@@ -637,9 +637,10 @@ static int parse_two_mafs(const char *maf_a, const char *maf_b, MafDpBlocks &A, 
   return PM_OK;
 }
 
-// DP batches kept from call to call, per device (their workspace and buffers only grow: dp_batch.hpp): a resident caller's next
-// file finds gigabytes of path workspace allocated -- allocating and freeing it costs more than the kernels that use it.  A batch
-// whose workspace has grown past 24 GiB is not kept.
+// DP batches kept from call to call, at most two per device (their workspace and buffers only grow: dp_batch.hpp): a resident caller's
+// next file finds gigabytes of path workspace allocated -- allocating and freeing it costs more than the kernels that use it.  A batch
+// whose workspace has grown past 24 GiB is not kept; and whatever is kept is given back when a device allocation fails
+// (malloc_trimming, pm_internal.hpp).
 static std::mutex g_batch_lock;
 static std::vector<std::unique_ptr<pm_dp_batch> > g_batch_cache;
 static std::unique_ptr<pm_dp_batch> batch_acquire(int device) {
@@ -679,7 +680,11 @@ static void batch_release(std::unique_ptr<pm_dp_batch> b) {
   }
   if(b->tb.bytes <= ((size_t)24 << 30)) {
     std::lock_guard<std::mutex> hold(g_batch_lock);
-    if(g_batch_cache.size() < 8) {
+    size_t same_device = 0; // at most two kept batches per device (two workers may share one: the device list {0, 0})
+    for(size_t k = 0; k < g_batch_cache.size(); ++k) {
+      same_device += g_batch_cache[k]->device == b->device;
+    }
+    if(same_device < 2) {
       g_batch_cache.push_back(std::move(b));
       return;
     }
