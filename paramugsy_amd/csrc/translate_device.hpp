@@ -297,21 +297,97 @@ PM_HD inline int subset_seq(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I> &s
   return PM_ST_OK;
 }
 
+// Four binary searches in lock step.  A unit's set-up is some twenty searches of four to twelve probes each, every probe a
+// memory round trip the next one waits for; the searches of one stage do not depend on each other, so they probe together and a
+// stage costs the round trips of its deepest search (the count pass 128 -> 116 us on the bench job, profiles/r04_translate_ablation.txt).
+// KIND 0: g[k].s - pre[k] <= key (profile_idx_of_seq_idx's lower bound); 1: g[k].e < key (the first gap that ends at or after
+// key); 2: g[k].s <= key (the first gap that starts after key).  A probe with lo == hi is idle.
+template <typename I>
+struct LbProbe {
+  const R2T<I> *g;
+  const I *pre;
+  int lo, hi;
+  I key;
+};
+template <int KIND, typename I>
+PM_HD __forceinline__ bool lb_pred(const R2T<I> &g, I pre, I key) {
+  return KIND == 0 ? g.s - pre <= key : (KIND == 1 ? g.e < key : g.s <= key);
+}
+template <typename I>
+PM_HD __forceinline__ LbProbe<I> lb_probe(const PVT<I> &p, bool on, I key) {
+  return LbProbe<I>{p.g, p.pre, 0, on ? p.n : 0, key};
+}
+template <int K0, int K1, int K2, int K3, typename I>
+PM_HD __forceinline__ void lower_bounds4(LbProbe<I> &a, LbProbe<I> &b, LbProbe<I> &c, LbProbe<I> &d) {
+  while((a.lo < a.hi) | (b.lo < b.hi) | (c.lo < c.hi) | (d.lo < d.hi)) {
+    const bool oa = a.lo < a.hi, ob = b.lo < b.hi, oc = c.lo < c.hi, od = d.lo < d.hi;
+    const int ma = (a.lo + a.hi) >> 1, mb = (b.lo + b.hi) >> 1, mc = (c.lo + c.hi) >> 1, md = (d.lo + d.hi) >> 1;
+    R2T<I> ga{0, 0}, gb{0, 0}, gc{0, 0}, gd{0, 0};
+    I pa = 0, pb = 0, pc = 0, pd = 0;
+    if(oa) {
+      ga = a.g[ma];
+      if(K0 == 0) pa = a.pre[ma];
+    }
+    if(ob) {
+      gb = b.g[mb];
+      if(K1 == 0) pb = b.pre[mb];
+    }
+    if(oc) {
+      gc = c.g[mc];
+      if(K2 == 0) pc = c.pre[mc];
+    }
+    if(od) {
+      gd = d.g[md];
+      if(K3 == 0) pd = d.pre[md];
+    }
+    if(oa) {
+      if(lb_pred<K0>(ga, pa, a.key)) a.lo = ma + 1; else a.hi = ma;
+    }
+    if(ob) {
+      if(lb_pred<K1>(gb, pb, b.key)) b.lo = mb + 1; else b.hi = mb;
+    }
+    if(oc) {
+      if(lb_pred<K2>(gc, pc, c.key)) c.lo = mc + 1; else c.hi = mc;
+    }
+    if(od) {
+      if(lb_pred<K3>(gd, pd, d.key)) d.lo = md + 1; else d.hi = md;
+    }
+  }
+}
+// profile_idx_of_seq_idx's range test and offset (m_profile.cc:93-99): false = PM_ST_SEQ_IDX_OUT_OF_RANGE
+template <typename I>
+PM_HD __forceinline__ bool seq_idx_offset(const PVT<I> &p, I si, I &offset) {
+  const R2T<I> f = fwd_of(p.range);
+  const I d = p.range.s - si;
+  offset = (d < 0 ? -d : d) + 1;
+  return f.s <= si && si <= f.e;
+}
+
 // a11, m_translate.cc:24-139: two gap lists, one push-back slot each.  Row 0 = reference, 1 = query.
 // Kept as scalars (no runtime-indexed arrays: those would go to scratch).
+// The element a list stands at is held in registers (cur) and read again only when the list moves on: the merge decides every
+// step from the four fronts, and read from memory at the start of every step they were four or five scattered loads a step -- a
+// lane's addresses share no line with its neighbours', so what a unit pass costs is the number of such loads, not their latency
+// (profiles/r04_translate_ablation.txt: also holding the element after it, to take the read off the step's path, bought nothing).
 template <typename I>
 struct PairCursorT {
   GapViewT<I> v0, v1;
   int at0, at1;
   bool held0, held1;
   R2T<I> hold0, hold1;
+  R2T<I> cur0, cur1; // view_get(v, at); anything past the list's end
 
+  PM_HD __forceinline__ void prime() { // after the views and at0/at1 are set
+    const R2T<I> z{0, 0};
+    cur0 = at0 < v0.n ? view_get(v0, at0) : z;
+    cur1 = at1 < v1.n ? view_get(v1, at1) : z;
+  }
   PM_HD __forceinline__ bool has(int r) const { return r ? (held1 || at1 < v1.n) : (held0 || at0 < v0.n); }
   PM_HD __forceinline__ R2T<I> front(int r) const {
     if(r) {
-      return held1 ? hold1 : view_get(v1, at1);
+      return held1 ? hold1 : cur1;
     }
-    return held0 ? hold0 : view_get(v0, at0);
+    return held0 ? hold0 : cur0;
   }
   PM_HD __forceinline__ bool done() const { return !has(0) && !has(1); }
   PM_HD __forceinline__ void pop(int r) {
@@ -321,6 +397,9 @@ struct PairCursorT {
       }
       else {
         ++at1;
+        if(at1 < v1.n) {
+          cur1 = view_get(v1, at1);
+        }
       }
     }
     else {
@@ -329,6 +408,9 @@ struct PairCursorT {
       }
       else {
         ++at0;
+        if(at0 < v0.n) {
+          cur0 = view_get(v0, at0);
+        }
       }
     }
   }
@@ -774,12 +856,16 @@ PM_HD inline int unit_prefix(const RowsT<I> &left, const RowsT<I> &right, const 
   dq.pre = ds.qry_pre[o] + qo + d;
   dq.len = rlen(de_qry) + dq.pre[dq.n];
 
-  int st;
-  R2T<I> d_ref_cols, d_query_cols;
-  if((st = profile_idx_of_seq_idx(dr, ref_seq.s, d_ref_cols.s))) return st; // :508-511
-  if((st = profile_idx_of_seq_idx(dr, ref_seq.e, d_ref_cols.e))) return st;
-  if((st = profile_idx_of_seq_idx(dq, query_seq.s, d_query_cols.s))) return st;
-  if((st = profile_idx_of_seq_idx(dq, query_seq.e, d_query_cols.e))) return st;
+  // :508-511: four profile_idx_of_seq_idx; their range tests in the reference's order, their searches together
+  I o0, o1, o2, o3;
+  if(!seq_idx_offset(dr, ref_seq.s, o0) || !seq_idx_offset(dr, ref_seq.e, o1) || !seq_idx_offset(dq, query_seq.s, o2) ||
+     !seq_idx_offset(dq, query_seq.e, o3)) {
+    return PM_ST_SEQ_IDX_OUT_OF_RANGE;
+  }
+  LbProbe<I> a = lb_probe(dr, true, o0), b = lb_probe(dr, true, o1), c = lb_probe(dq, true, o2), e = lb_probe(dq, true, o3);
+  lower_bounds4<0, 0, 0, 0>(a, b, c, e);
+  const I p0 = dr.pre[a.lo], p1 = dr.pre[b.lo], p2 = dq.pre[c.lo], p3 = dq.pre[e.lo];
+  const R2T<I> d_ref_cols{p0 + o0, p1 + o1}, d_query_cols{p2 + o2, p3 + o3};
   live = overlap(d_ref_cols, d_query_cols, cols); // :513
   return PM_ST_OK;
 }
@@ -800,16 +886,176 @@ typedef UnitStateT<i64> UnitState;
 template <bool EMIT, typename I>
 PM_HD inline int unit_setup(const PVT<I> &lp, const PVT<I> &rp, const PVT<I> &dr, const PVT<I> &dq, R2T<I> cols, Merge<EMIT, I> &m, bool &proceed) {
   proceed = false;
-  int st;
-  R2T<I> d_ref_seq, d_query_seq, l_seq, r_seq;
-  bool none_r, none_q;
-  if((st = subset_profile(dr, cols.s, cols.e, m.delta.v0, d_ref_seq, none_r))) return st;   // :527-529
-  if((st = subset_profile(dq, cols.s, cols.e, m.delta.v1, d_query_seq, none_q))) return st; // :531-533
-  if(none_r || none_q) {
+  // ---- :527-533: subset_profile (m_profile.cc:160-206) of the entry's two rows, side 0 = reference row, 1 = query row, stage by
+  // stage for both at once.  Every stage is pure, so a side's status is found whatever the other side's is; the reference's (the
+  // first side's first failure) is picked at the end.
+  const PVT<I> *pv[2] = {&dr, &dq};
+  GapViewT<I> *vv[2] = {&m.delta.v0, &m.delta.v1};
+  int st_side[2] = {PM_ST_OK, PM_ST_OK};
+  bool none_side[2] = {false, false}, on[2];
+  I ws[2], we[2];
+#pragma unroll
+  for(int k = 0; k < 2; ++k) {
+    I s = cols.s, e = cols.e;
+    on[k] = !(s <= 0 || pv[k]->len < s || e <= 0 || pv[k]->len < e);
+    if(!on[k]) {
+      st_side[k] = PM_ST_PROFILE_IDX_OUT_OF_RANGE;
+    }
+    ws[k] = s <= e ? s : e;
+    we[k] = s <= e ? e : s;
+  }
+  {
+    // the kept gaps: from the first that ends at or after s to the first that starts after e (searched from the list's start:
+    // every gap before the first kept one starts before s <= e)
+    LbProbe<I> a = lb_probe(dr, on[0], ws[0]), b = lb_probe(dr, on[0], we[0]), c = lb_probe(dq, on[1], ws[1]), d = lb_probe(dq, on[1], we[1]);
+    lower_bounds4<1, 2, 1, 2>(a, b, c, d);
+    const int first[2] = {a.lo, c.lo}, last[2] = {b.lo, d.lo};
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+      vv[k]->g = pv[k]->g;
+      vv[k]->lo = first[k];
+      vv[k]->n = last[k] - first[k];
+      vv[k]->ws = ws[k];
+      vv[k]->we = we[k];
+      vv[k]->mirror = false;
+      vv[k]->L = 0;
+    }
+  }
+  // a kept gap that reaches an end of the window is cut off it (:182-193); the one gap that is the window: the empty option
+  I cs[2] = {ws[0], ws[1]}, ce[2] = {we[0], we[1]};
+  {
+    R2T<I> ga[2] = {{0, 0}, {0, 0}}, gb[2] = {{0, 0}, {0, 0}};
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+      if(on[k] && vv[k]->n > 0) {
+        ga[k] = view_get(*vv[k], 0);
+        gb[k] = view_get(*vv[k], vv[k]->n - 1);
+      }
+    }
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+      if(on[k] && vv[k]->n > 0) {
+        if(vv[k]->n == 1 && ga[k].s == ws[k] && ga[k].e == we[k]) {
+          none_side[k] = true;
+          on[k] = false;
+        }
+        else {
+          if(ga[k].s == ws[k]) {
+            cs[k] = ga[k].e + 1;
+          }
+          if(gb[k].e == we[k]) {
+            ce[k] = gb[k].s - 1;
+          }
+        }
+      }
+    }
+  }
+  // the sequence positions of the window's ends: seq_idx_of_profile_idx (m_profile.cc:114-149) of both, both sides
+  R2T<I> seq_side[2] = {{0, 0}, {0, 0}};
+  {
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+      if(on[k] && (!(cs[k] < pv[k]->len + 1) || !(ce[k] < pv[k]->len + 1))) {
+        st_side[k] = PM_ST_PROFILE_IDX_OUT_OF_RANGE;
+        on[k] = false;
+      }
+    }
+    LbProbe<I> a = lb_probe(dr, on[0], cs[0]), b = lb_probe(dr, on[0], ce[0]), c = lb_probe(dq, on[1], cs[1]), d = lb_probe(dq, on[1], ce[1]);
+    lower_bounds4<1, 1, 1, 1>(a, b, c, d);
+    const int at[2][2] = {{a.lo, b.lo}, {c.lo, d.lo}};
+    I gs[2][2], pr[2][2];
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+#pragma unroll
+      for(int w = 0; w < 2; ++w) {
+        gs[k][w] = 0;
+        pr[k][w] = 0;
+        if(on[k]) {
+          pr[k][w] = pv[k]->pre[at[k][w]];
+          if(at[k][w] < pv[k]->n) {
+            gs[k][w] = pv[k]->g[at[k][w]].s;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+      if(on[k]) {
+        const I pi[2] = {cs[k], ce[k]};
+        I out[2];
+        bool none = false;
+#pragma unroll
+        for(int w = 0; w < 2; ++w) {
+          none = none || (at[k][w] < pv[k]->n && gs[k][w] <= pi[w]);
+          const I offset = pi[w] - pr[k][w] - 1;
+          out[w] = fwd(pv[k]->range) ? pv[k]->range.s + offset : pv[k]->range.s - offset;
+        }
+        if(none) {
+          st_side[k] = PM_ST_IS_NONE;
+        }
+        seq_side[k] = R2T<I>{out[0], out[1]};
+      }
+    }
+  }
+  if(st_side[0]) return st_side[0]; // :527-529
+  if(st_side[1]) return st_side[1]; // :531-533
+  if(none_side[0] || none_side[1]) {
     return PM_ST_OK; // :535
   }
-  if((st = subset_seq(lp, d_ref_seq.s, d_ref_seq.e, m.rows.v0, l_seq))) return st;     // :539-541
-  if((st = subset_seq(rp, d_query_seq.s, d_query_seq.e, m.rows.v1, r_seq))) return st; // :543-545
+  const R2T<I> d_ref_seq = seq_side[0], d_query_seq = seq_side[1];
+  // ---- :539-545: subset_seq of the two row profiles (see subset_seq above for why two conversions each are all of it)
+  R2T<I> l_seq, r_seq;
+  {
+    const PVT<I> *rv[2] = {&lp, &rp};
+    GapViewT<I> *rw[2] = {&m.rows.v0, &m.rows.v1};
+    const I si[2][2] = {{d_ref_seq.s, d_ref_seq.e}, {d_query_seq.s, d_query_seq.e}};
+    I off[2][2];
+    bool ok[2];
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+      const bool in0 = seq_idx_offset(*rv[k], si[k][0], off[k][0]), in1 = seq_idx_offset(*rv[k], si[k][1], off[k][1]);
+      ok[k] = in0 && in1;
+    }
+    LbProbe<I> a = lb_probe(lp, ok[0], off[0][0]), b = lb_probe(lp, ok[0], off[0][1]), c = lb_probe(rp, ok[1], off[1][0]), d = lb_probe(rp, ok[1], off[1][1]);
+    lower_bounds4<0, 0, 0, 0>(a, b, c, d);
+    const int at[2][2] = {{a.lo, b.lo}, {c.lo, d.lo}};
+    I pr[2][2];
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+#pragma unroll
+      for(int w = 0; w < 2; ++w) {
+        pr[k][w] = ok[k] ? rv[k]->pre[at[k][w]] : 0;
+      }
+    }
+    int st_row[2];
+    bool swp[2] = {false, false};
+#pragma unroll
+    for(int k = 0; k < 2; ++k) {
+      const I ps = pr[k][0] + off[k][0], pe = pr[k][1] + off[k][1];
+      if(!ok[k]) {
+        st_row[k] = PM_ST_SEQ_IDX_OUT_OF_RANGE;
+      }
+      else if(ps <= 0 || rv[k]->len < ps || pe <= 0 || rv[k]->len < pe) { // m_profile.cc:163-166
+        st_row[k] = PM_ST_PROFILE_IDX_OUT_OF_RANGE;
+      }
+      else {
+        st_row[k] = PM_ST_OK;
+        const bool swap = ps > pe;
+        swp[k] = swap;
+        rw[k]->g = rv[k]->g;
+        rw[k]->lo = swap ? at[k][1] : at[k][0];
+        rw[k]->n = (swap ? at[k][0] : at[k][1]) - rw[k]->lo;
+        rw[k]->ws = swap ? pe : ps;
+        rw[k]->we = swap ? ps : pe;
+        rw[k]->mirror = false;
+        rw[k]->L = 0;
+      }
+    }
+    if(st_row[0]) return st_row[0]; // :539-541
+    if(st_row[1]) return st_row[1]; // :543-545
+    l_seq = swp[0] ? R2T<I>{d_ref_seq.e, d_ref_seq.s} : d_ref_seq;
+    r_seq = swp[1] ? R2T<I>{d_query_seq.e, d_query_seq.s} : d_query_seq;
+  }
   if(rlen(d_ref_seq) != rlen(l_seq) || rlen(d_query_seq) != rlen(r_seq)) {
     return PM_ST_ASSERT_SUB_LENGTHS; // :550-551
   }
@@ -830,6 +1076,8 @@ PM_HD inline int unit_setup(const PVT<I> &lp, const PVT<I> &rp, const PVT<I> &dr
   m.mirrored = mirrored;
   m.query_columns = rp.len;
   m.b_restart(ref_start, query_start);
+  m.rows.prime();
+  m.delta.prime();
   proceed = true;
   return PM_ST_OK;
 }
@@ -907,6 +1155,8 @@ PM_HD inline void unit_restore(const RowsT<I> &left, const RowsT<I> &right, cons
   m.mirrored = s.mirrored != 0;
   m.query_columns = s.query_columns;
   m.b_restart(s.ref_start, s.query_start);
+  m.rows.prime();
+  m.delta.prime();
 }
 
 // One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
