@@ -281,7 +281,7 @@ def bench_translate(args, rank, world, local, torch, dist):
                    % (args.tr_genomes, args.tr_genomes, args.tr_genome_len, args.tr_blocks, args.tr_deltas, args.tr_entries),
                    "units_per_rank": units, "live_units": n_live, "entries_out": n_ent, "offsets_out": n_off,
                    "coordinate_bits": bits},
-        "kernel_ms": {"filter+compact": ms_filter, "translate_kernel<count>": ms_count, "rocprim_scan_x2": ms_scan,
+        "kernel_ms": {"filter+compact": ms_filter, "translate_kernel<count>": ms_count, "offset_sums (2 kernels)": ms_scan,
                       "translate_kernel<emit>": ms_emit},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(dom_name, tr_key),

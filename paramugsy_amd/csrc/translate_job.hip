@@ -8,8 +8,8 @@
 //   out    : status[int U], cnt_ent[U+1], cnt_off[U+1] -> exclusive scans ent_off[U+1], off_off[U+1],
 //            entries[E] + offsets[O]: 32-byte Entry32 records + int offsets for a job on the int tables (pm_job_fetch widens them),
 //            pm_entry_t + int64 else (translate_device.hpp, EntRecT)
-// Kernels: prepare_rows / prepare_deltas (once per job), translate_count, 2x rocprim exclusive_scan,
-// translate_emit.  One lane per unit (the merge is a sequential state machine; the batch supplies the
+// Kernels: prepare_rows / prepare_deltas (once per job), translate_filter + the live list, translate_count, the prefix sums of
+// the counts (flag_* / count_* kernels below), translate_emit.  One lane per unit (the merge is a sequential state machine; the batch supplies the
 // parallelism), 64-lane workgroups so a 100 k-unit batch spreads over all 256 CUs.
 #include <hip/hip_runtime.h>
 
@@ -151,6 +151,156 @@ __global__ void scatter_live_kernel(i64 n_units, const int *live_flag, const int
   i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(u < n_units && live_flag[u]) {
     live_units[live_pos[u]] = (int)u;
+  }
+}
+
+// ---- The step's prefix sums.  Between its passes a step needs three exclusive sums over the units (the live flags; the entries and
+// the offsets each unit writes).  As three library scans they were seven launches and 60 us of a 320 us step, each a chained
+// look-back over some 1.4 M elements (profiles/r04_translate_ablation.txt).  Here: tiles of 2 048 elements; one kernel adds up every
+// tile, the next gives every tile the sum of the tiles before it (a block adds up to SCAN_MAX_TILES partial sums: a few KB out of
+// the L2) and scans the tile; the two count arrays go through together, and the flags' kernel also writes the list of live units
+// (scatter_live_kernel's work).  Jobs of more than SCAN_MAX_TILES tiles (8.4 M units) keep the library scans.
+constexpr int SCAN_THREADS = 256, SCAN_PER = 8, SCAN_TILE = SCAN_THREADS * SCAN_PER, SCAN_MAX_TILES = 4096;
+struct Sum2 {
+  i64 a, b;
+};
+__device__ __forceinline__ int scan_add(int x, int y) { return x + y; }
+__device__ __forceinline__ Sum2 scan_add(Sum2 x, Sum2 y) { return Sum2{x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ int scan_up(int v, int d) { return __shfl_up(v, d); }
+__device__ __forceinline__ Sum2 scan_up(Sum2 v, int d) { return Sum2{__shfl_up(v.a, d), __shfl_up(v.b, d)}; }
+__device__ __forceinline__ int scan_zero(int) { return 0; }
+__device__ __forceinline__ Sum2 scan_zero(Sum2) { return Sum2{0, 0}; }
+// exclusive sum of v over the block's SCAN_THREADS threads; total = the block's sum.  sh: SCAN_THREADS / 64 slots
+template <typename T>
+__device__ __forceinline__ T block_exclusive(T v, T *sh, T &total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  T inc = v;
+#pragma unroll
+  for(int d = 1; d < 64; d <<= 1) {
+    const T o = scan_up(inc, d);
+    if(lane >= d) {
+      inc = scan_add(inc, o);
+    }
+  }
+  __syncthreads(); // sh may still be read from an earlier call
+  if(lane == 63) {
+    sh[wv] = inc;
+  }
+  __syncthreads();
+  T before = scan_zero(v);
+  total = scan_zero(v);
+#pragma unroll
+  for(int w = 0; w < SCAN_THREADS / 64; ++w) {
+    if(w < wv) {
+      before = scan_add(before, sh[w]);
+    }
+    total = scan_add(total, sh[w]);
+  }
+  T exc = scan_up(inc, 1);
+  if(lane == 0) {
+    exc = scan_zero(v);
+  }
+  return scan_add(before, exc);
+}
+// the sum of the tiles before this block's
+template <typename T>
+__device__ __forceinline__ T tiles_before(const T *partial, T *sh) {
+  T acc = scan_zero(partial[0]);
+  for(int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_THREADS) {
+    acc = scan_add(acc, partial[k]);
+  }
+  T total;
+  (void)block_exclusive(acc, sh, total);
+  return total;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) flag_tile_sums_kernel(i64 n, const int *__restrict__ flag, int *__restrict__ partial) {
+  __shared__ int sh[SCAN_THREADS / 64];
+  const i64 base = (i64)blockIdx.x * SCAN_TILE;
+  int acc = 0;
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    const i64 k = base + i * SCAN_THREADS + threadIdx.x;
+    acc += k < n ? flag[k] : 0;
+  }
+  int total;
+  (void)block_exclusive(acc, sh, total);
+  if(threadIdx.x == 0) {
+    partial[blockIdx.x] = total;
+  }
+}
+// live_pos[u] = live flags before u (u = 0 .. n_units: the last one is the number of live units); live_units = the live ones in order
+__global__ void __launch_bounds__(SCAN_THREADS)
+flag_scan_scatter_kernel(i64 n, i64 n_units, const int *__restrict__ flag, const int *__restrict__ partial, int *__restrict__ live_pos,
+                         int *__restrict__ live_units) {
+  __shared__ int sh[SCAN_THREADS / 64];
+  const int before = tiles_before(partial, sh);
+  const i64 first = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_PER;
+  int f[SCAN_PER], sum = 0;
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    f[i] = first + i < n ? flag[first + i] : 0;
+    sum += f[i];
+  }
+  int total;
+  int at = before + block_exclusive(sum, sh, total);
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    const i64 u = first + i;
+    if(u < n) {
+      live_pos[u] = at;
+      if(f[i] && u < n_units) {
+        live_units[at] = (int)u;
+      }
+    }
+    at += f[i];
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+count_tile_sums_kernel(i64 n, const i64 *__restrict__ cnt_ent, const i64 *__restrict__ cnt_off, Sum2 *__restrict__ partial) {
+  __shared__ Sum2 sh[SCAN_THREADS / 64];
+  const i64 base = (i64)blockIdx.x * SCAN_TILE;
+  Sum2 acc{0, 0};
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    const i64 k = base + i * SCAN_THREADS + threadIdx.x;
+    if(k < n) {
+      acc.a += cnt_ent[k];
+      acc.b += cnt_off[k];
+    }
+  }
+  Sum2 total;
+  (void)block_exclusive(acc, sh, total);
+  if(threadIdx.x == 0) {
+    partial[blockIdx.x] = total;
+  }
+}
+__global__ void __launch_bounds__(SCAN_THREADS)
+count_scan_kernel(i64 n, const i64 *__restrict__ cnt_ent, const i64 *__restrict__ cnt_off, const Sum2 *__restrict__ partial,
+                  i64 *__restrict__ ent_off, i64 *__restrict__ off_off) {
+  __shared__ Sum2 sh[SCAN_THREADS / 64];
+  const Sum2 before = tiles_before(partial, sh);
+  const i64 first = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_PER;
+  i64 ce[SCAN_PER], co[SCAN_PER];
+  Sum2 sum{0, 0};
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    ce[i] = first + i < n ? cnt_ent[first + i] : 0;
+    co[i] = first + i < n ? cnt_off[first + i] : 0;
+    sum.a += ce[i];
+    sum.b += co[i];
+  }
+  Sum2 total;
+  Sum2 at = scan_add(before, block_exclusive(sum, sh, total));
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    if(first + i < n) {
+      ent_off[first + i] = at.a;
+      off_off[first + i] = at.b;
+    }
+    at.a += ce[i];
+    at.b += co[i];
   }
 }
 
@@ -824,7 +974,7 @@ struct pm_job {
   DevBuf u_delta, u_left, u_right;
   i64 n_units = 0;
   DevBuf status, cnt_ent, cnt_off, ent_off, off_off, entries, offsets, overflow, scan_tmp;
-  DevBuf live_flag, live_pos, live_units, scan_tmp32;
+  DevBuf live_flag, live_pos, live_units, scan_tmp32, scan_partial;
   DevBuf states; // UnitState per live unit (null during the sizing pass of pm_job_create)
   DevBuf maxabs, narrow_trip;
   // units whose gaps arrive out of the writer's order (Sink): found by the sizing pass, emitted again by the FIX pass
@@ -833,6 +983,7 @@ struct pm_job {
   // what the EMIT pass writes per entry / per offset (translate_device.hpp: Entry32 + int for a narrow job, pm_entry_t + int64 else)
   int64_t rec_bytes() const { return narrow ? (int64_t)sizeof(Entry32) : (int64_t)sizeof(pm_entry_t); }
   int64_t off_bytes() const { return narrow ? 4 : 8; }
+  bool library_scans = false; // PM_TRANSLATE_LIBRARY_SCANS=1 at pm_job_create: the prefix sums of jobs above SCAN_MAX_TILES tiles, for any job (tests)
   bool narrow = false; // the job runs on the int tables (every table value below PM_NARROW_INPUT_LIMIT, no PM_ST_NARROW seen)
   size_t scan_tmp32_bytes = 0;
   size_t scan_tmp_bytes = 0;
@@ -870,12 +1021,23 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
     }
     PM_HIP(hipGetLastError());
   }
-  size_t tmp32 = j->scan_tmp32_bytes;
-  PM_HIP(rocprim::exclusive_scan(j->scan_tmp32.p, tmp32, (int *)j->live_flag.p, (int *)j->live_pos.p, 0, (size_t)(U + 1),
-                                 rocprim::plus<int>(), stream));
-  if(U > 0) {
-    scatter_live_kernel<<<blocks256, 256, 0, stream>>>(U, (const int *)j->live_flag.p, (const int *)j->live_pos.p, (int *)j->live_units.p);
+  const i64 n_scan = U + 1;
+  const unsigned tiles = (unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE);
+  const bool own_scans = tiles <= (unsigned)SCAN_MAX_TILES && !j->library_scans;
+  if(own_scans) {
+    flag_tile_sums_kernel<<<tiles, SCAN_THREADS, 0, stream>>>(n_scan, (const int *)j->live_flag.p, (int *)j->scan_partial.p);
+    flag_scan_scatter_kernel<<<tiles, SCAN_THREADS, 0, stream>>>(n_scan, U, (const int *)j->live_flag.p, (const int *)j->scan_partial.p,
+                                                               (int *)j->live_pos.p, (int *)j->live_units.p);
     PM_HIP(hipGetLastError());
+  }
+  else {
+    size_t tmp32 = j->scan_tmp32_bytes;
+    PM_HIP(rocprim::exclusive_scan(j->scan_tmp32.p, tmp32, (int *)j->live_flag.p, (int *)j->live_pos.p, 0, (size_t)(U + 1),
+                                   rocprim::plus<int>(), stream));
+    if(U > 0) {
+      scatter_live_kernel<<<blocks256, 256, 0, stream>>>(U, (const int *)j->live_flag.p, (const int *)j->live_pos.p, (int *)j->live_units.p);
+      PM_HIP(hipGetLastError());
+    }
   }
   if(ev) {
     PM_HIP(hipEventRecord(ev[1], stream));
@@ -899,12 +1061,20 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
     PM_HIP(hipEventRecord(ev[2], stream));
   }
   // 3. output offsets
-  size_t tmp = j->scan_tmp_bytes;
-  PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off.p, (i64)0, (size_t)(U + 1),
-                                 rocprim::plus<i64>(), stream));
-  tmp = j->scan_tmp_bytes;
-  PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_off.p, (i64 *)j->off_off.p, (i64)0, (size_t)(U + 1),
-                                 rocprim::plus<i64>(), stream));
+  if(own_scans) {
+    count_tile_sums_kernel<<<tiles, SCAN_THREADS, 0, stream>>>(n_scan, (const i64 *)j->cnt_ent.p, (const i64 *)j->cnt_off.p, (Sum2 *)j->scan_partial.p);
+    count_scan_kernel<<<tiles, SCAN_THREADS, 0, stream>>>(n_scan, (const i64 *)j->cnt_ent.p, (const i64 *)j->cnt_off.p,
+                                                        (const Sum2 *)j->scan_partial.p, (i64 *)j->ent_off.p, (i64 *)j->off_off.p);
+    PM_HIP(hipGetLastError());
+  }
+  else {
+    size_t tmp = j->scan_tmp_bytes;
+    PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off.p, (i64)0, (size_t)(U + 1),
+                                   rocprim::plus<i64>(), stream));
+    tmp = j->scan_tmp_bytes;
+    PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_off.p, (i64 *)j->off_off.p, (i64)0, (size_t)(U + 1),
+                                   rocprim::plus<i64>(), stream));
+  }
   if(ev) {
     PM_HIP(hipEventRecord(ev[3], stream));
   }
@@ -1128,6 +1298,7 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
     JTRY(j->scan_tmp32.alloc(tmp32 ? tmp32 : 8));
   }
   JTRY(j->scan_tmp.alloc(tmp ? tmp : 8));
+  JTRY(j->scan_partial.alloc((size_t)SCAN_MAX_TILES * sizeof(Sum2)));
   lap("units up, per-unit arrays");
   // int or int64 tables?  int when every magnitude in the tables is below the limit (PM_TRANSLATE_WIDE=1 forces int64)
   {
@@ -1137,6 +1308,8 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
       return fail(PM_E_HIP, "hipMemcpy failed");
     }
     const char *wide = getenv("PM_TRANSLATE_WIDE");
+    const char *lib_scans = getenv("PM_TRANSLATE_LIBRARY_SCANS");
+    j->library_scans = lib_scans && lib_scans[0] == '1';
     j->narrow = big < (unsigned long long)PM_NARROW_INPUT_LIMIT && !(wide && wide[0] == '1');
   }
   // Size the outputs once: the inputs of a job never change, so neither do its output sizes.

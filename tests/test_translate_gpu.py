@@ -17,8 +17,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["int", "int64"])
 def coordinate_width(request, monkeypatch):
     """Every test of this file runs twice: on the int tables a job takes when all its numbers are below 2^25 (all the
-    inputs here are), and with PM_TRANSLATE_WIDE=1, on the int64 tables."""
+    inputs here are), and with PM_TRANSLATE_WIDE=1, on the int64 tables."""  # (and see below: the prefix sums)
     monkeypatch.setenv("PM_TRANSLATE_WIDE", "1" if request.param == "int64" else "0")
+    # the int64 runs also take the library's prefix sums (what jobs above 8.4 M units use), the int runs the step's own
+    monkeypatch.setenv("PM_TRANSLATE_LIBRARY_SCANS", "1" if request.param == "int64" else "0")
     return request.param
 
 
@@ -207,6 +209,27 @@ def test_gaps_out_of_the_writers_order_are_merged_as_the_writer_does(seed, mode,
         job.run()  # and again: the FIX pass rewrites what the EMIT pass wrote, every pass
         assert_same_result(job.fetch(), ora)
         job.close()
+
+
+def test_prefix_sums_of_the_step_equal_the_librarys_over_many_tiles(tmp_path, monkeypatch):
+    """The step's own prefix sums (tiles of 2 048 units: the live list, the entry and offset places) against the library scans a job
+    above 8.4 M units keeps, on a job of some hundred tiles whose last tile is ragged: the same live order, places and outputs."""
+    w = synth.make_workload(str(tmp_path / "job"), 77, n_left=3, n_right=3, genome_len=200000, n_blocks=500, n_deltas=4,
+                            entries_per_delta=1500, mean_len=1500)
+    t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+    assert t.n_units > 40 * 2048 and t.n_units % 2048 != 0
+    got = []
+    for library in ("0", "1"):
+        monkeypatch.setenv("PM_TRANSLATE_LIBRARY_SCANS", library)
+        job = TranslateJob(t)
+        job.run()
+        job.run()
+        got.append(job.fetch())
+        job.close()
+    a, b = got
+    assert np.array_equal(a.status, b.status) and np.array_equal(a.unit_entry_off, b.unit_entry_off)
+    assert a.entries.tobytes() == b.entries.tobytes() and np.array_equal(a.offsets, b.offsets)
+    assert len(a.offsets) > 0
 
 
 @pytest.mark.parametrize("mode,overlap", [(m, 0.0) for m in sorted(MODES)] + [("typical", 0.3), ("tiny_blocks", 0.8), ("reverse", 0.05)])
