@@ -1256,8 +1256,12 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     }
     if(any) {
       while(h->tier_streams.size() < 3) {
+        // at the highest priority: the tiers are what the step waits for, and the runtime gives every priority level hardware queues
+        // of its own -- the seven streams of a ragged batch in several chunks no longer share four (profiles/r04_stream.txt)
         hipStream_t st = nullptr;
-        PM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        int prio_least = 0, prio_greatest = 0;
+        PM_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        PM_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_greatest));
         h->tier_streams.push_back(st);
       }
       while(h->tier_events.size() < 4) {
@@ -1635,7 +1639,11 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
   // two fill streams (see dp_batch.hpp): the fill kernel of an odd chunk is held back only by the path kernel that frees its half
   // of the workspace, not by the fill kernel of the chunk before it
   const int K = h->n_slots;
-  const bool two_fills = pipelined && (int)h->fill_streams.size() >= K - 1 && h->ev_begin && h->seg_first.empty();
+  // (also for a batch that is still arriving in segments -- the host-fed engine: a chunk then waits for the segments its pairs lie in
+  // and goes as one launch.  The uploads run far ahead of the kernels, 57 GB/s against the 22 GB/s of columns the fill kernels use up,
+  // so only the first chunk ever waits; a launch per (chunk, segment) on one stream, as a single-chunk batch takes them to start
+  // before its last segment is up, cost the headline batch 342 instead of 297 ms of kernels: profiles/r04_stream.txt)
+  const bool two_fills = pipelined && (int)h->fill_streams.size() >= K - 1 && h->ev_begin;
   // progress words for every launch of the pass that may ask for several workgroups per pair (dp_launch_fill takes a piece each):
   // n * ng <= CUs and at most 16 waves per workgroup bound a launch's
   {
@@ -1690,11 +1698,18 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       tiers_end = c_lo;
       tiers_joined = 0;
       for(size_t sg = 0; sg + 1 < h->seg_first.size() && at < c_hi; ++sg) {
+        const bool armed = sg < h->ev_seg.size() && h->seg_events_armed;
+        if(two_fills) { // the chunk goes as one launch below, behind every segment its pairs lie in
+          if(armed && h->seg_first[sg + 1] > c_lo && h->seg_first[sg] < c_hi) {
+            PM_HIP(hipStreamWaitEvent(stream, h->ev_seg[sg], 0));
+          }
+          continue;
+        }
         const i64 s_hi = std::min(h->seg_first[sg + 1], c_hi);
         if(s_hi <= at) {
           continue;
         }
-        if(sg < h->ev_seg.size() && h->seg_events_armed) {
+        if(armed) {
           PM_HIP(hipStreamWaitEvent(stream, h->ev_seg[sg], 0)); // the segment's columns are in HBM
         }
         PM_TRY(dp_launch_fill(h, at, s_hi - at, tbw, traceback, stream));

@@ -97,9 +97,17 @@ int pm_dp_stream_create_opt(const pm_dp_params_t *params, const pm_dp_options_t 
       rc = fail(PM_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     }
   };
-  for(hipStream_t *st : {&s->up, &s->comp, &s->down}) {
-    hipok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
-  }
+  // The copy streams at priorities of their own: the runtime multiplexes a process's streams onto a few hardware queues per
+  // priority level, in creation order, and a stream whose queue it shares waits behind its packets.  With the batch's two extra
+  // fill streams in the normal pool, the third chunk's fill kernel sat behind the upload stream's last packet -- 133 ms into a call
+  // whose columns it needed had arrived at 62 (profiles/r04_stream.txt).  The upload stream at the HIGHEST: its small kernels (the
+  // column statistics, the packing of row texts) stand between a segment's copies and its event, and at the lowest they waited tens
+  // of milliseconds for a free slot beside the fill kernels, the uploads behind them.  The download stream carries copies only.
+  int prio_least = 0, prio_greatest = 0;
+  hipok(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest), "hipDeviceGetStreamPriorityRange");
+  hipok(hipStreamCreateWithPriority(&s->up, hipStreamNonBlocking, prio_greatest), "hipStreamCreate");
+  hipok(hipStreamCreateWithFlags(&s->comp, hipStreamNonBlocking), "hipStreamCreate");
+  hipok(hipStreamCreateWithPriority(&s->down, hipStreamNonBlocking, prio_least), "hipStreamCreate");
   hipok(hipEventCreateWithFlags(&s->ev_comp, hipEventDisableTiming), "hipEventCreate");
   hipok(hipHostMalloc((void **)&s->host_words, 16 * sizeof(int), hipHostMallocDefault), "hipHostMalloc");
   s->b = new(std::nothrow) pm_dp_batch();
@@ -157,12 +165,34 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
       return r;
     }
     PM_HIP(hipEventRecord(s->ev_comp, s->comp));
-    PM_HIP(hipStreamWaitEvent(s->down, s->ev_comp, 0));
-    PM_HIP(hipMemcpyAsync(scores, b->scores.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s->down));
-    if(traceback) {
-      PM_HIP(hipMemcpyAsync(n_ops, b->n_ops.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s->down));
-      if(b->total_a + b->total_b > 0) {
-        PM_HIP(hipMemcpyAsync(ops, b->ops.p, (size_t)(b->total_a + b->total_b), hipMemcpyDeviceToHost, s->down));
+    // A batch of several chunks that came in segments keeps the caller's order, so a chunk's results are one range of each array:
+    // they leave behind the chunk's path kernel, beside the kernels of the chunks after it (the headline batch: 820 MB, 14 ms at the
+    // end of the call otherwise).
+    const size_t nc = b->chunk_tb.size();
+    if(traceback && nc > 1 && b->path_stream && !b->seg_first.empty() && b->ev_path.size() >= nc && b->chunk_first.size() == nc + 1) {
+      for(size_t c = 0; c < nc; ++c) {
+        const i64 lo = b->chunk_first[c], hi = b->chunk_first[c + 1];
+        if(hi <= lo) {
+          continue;
+        }
+        PM_HIP(hipStreamWaitEvent(s->down, b->ev_path[c], 0));
+        PM_HIP(hipMemcpyAsync(scores + lo, (const int *)b->scores.p + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, s->down));
+        PM_HIP(hipMemcpyAsync(n_ops + lo, (const int *)b->n_ops.p + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, s->down));
+        const i64 o_lo = b->off_a[(size_t)lo] + b->off_b[(size_t)lo], o_hi = b->off_a[(size_t)hi] + b->off_b[(size_t)hi];
+        if(o_hi > o_lo) {
+          PM_HIP(hipMemcpyAsync(ops + o_lo, (const unsigned char *)b->ops.p + o_lo, (size_t)(o_hi - o_lo), hipMemcpyDeviceToHost, s->down));
+        }
+      }
+      PM_HIP(hipStreamWaitEvent(s->down, s->ev_comp, 0));
+    }
+    else {
+      PM_HIP(hipStreamWaitEvent(s->down, s->ev_comp, 0));
+      PM_HIP(hipMemcpyAsync(scores, b->scores.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s->down));
+      if(traceback) {
+        PM_HIP(hipMemcpyAsync(n_ops, b->n_ops.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s->down));
+        if(b->total_a + b->total_b > 0) {
+          PM_HIP(hipMemcpyAsync(ops, b->ops.p, (size_t)(b->total_a + b->total_b), hipMemcpyDeviceToHost, s->down));
+        }
       }
     }
     PM_HIP(hipMemcpyAsync(&s->host_words[8], b->pipe_error.p, 4, hipMemcpyDeviceToHost, s->down));
