@@ -632,7 +632,7 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
         pin = dpm.DpInputs(pa.a, inputs.off_a, pb.a, inputs.off_b)
         ps, pn = dpm.PinnedArray((n,), np.int32), dpm.PinnedArray((n,), np.int32)
         po = dpm.PinnedArray((max(1, int(inputs.off_a[-1] + inputs.off_b[-1])),), np.uint8)
-        st = dpm.DpStream(params, 4, device=local)
+        st = dpm.DpStream(params, 8, device=local)
         st.align(pin, ps.a, po.a, pn.a)
         best = 1e30
         for _ in range(3):
@@ -640,7 +640,7 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
             st.align(pin, ps.a, po.a, pn.a)
             best = min(best, time.perf_counter() - t0)
         out["end_to_end"] = {"value": cells / best / 1e9, "unit": "GCUPS", "ms": best * 1e3,
-                             "what": "pm_dp_stream_align: pinned host columns in (%.0f MB), scores + paths out (%.0f MB), 4 upload segments; "
+                             "what": "pm_dp_stream_align: pinned host columns in (%.0f MB), scores + paths out (%.0f MB), 8 upload segments; "
                                      "best of 3; results equal the resident batch's: %s"
                                      % ((pa.a.nbytes + pb.a.nbytes) / 1e6, po.a.nbytes / 1e6,
                                         bool(np.array_equal(ps.a, r_scores) and np.array_equal(pn.a, r_nops)))}

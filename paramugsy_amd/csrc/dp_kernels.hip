@@ -1135,26 +1135,46 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     h->chunk_first.assign(1, 0);
     h->chunk_tb.clear();
     h->tb_words_cap = 0;
-    std::vector<i64> cur;
-    i64 used = 0;
-    for(i64 q = 0; q < n_pairs; ++q) {
-      i64 need = need_words(h->order[(size_t)q]);
-      if(!cur.empty() && used + need > budget_words) {
-        h->chunk_tb.push_back(cur);
-        h->chunk_first.push_back(q);
-        h->tb_words_cap = std::max(h->tb_words_cap, used);
-        cur.clear();
-        used = 0;
-        if(one_chunk && uneven) {
-          budget_words = total_words; // the second chunk takes the rest
+    // Greedy: a chunk takes pairs while they fit.  A batch that is arriving in segments (the host-fed engine) ends a chunk at the last
+    // segment boundary inside it instead, if that keeps 60 % of it: a chunk then waits for whole segments only, and with segments no
+    // larger than chunks the first chunk starts when the FIRST segment is up (the headline batch in 8 segments: 15 ms into the call
+    // instead of 30, profiles/r04_stream.txt).
+    for(i64 c_lo = 0; c_lo < n_pairs || h->chunk_tb.empty();) {
+      std::vector<i64> cur;
+      i64 used = 0, q = c_lo;
+      while(q < n_pairs) {
+        const i64 need = need_words(h->order[(size_t)q]);
+        if(q > c_lo && used + need > budget_words) {
+          break;
+        }
+        cur.push_back(used);
+        used += need;
+        ++q;
+      }
+      if(q < n_pairs && !one_chunk && h->seg_first.size() > 2) {
+        i64 snap = -1;
+        for(const i64 b : h->seg_first) {
+          if(b > c_lo && b <= q) {
+            snap = b;
+          }
+        }
+        if(snap > 0 && snap < q && (snap - c_lo) * 10 >= (q - c_lo) * 6) {
+          q = snap;
+          cur.resize((size_t)(q - c_lo));
+          used = cur.back() + need_words(h->order[(size_t)(q - 1)]);
         }
       }
-      cur.push_back(used);
-      used += need;
+      h->chunk_tb.push_back(cur);
+      h->chunk_first.push_back(q);
+      h->tb_words_cap = std::max(h->tb_words_cap, used);
+      if(one_chunk && uneven) {
+        budget_words = total_words; // the second chunk takes the rest
+      }
+      c_lo = q;
+      if(n_pairs == 0) {
+        break;
+      }
     }
-    h->chunk_tb.push_back(cur);
-    h->chunk_first.push_back(n_pairs);
-    h->tb_words_cap = std::max(h->tb_words_cap, used);
     // (cutting the last chunk once more, so that the path kernel that runs alone at the very end is a short one, was measured and
     // costs more than it saves: the headline batch 310.2 -> 312.4 ms, profiles/r03_dp_chunks.txt)
     pipelined = h->chunk_tb.size() > 1;
