@@ -874,6 +874,27 @@ int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int6
     }
     const double per_segment = h->opt.segment_cells > 0 ? (double)h->opt.segment_cells : 5e9; // (tests cut tiny batches into many segments)
     segments = (int)std::min<int64_t>(segments, std::max<int64_t>(1, (int64_t)(cells / per_segment)));
+    // A segment is a launch of its own (dp_batch_plan).  Pairs of one length balance themselves; a RAGGED launch -- its longest pair
+    // more than twice the mean -- needs pairs in the tens of thousands to keep the chip evenly loaded beside its few long ones (the
+    // ragged 100 k-pair batch from host memory: 131 ms in 4 segments of 25 000 pairs, 179 in 8; profiles/r04_stream.txt)
+    if(h->opt.segment_cells <= 0 && n_pairs > 0) {
+      double longest = 0;
+      for(int64_t k = 0; k < n_pairs; ++k) {
+        longest = std::max(longest, (double)(h->off_a[(size_t)k + 1] - h->off_a[(size_t)k]) * (double)(h->off_b[(size_t)k + 1] - h->off_b[(size_t)k]));
+      }
+      if(longest > 2.0 * cells / (double)n_pairs) {
+        segments = (int)std::min<int64_t>(segments, std::max<int64_t>(1, n_pairs / 25000));
+      }
+      // ... and a launch of few LONG pairs should bring a few rounds' worth of stripes for the chip's 4 096 resident wavefronts
+      // (4 096 pairs of 32 x 10 kbp, ten stripes each: 120 ms in four segments of 1 024 pairs, profiles/r04_stream.txt)
+      if(cells >= 1e11) {
+        int64_t stripes = 0;
+        for(int64_t k = 0; k < n_pairs; ++k) {
+          stripes += (h->off_b[(size_t)k + 1] - h->off_b[(size_t)k] + 1023) / 1024;
+        }
+        segments = (int)std::min<int64_t>(segments, std::max<int64_t>(1, stripes / 16384));
+      }
+    }
   }
   segments = (int)std::max<int64_t>(1, std::min<int64_t>(segments, std::max<int64_t>(n_pairs, 1)));
   h->seg_first.assign(1, 0);
@@ -1071,18 +1092,25 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // processing order: a wavefront works through its pair's stripes one after the other, so a launch lasts at least as long as
   // its longest pair; pairs are therefore taken longest first (stripes x steps, ties in input order), which also puts pairs of
   // like length into the same chunk, where the waves-per-pair choice of dp_launch_fill can split the long ones.  A batch
-  // whose columns arrive in segments (dp_stream.hip) keeps the input order: its fill kernels follow the uploads.
+  // whose columns arrive in segments (dp_stream.hip) is cut into chunks in the input order -- a chunk never reaches across a
+  // segment boundary, so its fill kernel waits for one segment, and its results are one range of the caller's arrays -- and
+  // ordered longest first INSIDE every chunk (below).  (It kept the input order altogether until round 4: the ragged 100 k-pair
+  // batch from host memory ran at 1 960 GCUPS against the resident batch's 4 950, profiles/r04_stream.txt.)
+  const bool segmented = !h->seg_first.empty();
   h->order.resize((size_t)n_pairs);
   for(i64 k = 0; k < n_pairs; ++k) {
     h->order[(size_t)k] = (int)k;
   }
-  if(h->seg_first.empty() && !h->opt.keep_order) {
-    std::vector<i64> cost((size_t)n_pairs);
+  std::vector<i64> cost;
+  if(!h->opt.keep_order) {
+    cost.resize((size_t)n_pairs);
     for(i64 k = 0; k < n_pairs; ++k) {
       const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
       cost[(size_t)k] = dp_fill_cost(la, lb, h->cols_per_lane, h->tail);
     }
-    std::stable_sort(h->order.begin(), h->order.end(), [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
+    if(!segmented) {
+      std::stable_sort(h->order.begin(), h->order.end(), [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
+    }
   }
   i64 total_words = 0;
   h->cells = 0;
@@ -1126,6 +1154,10 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
       first_share = 1.0 - std::max(0.25, 4096.0 / (double)n_pairs);
     }
   }
+  // (tests and the fuzzer cut tiny batches into many segments, opt.segment_cells: theirs of four segments' worth and more go this way too)
+  const double per_segment_from = h->opt.segment_cells > 0 ? 4.0 * (double)h->opt.segment_cells : 1e11;
+  const bool per_segment = segmented && (h->seg_first.size() == 2 || (double)h->cells >= per_segment_from); // chunks end where segments end (below)
+  const bool sorted_chunks = !h->opt.keep_order && (!segmented || per_segment);                // ... and are ordered longest first
   bool pipelined = false;
   for(i64 budget = h->tb_budget_bytes;; budget /= 2) {
     const bool one_chunk = total_words <= budget / 4;
@@ -1135,34 +1167,40 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
     h->chunk_first.assign(1, 0);
     h->chunk_tb.clear();
     h->tb_words_cap = 0;
-    // Greedy: a chunk takes pairs while they fit.  A batch that is arriving in segments (the host-fed engine) ends a chunk at the last
-    // segment boundary inside it instead, if that keeps 60 % of it: a chunk then waits for whole segments only, and with segments no
-    // larger than chunks the first chunk starts when the FIRST segment is up (the headline batch in 8 segments: 15 ms into the call
-    // instead of 30, profiles/r04_stream.txt).
+    // Greedy: a chunk takes pairs while they fit; in a batch that is arriving in segments it also ends where a segment ends (with
+    // segments no larger than chunks the first chunk starts when the FIRST segment is up: the headline batch in 8 segments 15 ms into
+    // the call, profiles/r04_stream.txt), and its pairs are then put longest first.
+    // (Not a small batch in several segments: 10 000 pairs of 2 x 1 kbp in two segments are 5.9 ms as ONE chunk in the input order
+    // with a fill launch per segment -- the second segment's upload beside the first one's kernel -- and 7.0 as two chunks.)
+    if(segmented) {
+      for(i64 k = 0; k < n_pairs; ++k) {
+        h->order[(size_t)k] = (int)k; // (a second attempt with a smaller budget cuts other chunks)
+      }
+    }
+    size_t next_seg = 1; // the first segment boundary behind the chunk's start
     for(i64 c_lo = 0; c_lo < n_pairs || h->chunk_tb.empty();) {
-      std::vector<i64> cur;
+      while(per_segment && next_seg < h->seg_first.size() && h->seg_first[next_seg] <= c_lo) {
+        ++next_seg;
+      }
+      const i64 seg_end = per_segment && next_seg < h->seg_first.size() ? h->seg_first[next_seg] : n_pairs;
       i64 used = 0, q = c_lo;
-      while(q < n_pairs) {
+      while(q < n_pairs && q < seg_end) {
         const i64 need = need_words(h->order[(size_t)q]);
         if(q > c_lo && used + need > budget_words) {
           break;
         }
-        cur.push_back(used);
         used += need;
         ++q;
       }
-      if(q < n_pairs && !one_chunk && h->seg_first.size() > 2) {
-        i64 snap = -1;
-        for(const i64 b : h->seg_first) {
-          if(b > c_lo && b <= q) {
-            snap = b;
-          }
-        }
-        if(snap > 0 && snap < q && (snap - c_lo) * 10 >= (q - c_lo) * 6) {
-          q = snap;
-          cur.resize((size_t)(q - c_lo));
-          used = cur.back() + need_words(h->order[(size_t)(q - 1)]);
-        }
+      if(per_segment && !cost.empty()) {
+        std::stable_sort(h->order.begin() + c_lo, h->order.begin() + q, [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
+      }
+      std::vector<i64> cur;
+      cur.reserve((size_t)(q - c_lo));
+      i64 at_words = 0;
+      for(i64 p = c_lo; p < q; ++p) {
+        cur.push_back(at_words);
+        at_words += need_words(h->order[(size_t)p]);
       }
       h->chunk_tb.push_back(cur);
       h->chunk_first.push_back(q);
@@ -1230,7 +1268,7 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   // enough for dp_launch_fill to give them 8 and 4 wavefronts each (a third launch of the next 1 024 pairs, at 4 wavefronts each,
   // was the last to finish: 14.2 ms beside 11.6 for the rest).  Uniform batches have no such pairs.  PM_DP_NO_TIERS=1: not.
   h->chunk_tiers.assign(h->chunk_tb.size(), std::vector<i64>());
-  if(h->seg_first.empty() && !staged && !h->opt.no_tiers && !h->opt.keep_order && h->waves_override == 0) {
+  if(!h->opt.no_tiers && sorted_chunks && h->waves_override == 0) {
     bool any = false;
     for(size_t c = 0; c < h->chunk_tb.size(); ++c) {
       const i64 c_lo = h->chunk_first[c], c_hi = h->chunk_first[c + 1], n = c_hi - c_lo;
@@ -1659,10 +1697,10 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
   // two fill streams (see dp_batch.hpp): the fill kernel of an odd chunk is held back only by the path kernel that frees its half
   // of the workspace, not by the fill kernel of the chunk before it
   const int K = h->n_slots;
-  // (also for a batch that is still arriving in segments -- the host-fed engine: a chunk then waits for the segments its pairs lie in
-  // and goes as one launch.  The uploads run far ahead of the kernels, 57 GB/s against the 22 GB/s of columns the fill kernels use up,
-  // so only the first chunk ever waits; a launch per (chunk, segment) on one stream, as a single-chunk batch takes them to start
-  // before its last segment is up, cost the headline batch 342 instead of 297 ms of kernels: profiles/r04_stream.txt)
+  // (also for a batch that is still arriving in segments -- the host-fed engine: a chunk lies inside one segment, waits for it and
+  // goes as one launch.  The uploads run far ahead of the kernels, 57 GB/s against the 22 GB/s of columns the fill kernels use up,
+  // so only the first chunk ever waits; a launch per (chunk, segment) on one stream, as round 3 had them, cost the headline batch
+  // 342 instead of 297 ms of kernels: profiles/r04_stream.txt)
   const bool two_fills = pipelined && (int)h->fill_streams.size() >= K - 1 && h->ev_begin;
   // progress words for every launch of the pass that may ask for several workgroups per pair (dp_launch_fill takes a piece each):
   // n * ng <= CUs and at most 16 waves per workgroup bound a launch's
@@ -1711,29 +1749,30 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
     if(timed) {
       PM_HIP(hipEventRecord(h->tv_fill0[c], stream));
     }
-    // the chunk's pairs, one launch per upload segment (a batch that was loaded in one piece has none: one launch)
+    // the chunk's pairs.  A batch that is arriving in segments: the chunk lies inside one of them (dp_batch_plan) and waits for it
     {
       const i64 c_lo = h->chunk_first[c], c_hi = h->chunk_first[c + 1];
       i64 at = c_lo;
       tiers_end = c_lo;
       tiers_joined = 0;
+      size_t spans = 0; // segments the chunk's pairs lie in
+      for(size_t sg = 0; sg + 1 < h->seg_first.size(); ++sg) {
+        spans += h->seg_first[sg + 1] > c_lo && h->seg_first[sg] < c_hi ? 1 : 0;
+      }
       for(size_t sg = 0; sg + 1 < h->seg_first.size() && at < c_hi; ++sg) {
-        const bool armed = sg < h->ev_seg.size() && h->seg_events_armed;
-        if(two_fills) { // the chunk goes as one launch below, behind every segment its pairs lie in
-          if(armed && h->seg_first[sg + 1] > c_lo && h->seg_first[sg] < c_hi) {
-            PM_HIP(hipStreamWaitEvent(stream, h->ev_seg[sg], 0));
-          }
+        if(!(h->seg_first[sg + 1] > c_lo && h->seg_first[sg] < c_hi)) {
           continue;
         }
-        const i64 s_hi = std::min(h->seg_first[sg + 1], c_hi);
-        if(s_hi <= at) {
-          continue;
-        }
-        if(armed) {
+        if(sg < h->ev_seg.size() && h->seg_events_armed) {
           PM_HIP(hipStreamWaitEvent(stream, h->ev_seg[sg], 0)); // the segment's columns are in HBM
         }
-        PM_TRY(dp_launch_fill(h, at, s_hi - at, tbw, traceback, stream));
-        at = s_hi;
+        if(spans > 1 && !two_fills) { // a small batch, in the input order (dp_batch_plan): a launch per segment, as the segments arrive
+          const i64 s_hi = std::min(h->seg_first[sg + 1], c_hi);
+          if(s_hi > at) {
+            PM_TRY(dp_launch_fill(h, at, s_hi - at, tbw, traceback, stream));
+            at = s_hi;
+          }
+        }
       }
       // the chunk's longest pairs in small launches of their own, on side streams, beside the launch of the rest
       if(at == c_lo && c < h->chunk_tiers.size() && !h->chunk_tiers[c].empty() && h->tier_streams.size() >= h->chunk_tiers[c].size() &&

@@ -46,6 +46,57 @@ def test_stream_equals_resident_batch_on_ragged_pairs(segments, oracle_build, mo
     assert np.array_equal(r_scores, o_scores)
 
 
+@pytest.mark.parametrize("tiers", [False, True])
+def test_small_batch_in_two_segments_runs_as_one_chunk_in_the_input_order(tiers, oracle_build, monkeypatch):
+    """A batch of fewer than four segments' worth of cells stays ONE chunk in the caller's order with a fill launch per segment (the
+    other tests here, with segments of one cell, get a chunk per segment, its pairs longest first, the long ones in tiers)."""
+    monkeypatch.setenv("PM_DP_MODE", "ckpt")
+    la, lb = dp.ragged_lengths(9, 90, median=300, sigma=0.8, lo=1, hi=3000)
+    inputs = dp.synth_batch(10, la, lb, 2, 2)
+    params = dp.make_params(2, 2)
+    cells = int(np.sum(la.astype(np.int64) * lb))
+    monkeypatch.setenv("PM_DP_SEGMENT_CELLS", str(cells // 3 + 1))
+    if tiers:
+        monkeypatch.setenv("PM_DP_TIER_MIN_PAIRS", "8")
+    r_scores, r_ops, r_nops = resident(inputs, params)
+    for segments in (2, 6):
+        st = dp.DpStream(params, segments)
+        for _ in range(2):
+            scores, ops, n_ops = st.align(inputs)
+            assert np.array_equal(scores, r_scores) and np.array_equal(n_ops, r_nops)
+            for p, q in zip(dp.paths_of(inputs, ops, n_ops), dp.paths_of(inputs, r_ops, r_nops)):
+                assert np.array_equal(p, q)
+        st.close()
+
+
+@pytest.mark.parametrize("segments", [1, 3, 8])
+def test_ragged_batch_with_tiers_in_a_chunk_per_segment(segments, oracle_build, monkeypatch):
+    """Chunks that end where segments end, ordered longest first, the longest pairs of every chunk in tiers of their own (the
+    mark for tiers lowered to 8 pairs), results leaving chunk by chunk into pinned arrays: equal to the resident batch."""
+    monkeypatch.setenv("PM_DP_MODE", "ckpt")
+    monkeypatch.setenv("PM_DP_TIER_MIN_PAIRS", "8")
+    la, lb = dp.ragged_lengths(21, 400, median=250, sigma=0.9, lo=1, hi=4000)
+    src = dp.synth_batch(22, la, lb, 4, 4)
+    params = dp.make_params(4, 4)
+    r_scores, r_ops, r_nops = resident(src, params)
+    pa, pb = dp.PinnedArray(src.cols_a.shape, np.uint8), dp.PinnedArray(src.cols_b.shape, np.uint8)
+    pa.a[...] = src.cols_a
+    pb.a[...] = src.cols_b
+    inputs = dp.DpInputs(pa.a, src.off_a, pb.a, src.off_b)
+    n = len(la)
+    ps, pn = dp.PinnedArray((n,), np.int32), dp.PinnedArray((n,), np.int32)
+    po = dp.PinnedArray((max(1, int(src.off_a[-1] + src.off_b[-1])),), np.uint8)
+    st = dp.DpStream(params, segments)
+    for _ in range(2):
+        scores, ops, n_ops = st.align(inputs, ps.a, po.a, pn.a)
+        assert np.array_equal(scores, r_scores) and np.array_equal(n_ops, r_nops)
+        for p, q in zip(dp.paths_of(inputs, ops, n_ops), dp.paths_of(inputs, r_ops, r_nops)):
+            assert np.array_equal(p, q)
+    st.close()
+    for x in (pa, pb, ps, pn, po):
+        x.close()
+
+
 def test_stream_with_pinned_buffers_and_several_workspace_chunks(oracle_build, monkeypatch):
     monkeypatch.setenv("PM_DP_MODE", "ckpt")
     """Pinned inputs and outputs (the asynchronous case) and a workspace so small that the batch takes several chunks, each of

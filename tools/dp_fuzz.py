@@ -114,7 +114,12 @@ while time.time() < t_end:
     streamed = engine != "batch"
     try:
         if engine in ("stream", "stream_text"):
-            st = dp.DpStream(p, segments=int(rng.integers(1, 7)))
+            # the engine cuts a batch of at least four segments' worth of cells into a chunk per segment, ordered longest first, and
+            # runs a smaller one as one chunk in the input order with a launch per segment: half of the cases each
+            cells_case = int(np.sum(np.asarray(la, dtype=np.int64) * np.asarray(lb, dtype=np.int64)))
+            seg_cells = 1 if rng.random() < 0.5 else max(1, cells_case // 3 + 1)
+            st = dp.DpStream(p, segments=int(rng.integers(1, 7)), options=dp.options_from_env(dict(os.environ, PM_DP_SEGMENT_CELLS=str(seg_cells))))
+            env = dict(env, segment_cells=seg_cells)
             try:
                 if engine == "stream":
                     scores, ops, n_ops = st.align(inputs)
