@@ -887,12 +887,14 @@ int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int6
       }
       // ... and a launch of few LONG pairs should bring a few rounds' worth of stripes for the chip's 4 096 resident wavefronts
       // (4 096 pairs of 32 x 10 kbp, ten stripes each: 120 ms in four segments of 1 024 pairs, profiles/r04_stream.txt)
-      if(cells >= 1e11) {
+      // -- and a launch of a small batch at least one: 512 pairs of 32 x 10 kbp in four launches of 128 pairs, 1 280 stripes each,
+      // took 28.9 ms from host memory against the resident step's 15.6.
+      {
         int64_t stripes = 0;
         for(int64_t k = 0; k < n_pairs; ++k) {
           stripes += (h->off_b[(size_t)k + 1] - h->off_b[(size_t)k] + 1023) / 1024;
         }
-        segments = (int)std::min<int64_t>(segments, std::max<int64_t>(1, stripes / 16384));
+        segments = (int)std::min<int64_t>(segments, std::max<int64_t>(1, stripes / (cells >= 1e11 ? 16384 : 4096)));
       }
     }
   }
