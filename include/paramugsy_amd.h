@@ -304,8 +304,10 @@ int pm_dp_batch_path_mode(pm_dp_batch_t *batch, int32_t *checkpoints, int32_t *b
 void pm_dp_batch_destroy(pm_dp_batch_t *batch);
 
 /* The DP fed from host memory (csrc/dp_stream.hip): pm_dp_stream_align loads a batch in `segments` pieces of consecutive pairs
- * on an upload stream, runs the fill kernel on every piece as soon as it has arrived, one path kernel per workspace chunk, and
- * brings the results back on a download stream.  Same inputs, same outputs and same output layout as
+ * on an upload stream, runs the fill kernels behind the pieces as they arrive (a workspace chunk per piece, its pairs ordered longest
+ * first; a small batch: one chunk with a launch per piece), one path kernel per workspace chunk, and brings the results back on a
+ * download stream, chunk by chunk.  `segments` is an upper limit: the engine takes fewer when a piece would be too small a launch.
+ * Same inputs, same outputs and same output layout as
  * pm_dp_batch_create + run + fetch (ops == n_ops == NULL: scores only); the device buffers are kept from call to call.
  * Copies are asynchronous only from / to pinned host memory: pm_dp_host_alloc / pm_dp_host_free hand it out (pageable buffers
  * work, their copies just serialise on the host).  workspace_bytes: path workspace (<= 0: as pm_dp_batch_create).  Blocking: returns when

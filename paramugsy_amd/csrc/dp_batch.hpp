@@ -72,7 +72,8 @@ struct pm_dp_batch {
   std::vector<hipEvent_t> ev_fill, ev_path;                       // per chunk: fill done / path done
   std::vector<hipEvent_t> tv_fill0, tv_fill1, tv_path0, tv_path1; // timing events of the profiled run
   // dp_stream.hip: the columns arrive in segments of consecutive pairs (seg_first: first pair of each, plus n_pairs); ev_seg[k]
-  // fires on the upload stream when segment k is in HBM, and dp_run launches the fill kernel segment by segment behind them
+  // fires on the upload stream when segment k is in HBM; dp_batch_plan cuts such a batch into chunks that end where segments end
+  // (a small one: one chunk, which dp_run launches segment by segment), dp_run holds a chunk's launch back until its segment is up
   std::vector<pm::i64> seg_first;
   std::vector<hipEvent_t> ev_seg;
   bool seg_events_armed = false;
