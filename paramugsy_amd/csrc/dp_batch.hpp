@@ -133,6 +133,10 @@ int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int6
                                 bool have_b);
 // dp_batch_plan with the statistics given (dp_batch_plan itself reads the batch's own)
 int dp_batch_plan_with(pm_dp_batch *h, const int *stats, hipStream_t stream);
+// its two halves: what the statistics decide (validity, the kernel's arithmetic), and the layout (from the lengths and options alone)
+int dp_batch_plan_variant(pm_dp_batch *h, const int *stats);
+int dp_batch_plan_layout(pm_dp_batch *h, hipStream_t stream);
+const int *dp_batch_final_stats(const pm_dp_batch *h);
 // after the load has completed: validate against the statistics, choose the kernel variant, cut the batch into chunks of the
 // workspace, send the chunks' offset table on `stream`
 int dp_batch_plan(pm_dp_batch *h, hipStream_t stream);

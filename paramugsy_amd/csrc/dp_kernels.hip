@@ -944,8 +944,12 @@ int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int6
   return PM_OK;
 }
 
+const int *dp_batch_final_stats(const pm_dp_batch *h) { // where the load's last statistics copy lands
+  return h->pinned ? (const int *)((const char *)h->pinned + h->pinned_bytes - 32) : h->host_stats;
+}
+
 int dp_batch_plan(pm_dp_batch *h, hipStream_t stream) {
-  return dp_batch_plan_with(h, h->pinned ? (const int *)((char *)h->pinned + h->pinned_bytes - 32) : h->host_stats, stream);
+  return dp_batch_plan_with(h, dp_batch_final_stats(h), stream);
 }
 
 // lanes per pair of the checkpoint walk for the launch of the n pairs at positions [first, first + n): as few as still give the launch
@@ -983,6 +987,14 @@ static int dp_walk_lanes_for(const pm_dp_batch *h, i64 first, i64 n) { // positi
 }
 
 int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
+  PM_TRY(dp_batch_plan_variant(h, st));
+  return dp_batch_plan_layout(h, stream);
+}
+
+// What the column statistics decide: whether the batch can be run at all, and the kernel's arithmetic (int8 or int16 weights, the
+// uniform-depth form).  Nothing of the layout below depends on it -- the host-fed engine lays a batch out while its first segment is
+// still on the way and comes here when the statistics are (dp_stream.hip).
+int dp_batch_plan_variant(pm_dp_batch *h, const int *st) {
   const i64 n_pairs = h->n_pairs;
   const int max_a = st[0], max_colsum_b = st[3];
   if((int64_t)max_colsum_b * h->max_sub_all > 32767) { // the column weights are int16 lanes of v_dot2_i32_i16
@@ -1037,6 +1049,13 @@ int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   if(h->opt.int16_weights) {
     h->dot4 = false;
   }
+  return PM_OK;
+}
+
+// Everything that follows from the pairs' lengths and the options: columns per lane, where the paths come from, the processing
+// order, chunks and their workspace, tiers, the band.
+int dp_batch_plan_layout(pm_dp_batch *h, hipStream_t stream) {
+  const i64 n_pairs = h->n_pairs;
   // Columns of B per lane: 16, or 8 for a batch of a few hundred pairs at most whose profiles fit one 1 024-column stripe --
   // two stripes of 512 then, so twice the wavefronts a pair can keep busy, each with half the work per step (256 pairs of
   // 2 x 1 kbp: 0.60 -> 0.46 ms).  Longer pairs already have stripes to run side by side, and narrower stripes only make the

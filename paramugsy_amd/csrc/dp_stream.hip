@@ -199,6 +199,12 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
     return (int)PM_OK;
   };
   if(!rc) {
+    // the layout -- order, chunks, tiers: from the lengths alone -- while the first segment is on its way (8 ms of host time for the
+    // 100 000 ragged pairs of bench.py's c2, which stood between the segment's arrival and the first launch)
+    rc = dp_batch_plan_layout(b, s->comp);
+  }
+  lap("layout");
+  if(!rc) {
     // the first segment's statistics choose the kernel variant; its fill kernel starts while the other segments are on their way
     hipError_t e = hipEventSynchronize(b->ev_seg[0]);
     if(e != hipSuccess) {
@@ -207,9 +213,9 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
   }
   lap("first segment arrived");
   if(!rc) {
-    rc = dp_batch_plan_with(b, s->host_words, s->comp);
+    rc = dp_batch_plan_variant(b, s->host_words);
   }
-  lap("plan (first segment's statistics)");
+  lap("variant (first segment's statistics)");
   bool first_dot4 = false, first_uni = false;
   int first_rows = 0;
   if(!rc) {
@@ -227,7 +233,7 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
     }
   }
   if(!rc) {
-    rc = dp_batch_plan(b, s->comp);
+    rc = dp_batch_plan_variant(b, dp_batch_final_stats(b));
     if(!rc && (b->dot4 != first_dot4 || b->uni != first_uni || b->params.rows_a != first_rows)) {
       drain();
       if(!rc) {
@@ -235,7 +241,7 @@ static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load
       }
     }
   }
-  lap("second plan (whole batch's statistics)");
+  lap("uploads done, variant checked (whole batch's statistics)");
   drain();
   lap("drained");
   if(!rc && s->host_words[8]) {
