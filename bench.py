@@ -640,7 +640,7 @@ def bench_dp(args, cfg_name, rank, world, local, torch, dist, steps, warmup, wit
             st.align(pin, ps.a, po.a, pn.a)
             best = min(best, time.perf_counter() - t0)
         out["end_to_end"] = {"value": cells / best / 1e9, "unit": "GCUPS", "ms": best * 1e3,
-                             "what": "pm_dp_stream_align: pinned host columns in (%.0f MB), scores + paths out (%.0f MB), 8 upload segments; "
+                             "what": "pm_dp_stream_align: pinned host columns in (%.0f MB), scores + paths out (%.0f MB), at most 8 upload segments; "
                                      "best of 3; results equal the resident batch's: %s"
                                      % ((pa.a.nbytes + pb.a.nbytes) / 1e6, po.a.nbytes / 1e6,
                                         bool(np.array_equal(ps.a, r_scores) and np.array_equal(pn.a, r_nops)))}
@@ -694,8 +694,9 @@ def main():
             for name in ("c1", "c2", "deep"):
                 if name == args.config or (name == "c1" and world > 1):
                     continue
+                # (the transfer-inclusive rate for every configuration at N = 1: the host-fed engine orders and tiers a ragged batch itself)
                 rides[name] = bench_dp(args, name, rank, world, local, torch, dist, max(args.steps, 20) if name == "c1" else args.steps,
-                                       args.warmup, name == "c1", name == "c1")
+                                       args.warmup, name == "c1", True)
     main_part = dp if dp is not None else tr
     result.update(main_part)
     if os.environ.get("PM_BENCH_REHEARSAL") == "1":
