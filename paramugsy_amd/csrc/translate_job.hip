@@ -230,16 +230,31 @@ __global__ void __launch_bounds__(SCAN_THREADS) flag_tile_sums_kernel(i64 n, con
   }
 }
 // live_pos[u] = live flags before u (u = 0 .. n_units: the last one is the number of live units); live_units = the live ones in order
+// (the tile through LDS both ways, as in count_scan_kernel below)
+__device__ __forceinline__ int scan_pad(int x) { return x + (x >> 3); }
 __global__ void __launch_bounds__(SCAN_THREADS)
 flag_scan_scatter_kernel(i64 n, i64 n_units, const int *__restrict__ flag, const int *__restrict__ partial, int *__restrict__ live_pos,
                          int *__restrict__ live_units) {
   __shared__ int sh[SCAN_THREADS / 64];
+  __shared__ int sh_f[SCAN_TILE + SCAN_TILE / 8];
+  const i64 base = (i64)blockIdx.x * SCAN_TILE;
+  int g[SCAN_PER];
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) { // asked for before anything waits
+    const i64 k = base + i * SCAN_THREADS + threadIdx.x;
+    g[i] = k < n ? flag[k] : 0;
+  }
   const int before = tiles_before(partial, sh);
-  const i64 first = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_PER;
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    sh_f[scan_pad(i * SCAN_THREADS + (int)threadIdx.x)] = g[i];
+  }
+  __syncthreads();
+  const i64 first = base + (i64)threadIdx.x * SCAN_PER;
   int f[SCAN_PER], sum = 0;
 #pragma unroll
   for(int i = 0; i < SCAN_PER; ++i) {
-    f[i] = first + i < n ? flag[first + i] : 0;
+    f[i] = sh_f[scan_pad((int)threadIdx.x * SCAN_PER + i)];
     sum += f[i];
   }
   int total;
@@ -247,13 +262,19 @@ flag_scan_scatter_kernel(i64 n, i64 n_units, const int *__restrict__ flag, const
 #pragma unroll
   for(int i = 0; i < SCAN_PER; ++i) {
     const i64 u = first + i;
-    if(u < n) {
-      live_pos[u] = at;
-      if(f[i] && u < n_units) {
-        live_units[at] = (int)u;
-      }
+    sh_f[scan_pad((int)threadIdx.x * SCAN_PER + i)] = at; // (the place the thread has just read: nobody else's)
+    if(f[i] && u < n_units && u < n) {
+      live_units[at] = (int)u;
     }
     at += f[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    const i64 k = base + i * SCAN_THREADS + threadIdx.x;
+    if(k < n) {
+      live_pos[k] = sh_f[scan_pad(i * SCAN_THREADS + (int)threadIdx.x)];
+    }
   }
 }
 
@@ -276,31 +297,58 @@ count_tile_sums_kernel(i64 n, const i64 *__restrict__ cnt_ent, const i64 *__rest
     partial[blockIdx.x] = total;
   }
 }
+// (the tile goes through LDS both ways: the global loads and stores are contiguous across the wavefront, a thread's own eight
+// consecutive elements come out of LDS, one element of padding per eight keeping its reads off each other's banks)
 __global__ void __launch_bounds__(SCAN_THREADS)
 count_scan_kernel(i64 n, const i64 *__restrict__ cnt_ent, const i64 *__restrict__ cnt_off, const Sum2 *__restrict__ partial,
                   i64 *__restrict__ ent_off, i64 *__restrict__ off_off) {
   __shared__ Sum2 sh[SCAN_THREADS / 64];
+  __shared__ i64 sh_e[SCAN_TILE + SCAN_TILE / 8], sh_o[SCAN_TILE + SCAN_TILE / 8];
+  const i64 base = (i64)blockIdx.x * SCAN_TILE;
+  i64 ge[SCAN_PER], go[SCAN_PER];
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) { // asked for before anything waits
+    const i64 k = base + i * SCAN_THREADS + threadIdx.x;
+    ge[i] = k < n ? cnt_ent[k] : 0;
+    go[i] = k < n ? cnt_off[k] : 0;
+  }
   const Sum2 before = tiles_before(partial, sh);
-  const i64 first = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_PER;
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    const int x = scan_pad(i * SCAN_THREADS + (int)threadIdx.x);
+    sh_e[x] = ge[i];
+    sh_o[x] = go[i];
+  }
+  __syncthreads();
   i64 ce[SCAN_PER], co[SCAN_PER];
   Sum2 sum{0, 0};
 #pragma unroll
   for(int i = 0; i < SCAN_PER; ++i) {
-    ce[i] = first + i < n ? cnt_ent[first + i] : 0;
-    co[i] = first + i < n ? cnt_off[first + i] : 0;
+    const int x = scan_pad((int)threadIdx.x * SCAN_PER + i);
+    ce[i] = sh_e[x];
+    co[i] = sh_o[x];
     sum.a += ce[i];
     sum.b += co[i];
   }
   Sum2 total;
   Sum2 at = scan_add(before, block_exclusive(sum, sh, total));
 #pragma unroll
-  for(int i = 0; i < SCAN_PER; ++i) {
-    if(first + i < n) {
-      ent_off[first + i] = at.a;
-      off_off[first + i] = at.b;
-    }
+  for(int i = 0; i < SCAN_PER; ++i) { // (a thread rewrites the places it has just read: nobody else's)
+    const int x = scan_pad((int)threadIdx.x * SCAN_PER + i);
+    sh_e[x] = at.a;
+    sh_o[x] = at.b;
     at.a += ce[i];
     at.b += co[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for(int i = 0; i < SCAN_PER; ++i) {
+    const i64 k = base + i * SCAN_THREADS + threadIdx.x;
+    if(k < n) {
+      const int x = scan_pad(i * SCAN_THREADS + (int)threadIdx.x);
+      ent_off[k] = sh_e[x];
+      off_off[k] = sh_o[x];
+    }
   }
 }
 
