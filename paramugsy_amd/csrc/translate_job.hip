@@ -142,8 +142,8 @@ translate_filter_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_unit
   int orientation;
   int st = unit_prefix(left, right, ds, u_delta[u], u_left[u], u_right[u], lp, rp, dr, dq, cols, live, orientation);
   status[u] = st;
-  cnt_ent[u] = 0;
-  cnt_off[u] = 0;
+  // (cnt_ent[u] and cnt_off[u] of a unit that is not live stay what pm_job_create set them to, 0: nothing ever writes them -- the
+  // count pass writes the live units' -- and which units are live follows from the job's tables alone)
   live_flag[u] = (!st && live) ? 1 : 0;
 }
 
