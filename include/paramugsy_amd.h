@@ -146,7 +146,9 @@ int pm_job_algorithmic_bytes(pm_job_t *job, int64_t *bytes);
 int pm_job_kernel_bytes(pm_job_t *job, int64_t *count_bytes, int64_t *emit_bytes, int64_t *n_live);
 /* Width of the coordinate arithmetic the job's kernels run in: 32 when every number in the job's tables is below 2^25
  * in magnitude (the kernels then use int tables and int registers: same results, checked, about twice the resident
- * wavefronts), else 64 (the reference's `long`, lib/profiles_lib/m_range.hh:8).  PM_TRANSLATE_WIDE=1 forces 64. */
+ * wavefronts), else 64 (the reference's `long`, lib/profiles_lib/m_range.hh:8).  PM_TRANSLATE_WIDE=1 forces 64.
+ * (PM_TRANSLATE_LIBRARY_SCANS=1, read at pm_job_create like it: the step's prefix sums through rocPRIM, as jobs above 8.4 M units take
+ * them -- for tests.) */
 int pm_job_coordinate_bits(pm_job_t *job, int *bits);
 void pm_job_destroy(pm_job_t *job);
 
