@@ -401,8 +401,10 @@ __device__ __forceinline__ void state_load(const void *base, i64 n, i64 k, UnitS
 // latency of dependent loads, so resident waves matter more than a few spare registers.
 // I = int (the narrow tables): about 70-80 VGPRs, 6-7 waves per SIMD.  `narrow_trip` is set when a unit's int merge
 // left its checked range (PM_ST_NARROW): pm_job_create then switches the job to the int64 tables.
+// The int64 emit pass needs 162 VGPRs: held to 128 it spilled 38 of them to scratch, in the merge loop -- three waves per SIMD without
+// spills are the faster (the bench job on the int64 tables 0.470 -> 0.396 ms a step; the count pass, 5 spills, is the same either way).
 template <bool EMIT, typename I>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(I) == 8 && EMIT ? 3 : 4, 8)))
 translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                  const int *live_units, const int *live_pos, int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off,
                  const i64 *off_off, typename EntRecT<I>::type *entries, I *offsets, i64 ent_cap, i64 off_cap, int *overflow, void *states,
