@@ -867,8 +867,8 @@ int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int6
   // segments of about equal numbers of columns (A + B), cut at pair boundaries -- but no more of them than leave every fill
   // launch about 5e9 cells: a launch of a few thousand short pairs cannot fill the chip (2.4 wavefronts per SIMD at 2 500 pairs),
   // and four such launches cost more than the upload they hide (10 000 pairs of 2 x 1 kbp: 5.1 ms in four segments, 4.6 in two)
+  double cells = 0;
   {
-    double cells = 0;
     for(int64_t k = 0; k < n_pairs; ++k) {
       cells += (double)(h->off_a[(size_t)k + 1] - h->off_a[(size_t)k]) * (double)(h->off_b[(size_t)k + 1] - h->off_b[(size_t)k]);
     }
@@ -902,6 +902,21 @@ int dp_batch_load_segments_from(pm_dp_batch *h, const int64_t *off_a, const int6
   h->seg_first.assign(1, 0);
   {
     const i64 total = h->total_a + h->total_b;
+    // A large batch (one that runs a chunk per segment, dp_batch_plan_layout) gets a short segment in front, an eighth of the others:
+    // nothing can run before the first segment is up, and an eighth of a segment is still a launch that fills the chip
+    // (a round of stripes for the 4 096 resident wavefronts and a thousand pairs at least -- a launch of a few hundred long pairs is a
+    // poor one: 4 096 pairs of 32 x 10 kbp with 410 in front 143 ms, without 110 -- and at most a quarter of a regular segment)
+    if(segments >= 2 && cells >= 1e11 && h->opt.segment_cells <= 0) {
+      const i64 want = total / ((i64)segments * 8);
+      i64 k = 0, stripes = 0;
+      while(k < n_pairs && (h->off_a[(size_t)k] + h->off_b[(size_t)k] < want || stripes < 4096 || k < 1024)) {
+        stripes += (h->off_b[(size_t)k + 1] - h->off_b[(size_t)k] + 1023) / 1024;
+        ++k;
+      }
+      if(k < n_pairs && h->off_a[(size_t)k] + h->off_b[(size_t)k] <= total / ((i64)segments * 4)) {
+        h->seg_first.push_back(k);
+      }
+    }
     for(int sgi = 1; sgi < segments; ++sgi) {
       const i64 want = total * sgi / segments;
       i64 k = h->seg_first.back();
