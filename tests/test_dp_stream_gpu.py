@@ -97,6 +97,54 @@ def test_ragged_batch_with_tiers_in_a_chunk_per_segment(segments, oracle_build, 
         x.close()
 
 
+def _used_ops_equal(inputs, ops_x, ops_y, n_ops):
+    """The ops of every pair (the right-aligned, used part of its slot) equal in the two arrays, without a Python loop."""
+    end = (inputs.off_a[1:] + inputs.off_b[1:]).astype(np.int64)
+    start = end - n_ops.astype(np.int64)
+    mark = np.zeros(int(end[-1]) + 1, dtype=np.int32)
+    np.add.at(mark, start, 1)
+    np.add.at(mark, end, -1)
+    used = np.cumsum(mark[:-1]) > 0
+    return bool(np.array_equal(ops_x[:len(used)][used], ops_y[:len(used)][used]))
+
+
+@pytest.mark.parametrize("shape", ["uniform", "ragged"])
+def test_large_batches_take_the_engines_own_choices(shape, monkeypatch):
+    """Batches of more than 1e11 cells with the engine's defaults (no segment size forced): a short first segment, a chunk per
+    segment ordered longest first inside, tiers for the ragged one, results leaving chunk by chunk -- every score, path length and
+    op equal to the resident batch's (which tests/test_dp_full_gpu.py holds to the oracle at these sizes)."""
+    import torch
+    from paramugsy_amd.synth_device import synth_batch_device
+    monkeypatch.delenv("PM_DP_SEGMENT_CELLS", raising=False)
+    if shape == "uniform":
+        n, rows = 9000, 2
+        la = lb = np.full(n, 4096, dtype=np.int64)
+    else:
+        n, rows = 52000, 4
+        la, lb = dp.ragged_lengths(31, n)
+    inputs = synth_batch_device(77, la, lb, rows, rows)
+    assert float(np.sum(la.astype(np.float64) * lb)) > 1e11
+    params = dp.make_params(rows, rows)
+    r_scores, r_ops, r_nops = resident(inputs, params)
+    pa, pb = dp.PinnedArray(inputs.cols_a.shape, np.uint8), dp.PinnedArray(inputs.cols_b.shape, np.uint8)
+    pa.a[...] = inputs.cols_a
+    pb.a[...] = inputs.cols_b
+    pin = dp.DpInputs(pa.a, inputs.off_a, pb.a, inputs.off_b)
+    ps, pn = dp.PinnedArray((n,), np.int32), dp.PinnedArray((n,), np.int32)
+    po = dp.PinnedArray((int(inputs.off_a[-1] + inputs.off_b[-1]),), np.uint8)
+    st = dp.DpStream(params, 8)
+    for _ in range(2):
+        ps.a[...] = 0
+        pn.a[...] = 0
+        st.align(pin, ps.a, po.a, pn.a)
+        assert np.array_equal(ps.a, r_scores) and np.array_equal(pn.a, r_nops)
+        assert _used_ops_equal(inputs, po.a, r_ops, r_nops)
+    st.close()
+    for x in (pa, pb, ps, pn, po):
+        x.close()
+    torch.cuda.empty_cache()
+
+
 def test_stream_with_pinned_buffers_and_several_workspace_chunks(oracle_build, monkeypatch):
     monkeypatch.setenv("PM_DP_MODE", "ckpt")
     """Pinned inputs and outputs (the asynchronous case) and a workspace so small that the batch takes several chunks, each of
