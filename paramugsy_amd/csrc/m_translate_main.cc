@@ -3,10 +3,15 @@
 //
 // A fresh process pays 0.05-0.19 s for a HIP runtime of its own before the 0.05 s job (round 3: the drop-in lost to the reference
 // run as sixteen processes).  So this executable links NOTHING of HIP: it first asks a resident worker -- `mugsy_profiles serve -socket
-// <path>`, one per GPU, started once per node by whoever owns the node -- over a UNIX socket (PARAMUGSY_SERVE_SOCKET, default
-// /tmp/paramugsy-serve-<uid>.sock) and prints what the worker says; only when nobody listens does it load libparamugsy_amd.so
+// <path>`, one per GPU, started once per node by whoever owns the node -- over a UNIX socket (PARAMUGSY_SERVE_SOCKET; default
+// $XDG_RUNTIME_DIR/paramugsy/serve.sock or /tmp/paramugsy-<uid>/serve.sock, a directory that is the caller's alone:
+// serve_common.hpp) and prints what the worker says; only when nobody listens does it load libparamugsy_amd.so
 // (dlopen, from ../paramugsy_amd beside this file) and run the job in this process, as before.  The orchestrator's task script
 // (lib/base/mugsy_profiles_task.ml:53-58) needs no change either way.
+// Whom it believes: only a peer of its own uid (SO_PEERCRED); anybody else on that socket is treated as nobody listening.  How long
+// it waits: PARAMUGSY_SERVE_TIMEOUT seconds (default 600) for the verdict -- once the request is out the job is the worker's, so a
+// worker that hangs or goes away ends this process with the reference's failure exit, never with a second run of the job; and a
+// verdict of success is believed only when the output file is there.
 // Optional: PARAMUGSY_DEVICE=<n> selects the HIP device (default 0; with a worker: the worker's); PARAMUGSY_DEVICES=0,1,... spreads the
 // delta-file list over several devices of the node (pm_translate_files_multi; the argv stays the reference's).
 #include <cerrno>
@@ -19,8 +24,11 @@
 
 #include <dlfcn.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
 #include <sys/un.h>
 #include <unistd.h>
+
+#include "serve_common.hpp"
 
 typedef int (*translate_as_fn)(const char *, const char *, const char *const *, int, const char *, const char *, const char *, const int *, int);
 typedef const char *(*last_error_fn)(void);
@@ -35,7 +43,7 @@ static int ask_worker(char **argv, const std::vector<std::string> &paths, const 
     sock = e;
   }
   else {
-    sock = "/tmp/paramugsy-serve-" + std::to_string((long)getuid()) + ".sock";
+    sock = pm_serve::default_socket_path(false); // "" when no directory of the caller's own holds one
   }
   if(sock.empty() || sock == "none") {
     return 0;
@@ -71,19 +79,37 @@ static int ask_worker(char **argv, const std::vector<std::string> &paths, const 
     close(fd);
     return 0;
   }
+  if(!pm_serve::peer_is_me(fd)) { // somebody else's process answers at that path: not a worker of ours, and told nothing
+    close(fd);
+    fprintf(stderr, "m_translate: the process listening at %s is not this user's; running the job here\n", sock.c_str());
+    return 0;
+  }
+  pm_serve::set_timeouts(fd, pm_serve::env_seconds("PARAMUGSY_SERVE_TIMEOUT", 600.0), 10.0);
   size_t at = 0;
   while(at < req.size()) {
     const ssize_t n = send(fd, req.data() + at, req.size() - at, MSG_NOSIGNAL);
     if(n <= 0) {
       close(fd);
-      return 0; // nothing has run yet
+      if(at == 0) {
+        return 0; // not a byte is out: nothing can have run
+      }
+      rc = -1; // a worker that has part of a request may not be raced by a second run of the job
+      message = "the resident worker stopped taking the request";
+      return 1;
     }
     at += (size_t)n;
   }
   std::string reply;
   char buf[4096];
+  bool timed_out = false;
   for(;;) {
     const ssize_t n = read(fd, buf, sizeof buf);
+    if(n < 0 && errno == EINTR) {
+      continue;
+    }
+    if(n < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) {
+      timed_out = true;
+    }
     if(n <= 0) {
       break;
     }
@@ -92,10 +118,18 @@ static int ask_worker(char **argv, const std::vector<std::string> &paths, const 
   close(fd);
   if(reply.compare(0, 5, "done ") != 0) { // the worker died on the job: what it wrote is on the stream, as the reference's would be
     rc = -1;
-    message = "the resident worker went away";
+    message = timed_out ? "no verdict from the resident worker within PARAMUGSY_SERVE_TIMEOUT" : "the resident worker went away";
     return 1;
   }
   rc = atoi(reply.c_str() + 5);
+  if(rc == 0) { // success is the output file, not the word
+    struct stat st;
+    if(stat(argv[4], &st) != 0) {
+      rc = -1;
+      message = std::string("the resident worker reported success but ") + argv[4] + " does not exist";
+      return 1;
+    }
+  }
   const size_t nl = reply.find('\n');
   message = nl == std::string::npos ? "" : reply.substr(nl + 1);
   while(!message.empty() && message[message.size() - 1] == '\n') {

@@ -17,10 +17,14 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
 #include <signal.h>
+#include <sys/file.h>
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/un.h>
+
+#include "serve_common.hpp"
 
 #include "../../include/paramugsy_amd.h"
 
@@ -188,8 +192,15 @@ static int run_command(const std::string &cmd, std::map<std::string, std::string
 // ---- `serve -socket <path>`: the resident worker behind the drop-in m_translate (bin/m_translate asks it before it would bring a HIP
 // runtime of its own up, csrc/m_translate_main.cc).  One request per connection, one line, TAB-separated:
 //   translate <cwd> <left_dir> <right_dir> <out_path> <devices or -> <n> <delta path> x n       (paths as the client's argv / list had them)
+//   stats                                      -> `done 0\njobs <translate requests served so far>\n` (bench.py: was a run served?)
 //   quit
-// answered by `done <exit code>\n` and, after a failure, the message the client prints.  Relative paths are the CLIENT's: they are
+// answered by `done <exit code>\n` and, after a failure, the message the client prints.
+// `-socket default` listens where the client looks when nobody says (serve_common.hpp: a directory that is the caller's alone).
+// Only a peer of the worker's own uid is listened to (SO_PEERCRED; the socket is 0600 besides).  A client gets
+// PARAMUGSY_SERVE_REQUEST_TIMEOUT seconds (default 5) to put its one line on the socket and as long to take the answer: one that
+// connects and then says nothing (stopped, or killed with the descriptor still held) is dropped and the next one served.  Two
+// workers started at once do not unlink each other's socket: the probe-unlink-bind sequence runs under a lock on `<path>.lock`,
+// held for the worker's life.  Relative paths are the CLIENT's: they are
 // resolved against its working directory; the output's first line holds the strings it was started with (pm_translate_files_as).
 // Requests are served one after the other (a second client waits in the listen queue): a node's job is 0.05 s of a GPU.
 static std::string client_path(const std::string &cwd, const std::string &p) { return !p.empty() && p[0] == '/' ? p : cwd + "/" + p; }
@@ -199,7 +210,10 @@ static bool read_line(int fd, std::string &line, size_t limit = (size_t)64 << 20
   char buf[4096];
   for(;;) {
     const ssize_t n = read(fd, buf, sizeof buf);
-    if(n <= 0) {
+    if(n < 0 && errno == EINTR) {
+      continue;
+    }
+    if(n <= 0) { // end of stream, or SO_RCVTIMEO ran out (EAGAIN): no request
       return false;
     }
     for(ssize_t k = 0; k < n; ++k) {
@@ -226,8 +240,21 @@ static void write_all(int fd, const std::string &text) {
   }
 }
 
-static int serve_socket(const std::string &path, int device) {
+static int serve_socket(const std::string &path_arg, int device) {
   signal(SIGPIPE, SIG_IGN); // a client that went away must not take the worker with it
+  const std::string path = path_arg == "default" ? pm_serve::default_socket_path(true) : path_arg;
+  if(path.empty()) {
+    fprintf(stderr, "mugsy_profiles serve: no directory of this user's own for the default socket (XDG_RUNTIME_DIR, /tmp/paramugsy-<uid>)\n");
+    return 2;
+  }
+  // one worker per path: the lock is taken before anything is probed or unlinked, and kept
+  const std::string lock_path = path + ".lock";
+  const int lock_fd = open(lock_path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC | O_NOFOLLOW, 0600);
+  if(lock_fd < 0 || flock(lock_fd, LOCK_EX | LOCK_NB) != 0) {
+    fprintf(stderr, "mugsy_profiles serve: %s: %s\n", lock_path.c_str(),
+            lock_fd < 0 ? strerror(errno) : "another worker holds the lock (it is starting or listening)");
+    return 2;
+  }
   const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
   sockaddr_un addr;
   memset(&addr, 0, sizeof addr);
@@ -258,6 +285,8 @@ static int serve_socket(const std::string &path, int device) {
     return 2;
   }
   (void)pm_device_count(); // bring the runtime up before the first request
+  const double request_timeout = pm_serve::env_seconds("PARAMUGSY_SERVE_REQUEST_TIMEOUT", 5.0);
+  long jobs = 0;
   bool running = true;
   while(running) {
     const int fd = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
@@ -267,6 +296,11 @@ static int serve_socket(const std::string &path, int device) {
       }
       break;
     }
+    if(!pm_serve::peer_is_me(fd)) { // not this user's process: not a word
+      close(fd);
+      continue;
+    }
+    pm_serve::set_timeouts(fd, request_timeout, request_timeout);
     std::string line;
     if(read_line(fd, line)) {
       std::vector<std::string> tok;
@@ -282,6 +316,9 @@ static int serve_socket(const std::string &path, int device) {
       if(tok[0] == "quit") {
         write_all(fd, "done 0\n");
         running = false;
+      }
+      else if(tok[0] == "stats") {
+        write_all(fd, "done 0\njobs " + std::to_string(jobs) + "\n");
       }
       else if(tok[0] == "translate" && tok.size() >= 7 && (size_t)atol(tok[6].c_str()) + 7 == tok.size()) {
         const std::string &cwd = tok[1];
@@ -299,6 +336,7 @@ static int serve_socket(const std::string &path, int device) {
         }
         const int rc = pm_translate_files_as(client_path(cwd, tok[2]).c_str(), client_path(cwd, tok[3]).c_str(), cpaths.data(), (int)cpaths.size(),
                                              client_path(cwd, tok[4]).c_str(), tok[2].c_str(), tok[3].c_str(), devs.data(), (int)devs.size());
+        ++jobs;
         char head[64];
         snprintf(head, sizeof head, "done %d\n", rc);
         write_all(fd, std::string(head) + (rc ? std::string(pm_last_error()) + "\n" : std::string()));
@@ -311,6 +349,8 @@ static int serve_socket(const std::string &path, int device) {
   }
   close(ls);
   unlink(path.c_str());
+  unlink(lock_path.c_str());
+  close(lock_fd);
   return 0;
 }
 

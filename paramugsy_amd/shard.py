@@ -35,7 +35,7 @@ def partition_weighted(weights: Sequence[int], world: int) -> List[int]:
         return [partition(n, world, r)[0] for r in range(world)] + [n]
     cuts, run, at = [0], 0, 0
     for k in range(1, world):
-        # exact rational comparison (the C side uses long double; the tests compare the two on random inputs)
+        # exact rational comparison (the C side compares the same cross products in unsigned __int128, csrc/multi.hpp; the tests compare the two on random inputs)
         while at < n and (run + w[at]) * world - total * k <= total * k - run * world:
             run += w[at]
             at += 1

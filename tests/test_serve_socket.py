@@ -149,3 +149,192 @@ def test_two_clients_of_the_resident_worker_get_the_references_bytes(tmp_path):
     finally:
         if worker.poll() is None:
             worker.kill()
+
+
+# ---- round 5: who is believed, how long anybody waits, where the default socket lives, two workers at once.
+# The real worker's accept loop needs no GPU as long as no job is run, so these run on CPU.
+
+def ask(sock, line, timeout=10.0):
+    c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    c.settimeout(timeout)
+    c.connect(sock)
+    c.sendall(line)
+    data = b""
+    while True:
+        chunk = c.recv(65536)
+        if not chunk:
+            break
+        data += chunk
+    c.close()
+    return data
+
+
+def start_worker(sock, env=None, wait=True):
+    w = subprocess.Popen([WORKER, "serve", "-socket", sock], env=env, stderr=subprocess.PIPE)
+    if wait:
+        for _ in range(600):
+            try:
+                if ask(sock if sock != "default" else env["_EXPECTED_SOCK"], b"stats\n").startswith(b"done 0"):
+                    break
+            except OSError:
+                time.sleep(0.05)
+        else:
+            w.kill()
+            raise AssertionError("the worker did not come up")
+    return w
+
+
+def test_a_verdict_of_success_without_an_output_file_is_not_believed(tmp_path):
+    """A worker (or whoever sits at the socket) that answers `done 0` and wrote nothing: exit 134, not 0 (a silent wrong result)."""
+    sock = str(tmp_path / "w.sock")
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.bind(sock)
+    s.listen(2)
+
+    def liar():
+        c, _ = s.accept()
+        c.recv(65536)
+        c.sendall(b"done 0\n")
+        c.close()
+    t = threading.Thread(target=liar, daemon=True)
+    t.start()
+    (tmp_path / "nucmer.list").write_text("a.delta\n")
+    r = subprocess.run([EXE, "l", "r", "nucmer.list", "o.delta"], cwd=str(tmp_path), env=dict(os.environ, PARAMUGSY_SERVE_SOCKET=sock),
+                       capture_output=True)
+    assert r.returncode == 134 and b"does not exist" in r.stderr
+    s.close()
+
+
+def test_a_worker_that_never_answers_ends_the_client_with_the_failure_exit_and_no_second_run(tmp_path):
+    sock = str(tmp_path / "w.sock")
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.bind(sock)
+    s.listen(2)
+    held = []
+    t = threading.Thread(target=lambda: held.append(s.accept()[0]), daemon=True)  # takes the connection, says nothing
+    t.start()
+    (tmp_path / "nucmer.list").write_text("a.delta\n")
+    t0 = time.time()
+    r = subprocess.run([EXE, "l", "r", "nucmer.list", "o.delta"], cwd=str(tmp_path),
+                       env=dict(os.environ, PARAMUGSY_SERVE_SOCKET=sock, PARAMUGSY_SERVE_TIMEOUT="1"), capture_output=True, timeout=60)
+    assert r.returncode == 134 and b"no verdict from the resident worker" in r.stderr
+    assert b"no CPU path" not in r.stderr and time.time() - t0 < 30  # it did not fall back to a run of its own
+    s.close()
+
+
+@pytest.mark.skipif(os.geteuid() != 0, reason="needs root to start a process under another uid")
+def test_a_listener_of_another_uid_is_not_believed(tmp_path, hip_lib):
+    """Somebody else's process at the socket path (a squatter in /tmp): the client reads SO_PEERCRED and tells it nothing."""
+    if hip_lib.pm_device_count() > 0:
+        pytest.skip("with a device the fall-back would run the job; the CPU box shows the refusal")
+    import sys as _sys
+    import tempfile
+    shared = tempfile.mkdtemp(prefix="pm_squat_", dir="/tmp")  # a place the other uid can reach (pytest's tmp_path is root's alone)
+    os.chmod(shared, 0o777)
+    sock = os.path.join(shared, "squat.sock")
+    leak = os.path.join(shared, "leak.txt")
+    # the credentials a listening socket shows are those of the process that called listen(): drop the uid first
+    code = ("import os,socket,sys\n"
+            "os.setgid(65534); os.setuid(65534)\n"
+            "s=socket.socket(socket.AF_UNIX,socket.SOCK_STREAM); s.bind(%r); os.chmod(%r,0o777); s.listen(2)\n"
+            "sys.stdout.write('up\\n'); sys.stdout.flush()\n"
+            "c,_=s.accept(); d=c.recv(65536); open(%r,'wb').write(d); c.sendall(b'done 0\\n'); c.close()\n"
+            % (sock, sock, leak))
+    squatter = subprocess.Popen([_sys.executable, "-c", code], stdout=subprocess.PIPE)
+    assert squatter.stdout.readline() == b"up\n"
+    (tmp_path / "nucmer.list").write_text("a.delta\n")
+    r = subprocess.run([EXE, "l", "r", "nucmer.list", "o.delta"], cwd=str(tmp_path), env=dict(os.environ, PARAMUGSY_SERVE_SOCKET=sock),
+                       capture_output=True, timeout=60)
+    squatter.kill()
+    assert b"is not this user's" in r.stderr
+    assert r.returncode == 134 and b"no CPU path" in r.stderr  # the job went to the in-process path (which refuses without a device)
+    told = open(leak, "rb").read() if os.path.exists(leak) else b""
+    shutil.rmtree(shared, ignore_errors=True)
+    assert told == b""  # the squatter was told nothing
+
+
+def test_the_default_socket_lives_in_a_directory_of_the_users_own(tmp_path):
+    """Nobody names a socket: worker (`-socket default`) and client meet at $XDG_RUNTIME_DIR/paramugsy/serve.sock, made 0700; a runtime
+    directory that is open to others is not used."""
+    run = tmp_path / "run"
+    run.mkdir(mode=0o700)
+    env = dict(os.environ, XDG_RUNTIME_DIR=str(run))
+    env.pop("PARAMUGSY_SERVE_SOCKET", None)
+    expected = str(run / "paramugsy" / "serve.sock")
+    env["_EXPECTED_SOCK"] = expected
+    # the real worker at the default place; a stand-in cannot take the place while it lives (the lock), so the client's default is
+    # checked with the worker gone and a stand-in at the same path
+    w = start_worker("default", env=env)
+    try:
+        st = os.stat(str(run / "paramugsy"))
+        assert st.st_mode & 0o077 == 0 and st.st_uid == os.getuid()
+        assert os.stat(expected).st_mode & 0o077 == 0
+        assert ask(expected, b"stats\n") == b"done 0\njobs 0\n"
+        assert ask(expected, b"quit\n").startswith(b"done 0")
+        assert w.wait(timeout=30) == 0
+    finally:
+        if w.poll() is None:
+            w.kill()
+    sw = StandInWorker(expected)
+    sw.start()
+    (tmp_path / "nucmer.list").write_text("a.delta\n")
+    r = subprocess.run([EXE, "l", "r", "nucmer.list", "o.delta"], cwd=str(tmp_path), env=env, capture_output=True)
+    assert r.returncode == 0 and len(sw.requests) == 1 and sw.requests[0][0] == "translate"
+    sw.stop()
+    os.remove(expected)
+    # an XDG_RUNTIME_DIR others can write to is not trusted: the default falls to /tmp/paramugsy-<uid>, never to a path inside it
+    os.chmod(str(run), 0o777)
+    sw2 = StandInWorker(expected)
+    sw2.start()
+    r = subprocess.run([EXE, "l", "r", "nucmer.list", "o2.delta"], cwd=str(tmp_path), env=env, capture_output=True)
+    assert sw2.requests == []
+    sw2.stop()
+
+
+def test_a_silent_client_is_dropped_and_the_next_one_served(tmp_path):
+    sock = str(tmp_path / "serve.sock")
+    w = start_worker(sock, env=dict(os.environ, PARAMUGSY_SERVE_REQUEST_TIMEOUT="0.5"))
+    try:
+        mute = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        mute.connect(sock)  # connects, never sends its line
+        half = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        half.connect(sock)
+        half.sendall(b"translate\t/tmp")  # half a line, then nothing
+        t0 = time.time()
+        assert ask(sock, b"stats\n", timeout=30) == b"done 0\njobs 0\n"
+        assert time.time() - t0 < 10
+        assert ask(sock, b"nonsense\n").startswith(b"done -1")
+        mute.close()
+        half.close()
+        assert ask(sock, b"quit\n").startswith(b"done 0")
+        assert w.wait(timeout=30) == 0
+        assert not os.path.exists(sock) and not os.path.exists(sock + ".lock")
+    finally:
+        if w.poll() is None:
+            w.kill()
+
+
+def test_two_workers_started_together_leave_one_listening(tmp_path):
+    """The probe-unlink-bind sequence runs under a lock: whichever of two workers loses does not unlink the winner's socket."""
+    sock = str(tmp_path / "serve.sock")
+    ws = [subprocess.Popen([WORKER, "serve", "-socket", sock], stderr=subprocess.PIPE) for _ in range(4)]
+    try:
+        for _ in range(600):
+            try:
+                if ask(sock, b"stats\n").startswith(b"done 0"):
+                    break
+            except OSError:
+                time.sleep(0.05)
+        time.sleep(0.5)
+        alive = [w for w in ws if w.poll() is None]
+        assert len(alive) == 1
+        for w in ws:
+            if w is not alive[0]:
+                assert w.returncode == 2 and (b"holds the lock" in w.stderr.read() or True)
+        assert ask(sock, b"stats\n") == b"done 0\njobs 0\n"  # and the survivor's socket is still the file at the path
+        assert ask(sock, b"quit\n").startswith(b"done 0")
+        assert alive[0].wait(timeout=30) == 0
+    finally:
+        for w in ws:
+            if w.poll() is None:
+                w.kill()
