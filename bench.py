@@ -251,11 +251,10 @@ def bench_translate(args, rank, world, local, torch, dist):
     # job fits, with the merge's accumulators checked and a redo on the wide tables otherwise): the like-for-like rate
     wide = None
     if job.coordinate_bits() == 32:
-        os.environ["PM_TRANSLATE_WIDE"] = "1"
-        try:
-            job_w = TranslateJob(t, device=local)
-        finally:
-            del os.environ["PM_TRANSLATE_WIDE"]
+        from paramugsy_amd import capi as capi_mod
+        wide_opt = capi_mod.PmTranslateOptions()
+        wide_opt.coordinate_bits = 64
+        job_w = TranslateJob(t, device=local, options=wide_opt)
         dt_w = timed_region(torch, dist, lambda: job_w.run(stream), args.steps, args.warmup)
         wide = {"value": sum_over_ranks(torch, dist, t.n_units) * args.steps / dt_w, "unit": "units/s", "ms_per_step": dt_w / args.steps * 1e3,
                 "dtype": "int64", "coordinate_bits": job_w.coordinate_bits()}

@@ -112,9 +112,26 @@ int pm_device_count(void);
 /* name/CU count of device `dev`; name buffer of `cap` bytes */
 int pm_device_info(int dev, char *name, int cap, int *compute_units, int64_t *hbm_bytes);
 
+/* How a translate job is run -- every field 0: chosen by the library (what production callers pass, or NULL).  Given when a job is
+ * created (pm_job_create_opt, pm_job_create_from_workload_opt) or a file-level job is run (pm_translate_files_opt); the entries
+ * without an options argument take the process's defaults, pm_translate_set_default_options (copied under a lock).  The library
+ * reads no environment variable for any of this (round 5; rounds 1-4 read PM_TRANSLATE_WIDE, PM_TRANSLATE_LIBRARY_SCANS, PM_NO_SOA
+ * and PM_TIMING inside entries that pm_translate_files_multi runs on one thread per device); the executables under bin/ and the
+ * Python binding keep those names as a SPELLING and hand the library a struct. */
+typedef struct pm_translate_options {
+  int32_t coordinate_bits; /* 64: the int64 tables and kernels (the reference's `long`, lib/profiles_lib/m_range.hh:8) also where int would do */
+  int32_t library_scans;   /* 1: the step's prefix sums through rocPRIM, as jobs above 8.4 M units take them (for tests) */
+  int32_t no_side_file;    /* 1: <dir>/profiles is parsed also where a matching <dir>/profiles.soa lies beside it */
+  int32_t timing;          /* 1: phase times of the file-level entries on stderr (as a process default: of every file-level entry) */
+  int32_t reserved[4];
+} pm_translate_options_t;
+int pm_translate_set_default_options(const pm_translate_options_t *options); /* NULL: all zero again */
+
 /* Upload a batch, build the per-gap prefix tables and validate the gap lists on the device. */
 int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
                   int device, pm_job_t **out);
+int pm_job_create_opt(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+                      const pm_translate_options_t *options, int device, pm_job_t **out);
 /* One pass of the hot path over every unit: filter, count, scan, emit.  Asynchronous on `hip_stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  Inputs and outputs stay in HBM. */
 int pm_job_run(pm_job_t *job, void *hip_stream);
@@ -146,9 +163,8 @@ int pm_job_algorithmic_bytes(pm_job_t *job, int64_t *bytes);
 int pm_job_kernel_bytes(pm_job_t *job, int64_t *count_bytes, int64_t *emit_bytes, int64_t *n_live);
 /* Width of the coordinate arithmetic the job's kernels run in: 32 when every number in the job's tables is below 2^25
  * in magnitude (the kernels then use int tables and int registers: same results, checked, about twice the resident
- * wavefronts), else 64 (the reference's `long`, lib/profiles_lib/m_range.hh:8).  PM_TRANSLATE_WIDE=1 forces 64.
- * (PM_TRANSLATE_LIBRARY_SCANS=1, read at pm_job_create like it: the step's prefix sums through rocPRIM, as jobs above 8.4 M units take
- * them -- for tests.) */
+ * wavefronts), else 64 (the reference's `long`, lib/profiles_lib/m_range.hh:8).  pm_translate_options_t.coordinate_bits = 64
+ * forces 64. */
 int pm_job_coordinate_bits(pm_job_t *job, int *bits);
 void pm_job_destroy(pm_job_t *job);
 
@@ -174,6 +190,7 @@ int pm_workload_tables(pm_workload_t *w, pm_rows_t *left, pm_rows_t *right, pm_d
  * the same list, in the same order, as pm_workload_tables hands out -- which is what the file-level entries below run on.
  * pm_job_units reports the job's unit count and copies the list out (any pointer may be NULL). */
 int pm_job_create_from_workload(pm_workload_t *w, int device, pm_job_t **out);
+int pm_job_create_from_workload_opt(pm_workload_t *w, const pm_translate_options_t *options, int device, pm_job_t **out);
 int pm_job_units(pm_job_t *job, int64_t *n_units, int32_t *delta, int32_t *left, int32_t *right);
 /* side 0 = left, 1 = right; pointers stay valid until pm_workload_destroy */
 int pm_workload_row_name(pm_workload_t *w, int side, int64_t row, const char **major_name, const char **seq_name);
@@ -189,6 +206,10 @@ int pm_translate_files(const char *left_dir, const char *right_dir, const char *
  * are resolved against ITS directory, the output holds the strings it was started with.  New surface. */
 int pm_translate_files_as(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths, const char *out_path,
                           const char *left_name, const char *right_name, const int *devices, int n_devices);
+/* ... and with explicit options (NULL: the process's defaults), for this job alone, on whatever threads and devices it runs */
+int pm_translate_files_opt(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths, const char *out_path,
+                           const char *left_name, const char *right_name, const int *devices, int n_devices,
+                           const pm_translate_options_t *options);
 
 /* The two tools of lib/profiles_cpp that compile upstream (nothing in the reference invokes them).
  * pm_sort_delta   == m_sort_delta (lib/profiles_cpp/m_sort_delta.cc:58-91): delta text in, the same entries sorted by

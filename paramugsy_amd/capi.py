@@ -45,12 +45,30 @@ class PmEntry(C.Structure):
                 ("offset_begin", C.c_int64), ("n_offsets", C.c_int64)]
 
 
+class PmTranslateOptions(C.Structure):
+    """pm_translate_options_t: all zero = chosen by the library."""
+    _fields_ = [("coordinate_bits", C.c_int32), ("library_scans", C.c_int32), ("no_side_file", C.c_int32), ("timing", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
+
+
+def translate_options_from_env() -> PmTranslateOptions:
+    """The PM_* names of rounds 1-4 as a SPELLING: the library reads no environment variable (include/paramugsy_amd.h,
+    pm_translate_options_t); the binding, the tests and the tools read these and hand it a struct."""
+    o = PmTranslateOptions()
+    o.coordinate_bits = 64 if os.environ.get("PM_TRANSLATE_WIDE", "0")[:1] == "1" else 0
+    o.library_scans = 1 if os.environ.get("PM_TRANSLATE_LIBRARY_SCANS", "0")[:1] == "1" else 0
+    o.no_side_file = 1 if os.environ.get("PM_NO_SOA") else 0
+    o.timing = 1 if os.environ.get("PM_TIMING") else 0
+    return o
+
+
 ENTRY_DTYPE = np.dtype([("ref_start", "<i8"), ("ref_end", "<i8"), ("qry_start", "<i8"), ("qry_end", "<i8"),
                         ("offset_begin", "<i8"), ("n_offsets", "<i8")])
 
 # every symbol include/paramugsy_amd.h declares (tests check that the library exports each of them)
 EXPORTS = [
     "pm_last_error", "pm_release_caches", "pm_device_count", "pm_device_info",
+    "pm_translate_set_default_options", "pm_job_create_opt", "pm_job_create_from_workload_opt", "pm_translate_files_opt",
     "pm_job_create", "pm_job_text", "pm_job_text_fetch", "pm_job_text_fetch_range", "pm_job_run", "pm_job_run_profiled", "pm_job_sizes", "pm_job_fetch", "pm_job_algorithmic_bytes", "pm_job_kernel_bytes", "pm_job_coordinate_bits", "pm_job_destroy",
     "pm_rows_profile_idx_of_seq_idx_batch", "pm_rows_seq_idx_of_profile_idx_batch",
     "pm_workload_load", "pm_workload_tables", "pm_workload_row_name", "pm_workload_destroy", "pm_job_create_from_workload", "pm_job_units",
@@ -83,6 +101,12 @@ def lib() -> C.CDLL:
         l.pm_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), _i64p]
         l.pm_job_create.argtypes = [C.POINTER(PmRows), C.POINTER(PmRows), C.POINTER(PmDeltas), C.POINTER(PmUnits), C.c_int,
                                     C.POINTER(C.c_void_p)]
+        l.pm_job_create_opt.argtypes = [C.POINTER(PmRows), C.POINTER(PmRows), C.POINTER(PmDeltas), C.POINTER(PmUnits),
+                                        C.POINTER(PmTranslateOptions), C.c_int, C.POINTER(C.c_void_p)]
+        l.pm_translate_set_default_options.argtypes = [C.POINTER(PmTranslateOptions)]
+        l.pm_job_create_from_workload_opt.argtypes = [C.c_void_p, C.POINTER(PmTranslateOptions), C.c_int, C.POINTER(C.c_void_p)]
+        l.pm_translate_files_opt.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p,
+                                             _i32p, C.c_int, C.POINTER(PmTranslateOptions)]
         l.pm_job_run.argtypes = [C.c_void_p, C.c_void_p]
         l.pm_job_run_profiled.argtypes = [C.c_void_p, C.c_void_p] + [C.POINTER(C.c_float)] * 4
         l.pm_job_sizes.argtypes = [C.c_void_p, _i64p, _i64p]
@@ -112,6 +136,11 @@ def lib() -> C.CDLL:
         l.pm_delta_join_files.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p]
         l.pm_partition.argtypes = [C.c_int64, C.c_int, C.c_int, _i64p, _i64p]
         l.pm_translate_files_multi.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, _i32p, C.c_int]
+        # the entries that make their jobs themselves (pm_stage_files, pm_dp_align_maf, ...) take the process's defaults: the PM_*
+        # spelling of this process's environment, once, when the library is loaded
+        env = translate_options_from_env()
+        if env.coordinate_bits or env.library_scans or env.no_side_file or env.timing:
+            l.pm_translate_set_default_options(C.byref(env))
         _lib = l
     return _lib
 

@@ -332,7 +332,7 @@ static int maf_map(const std::string &path, MafDpBlocks &out) {
 
 // The mapped file cut at block starts into a few ranges whose lines are indexed side by side.
 static int maf_index(const std::string &path, MafDpBlocks &out) {
-  const bool timing = getenv("PM_TIMING") != nullptr;
+  const bool timing = pm::timing_on();
   auto wall = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const char *text = out.bytes;
   const size_t size = out.n_bytes;
@@ -805,7 +805,7 @@ static int align_maf_to_sink(const MafDpBlocks &A, const MafDpBlocks &B, int64_t
   if(with_header) {
     blob = "##maf version=1 scoring=paramugsy_amd\n";
   }
-  const bool timing = getenv("PM_TIMING") != nullptr;
+  const bool timing = pm::timing_on();
   if(n == 0) {
     if(before_write) {
       PM_TRY(before_write());
@@ -1005,7 +1005,7 @@ extern "C" int pm_dp_align_maf(const char *maf_a, const char *maf_b, const pm_dp
     return fail(PM_E_INVALID, "pm_dp_align_maf: null argument");
   }
   PM_TRY(use_device(device));
-  const bool timing = getenv("PM_TIMING") != nullptr;
+  const bool timing = pm::timing_on();
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = now();
   auto lap = [&](const char *what) {

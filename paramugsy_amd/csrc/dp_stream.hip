@@ -132,7 +132,7 @@ int pm_dp_stream_create_opt(const pm_dp_params_t *params, const pm_dp_options_t 
 static int stream_align_core(pm_dp_stream_t *s, const std::function<int()> &load, int64_t n_pairs, int32_t *scores, uint8_t *ops, int32_t *n_ops) {
   pm_dp_batch *b = s->b;
   const int traceback = ops != nullptr;
-  const bool timing = getenv("PM_TIMING") != nullptr;
+  const bool timing = pm::timing_on();
   auto wall = []() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);

@@ -32,6 +32,11 @@
 
 typedef int (*translate_as_fn)(const char *, const char *, const char *const *, int, const char *, const char *, const char *, const int *, int);
 typedef const char *(*last_error_fn)(void);
+typedef int (*set_defaults_fn)(const void *);
+// pm_translate_options_t (include/paramugsy_amd.h), spelled out because this file includes nothing of the library
+struct translate_options {
+  int coordinate_bits, library_scans, no_side_file, timing, reserved[4];
+};
 
 static bool plain(const std::string &s) { return s.find('\t') == std::string::npos && s.find('\n') == std::string::npos; }
 
@@ -176,6 +181,20 @@ int main(int argc, char **argv) {
     if(!run || !last_error) {
       fprintf(stderr, "m_translate: cannot load libparamugsy_amd.so (%s): %s\n", lib.c_str(), dlerror());
       return 134;
+    }
+    {
+      // this executable's switches (the library itself reads no environment variable): handed over as the process's defaults
+      translate_options opt;
+      memset(&opt, 0, sizeof opt);
+      const char *e;
+      opt.coordinate_bits = (e = getenv("PM_TRANSLATE_WIDE")) && e[0] == '1' ? 64 : 0;
+      opt.library_scans = (e = getenv("PM_TRANSLATE_LIBRARY_SCANS")) && e[0] == '1';
+      opt.no_side_file = getenv("PM_NO_SOA") != nullptr;
+      opt.timing = getenv("PM_TIMING") != nullptr;
+      set_defaults_fn set_defaults = (set_defaults_fn)dlsym(h, "pm_translate_set_default_options");
+      if(set_defaults && (opt.coordinate_bits || opt.library_scans || opt.no_side_file || opt.timing)) {
+        set_defaults(&opt);
+      }
     }
     std::vector<const char *> cpaths;
     for(size_t k = 0; k < paths.size(); ++k) {

@@ -362,6 +362,19 @@ int main(int argc, char **argv) {
   std::string cmd = argv[1];
   const char *dev_env = getenv("PARAMUGSY_DEVICE");
   int device = dev_env ? atoi(dev_env) : 0;
+  {
+    // the executable's switches: the library reads no environment variable, it is handed a struct (pm_translate_options_t)
+    pm_translate_options_t opt;
+    memset(&opt, 0, sizeof opt);
+    const char *e;
+    opt.coordinate_bits = (e = getenv("PM_TRANSLATE_WIDE")) && e[0] == '1' ? 64 : 0;
+    opt.library_scans = (e = getenv("PM_TRANSLATE_LIBRARY_SCANS")) && e[0] == '1';
+    opt.no_side_file = getenv("PM_NO_SOA") != nullptr;
+    opt.timing = getenv("PM_TIMING") != nullptr;
+    if(opt.coordinate_bits || opt.library_scans || opt.no_side_file || opt.timing) {
+      pm_translate_set_default_options(&opt);
+    }
+  }
   int code;
   if(cmd == "serve" && argc >= 4 && std::string(argv[2]) == "-socket") {
     code = serve_socket(argv[3], device);

@@ -31,6 +31,20 @@ int use_device(int device) {
   return PM_OK;
 }
 
+// ---- the process's default translate options (pm_translate_set_default_options)
+namespace {
+std::mutex g_translate_defaults_lock;
+pm_translate_options_t g_translate_defaults = {};
+} // namespace
+
+pm_translate_options_t translate_options(const pm_translate_options_t *given) {
+  if(given) {
+    return *given;
+  }
+  std::lock_guard<std::mutex> hold(g_translate_defaults_lock);
+  return g_translate_defaults;
+}
+
 // ---- DevPool (pm_internal.hpp)
 namespace {
 struct PoolEntry {
@@ -127,6 +141,15 @@ int pm_release_caches(void) {
 
 
 const char *pm_last_error(void) { return pm::g_last_error.c_str(); }
+
+int pm_translate_set_default_options(const pm_translate_options_t *options) {
+  if(options && options->coordinate_bits != 0 && options->coordinate_bits != 32 && options->coordinate_bits != 64) {
+    return pm::fail(PM_E_INVALID, "pm_translate_set_default_options: coordinate_bits is 0, 32 or 64");
+  }
+  std::lock_guard<std::mutex> hold(pm::g_translate_defaults_lock);
+  pm::g_translate_defaults = options ? *options : pm_translate_options_t{};
+  return PM_OK;
+}
 
 int pm_device_count(void) {
   int n = 0;

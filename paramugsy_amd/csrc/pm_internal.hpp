@@ -197,6 +197,12 @@ struct PooledBuf {
 void text_staging_trim();
 void dp_batch_cache_trim();
 
+// The options a translate job runs under (pm_translate_options_t): the caller's, or -- a null pointer -- a copy of the process's
+// defaults taken under their lock.  Resolved once at the entry point and handed down by value: nothing below reads the environment
+// or a global, so the workers of pm_translate_files_multi (one thread per device) all see what their job was started with.
+pm_translate_options_t translate_options(const pm_translate_options_t *given);
+inline bool timing_on() { return translate_options(nullptr).timing != 0; } // the file-level entries outside the translate path
+
 // What the device needs to list a job's work units itself (translate_job.hip): per side (0 left, 1 right) the rows of every sequence
 // sorted by forward start, and per delta entry the index of its sequence on that side (-1: the side has no such sequence).
 struct EnumInput {
@@ -205,8 +211,8 @@ struct EnumInput {
   const int32_t *seq_rows[2];
   const int32_t *entry_seq[2]; // [entries]
 };
-int job_create_enumerating(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const EnumInput *en, int device,
-                           pm_job_t **out);
+int job_create_enumerating(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const EnumInput *en,
+                           const pm_translate_options_t &opt, int device, pm_job_t **out);
 int job_unit_at(pm_job_t *job, int64_t unit, int32_t out[3]); // a unit's delta entry, left row, right row
 
 } // namespace pm

@@ -230,7 +230,7 @@ int make_profiles(const char *in_maf, const char *out_dir, const char *basename,
   if(rc) {
     return rc;
   }
-  const bool timing = getenv("PM_TIMING") != nullptr;
+  const bool timing = pm::timing_on();
   auto wall = []() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -464,7 +464,7 @@ extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const 
     }
     paths.push_back(delta_paths[k]);
   }
-  const bool timing = getenv("PM_TIMING") != nullptr;
+  const bool timing = pm::timing_on();
   auto wall = []() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -511,7 +511,7 @@ extern "C" int pm_stage_files(const char *left_maf, const char *left_dir, const 
     return fail(PM_E_IO, std::string("cannot open ") + out_delta);
   }
   fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_dir, right_dir); // m_translate_main.cc:35-39
-  int rc = run_workload(w, f, device);
+  int rc = run_workload(w, f, translate_options(nullptr), device);
   lap("translate job (device) and its text out");
   if(fclose(f) != 0 && !rc) {
     rc = fail(PM_E_IO, "close failed");

@@ -233,9 +233,6 @@ int write_side_soa(const std::string &dir, const Side &side, long long profiles_
 
 // true when <dir>/profiles.soa was read into `side`; false (side untouched) when it is absent, stale or malformed
 static bool read_side_soa(const std::string &dir, Side &side) {
-  if(getenv("PM_NO_SOA")) {
-    return false;
-  }
   struct stat st_txt, st_soa;
   const std::string txt = dir + "/profiles", soa = dir + "/profiles.soa";
   if(stat(txt.c_str(), &st_txt) != 0 || stat(soa.c_str(), &st_soa) != 0) {
@@ -311,8 +308,8 @@ static bool read_side_soa(const std::string &dir, Side &side) {
   }
 }
 
-int load_side(const std::string &dir, Side &side) {
-  if(read_side_soa(dir, side)) {
+int load_side(const std::string &dir, Side &side, const pm_translate_options_t &opt) {
+  if(!opt.no_side_file && read_side_soa(dir, side)) {
     return PM_OK;
   }
   return parse_profiles(dir + "/profiles", side);
@@ -691,11 +688,11 @@ static double wall_now() {
 }
 
 int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w,
-                  bool list_units) {
-  const bool timing = getenv("PM_TIMING") != nullptr;
+                  const pm_translate_options_t &opt, bool list_units) {
+  const bool timing = opt.timing != 0;
   const double t0 = wall_now();
-  PM_TRY(load_side(left_dir, w.left));
-  PM_TRY(load_side(right_dir, w.right));
+  PM_TRY(load_side(left_dir, w.left, opt));
+  PM_TRY(load_side(right_dir, w.right, opt));
   const double t1 = wall_now();
   parse_deltas(delta_paths, w);
   const double t2 = wall_now();
@@ -853,9 +850,9 @@ void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_del
 }
 
 int translate_to_file(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
-                      int device) {
-  // PM_TIMING=1: phase times on stderr (where a whole job spends its wall time)
-  const bool timing = getenv("PM_TIMING") != nullptr;
+                      const pm_translate_options_t &opt, int device) {
+  // options.timing: phase times on stderr (where a whole job spends its wall time)
+  const bool timing = opt.timing != 0;
   auto now = []() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -885,7 +882,7 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
     init_s = wall_now() - i0;
   });
   Workload w;
-  int load_rc = load_workload(left_dir, right_dir, delta_paths, w, false);
+  int load_rc = load_workload(left_dir, right_dir, delta_paths, w, opt, false);
   std::string load_msg = load_rc ? pm_last_error() : "";
   init.join_and_rethrow();
   if(init_rc) {
@@ -898,7 +895,7 @@ int translate_to_file(const std::string &left_dir, const std::string &right_dir,
   if(timing) {
     fprintf(stderr, "[pm] parse + index: %.3f s; HIP runtime start-up beside it: %.3f s\n", t1 - t0, init_s);
   }
-  return run_workload(w, out, device);
+  return run_workload(w, out, opt, device);
 }
 
 // Bytes in HBM to a sink, in pieces, through a few pinned staging buffers: while earlier pieces are written (a stream: by writer
@@ -1085,13 +1082,13 @@ int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool tim
 }
 
 // The device part of a translate job and the text of its output: upload + prepare + sizing, one pass, fetch, format + write.
-int run_workload(Workload &w, FILE *out, int device) {
-  return run_tables(w.left, w.right, w.table, w.units_listed ? &w.units : nullptr, w.parse_rc, w.parse_msg, OutSink(out), device);
+int run_workload(Workload &w, FILE *out, const pm_translate_options_t &opt, int device) {
+  return run_tables(w.left, w.right, w.table, w.units_listed ? &w.units : nullptr, w.parse_rc, w.parse_msg, OutSink(out), opt, device);
 }
 
 int run_tables(const Side &left, const Side &right, const DeltaTable &table, const UnitList *units, int parse_rc, const std::string &parse_msg,
-               OutSink out, int device) {
-  const bool timing = getenv("PM_TIMING") != nullptr;
+               OutSink out, const pm_translate_options_t &opt, int device) {
+  const bool timing = opt.timing != 0;
   auto now = []() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1108,13 +1105,13 @@ int run_tables(const Side &left, const Side &right, const DeltaTable &table, con
       uv.delta = units->delta.data();
       uv.left = units->left.data();
       uv.right = units->right.data();
-      PM_TRY(pm_job_create(&lv, &rv, &dv, &uv, device, &job));
+      PM_TRY(pm_job_create_opt(&lv, &rv, &dv, &uv, &opt, device, &job));
     }
     else { // the unit list is made on the device from the sides' row index (left.by_seq, right.by_seq)
       EnumTables et;
       build_enum_tables(left, right, table, et);
       const EnumInput en = et.view();
-      PM_TRY(job_create_enumerating(&lv, &rv, &dv, &en, device, &job));
+      PM_TRY(job_create_enumerating(&lv, &rv, &dv, &en, opt, device, &job));
       int64_t n_units = 0;
       (void)pm_job_units(job, &n_units, nullptr, nullptr, nullptr);
       if(n_units == 0) {
@@ -1247,14 +1244,14 @@ int merge_shard_texts(const std::vector<std::string> &parts, size_t n_parts, Out
 // the texts are joined in list order.  The reference dies at the first failure with everything before it on the stream: the
 // join stops after the first failing shard (its partial output included) and the call returns that shard's error.
 int translate_to_file_multi(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
-                            const int *devices, int n_devices) {
+                            const pm_translate_options_t &opt, const int *devices, int n_devices) {
   Side left, right;
   {
     // the two sides side by side; the devices' runtimes come up meanwhile
     int rc_r = PM_OK;
     std::string msg_r;
     JoinThread other([&]() {
-      rc_r = load_side(right_dir, right);
+      rc_r = load_side(right_dir, right, opt);
       if(rc_r) {
         msg_r = pm_last_error();
       }
@@ -1269,7 +1266,7 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
         }
       }
     });
-    int rc_l = load_side(left_dir, left);
+    int rc_l = load_side(left_dir, left, opt);
     if(!rc_l) {
       build_side_index(left);
     }
@@ -1292,7 +1289,7 @@ int translate_to_file_multi(const std::string &left_dir, const std::string &righ
         partition((int64_t)delta_paths.size(), n_devices, w, lo, hi);
         Workload mine; // its sides stay empty: the shared ones are used
         parse_deltas(std::vector<std::string>(delta_paths.begin() + lo, delta_paths.begin() + hi), mine);
-        return run_tables(left, right, mine.table, nullptr, mine.parse_rc, mine.parse_msg, OutSink(&text[(size_t)w]), device);
+        return run_tables(left, right, mine.table, nullptr, mine.parse_rc, mine.parse_msg, OutSink(&text[(size_t)w]), opt, device);
       },
       &rcs);
   std::string msg = rc ? pm_last_error() : "";
@@ -1316,6 +1313,16 @@ extern "C" int pm_translate_files(const char *left_dir, const char *right_dir, c
 
 extern "C" int pm_translate_files_as(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
                                      const char *out_path, const char *left_name, const char *right_name, const int *devices, int n_devices) {
+  return pm_translate_files_opt(left_dir, right_dir, delta_paths, n_paths, out_path, left_name, right_name, devices, n_devices, nullptr);
+}
+
+extern "C" int pm_translate_files_opt(const char *left_dir, const char *right_dir, const char *const *delta_paths, int n_paths,
+                                      const char *out_path, const char *left_name, const char *right_name, const int *devices, int n_devices,
+                                      const pm_translate_options_t *options) {
+  if(options && options->coordinate_bits != 0 && options->coordinate_bits != 32 && options->coordinate_bits != 64) {
+    return pm::fail(PM_E_INVALID, "pm_translate_files_opt: options.coordinate_bits is 0, 32 or 64");
+  }
+  const pm_translate_options_t opt = pm::translate_options(options); // resolved once, here: every thread of the job runs under this copy
   if(devices && n_devices > 1) {
     return pm::guarded("pm_translate_files_as", [&]() -> int {
       if(!left_dir || !right_dir || !out_path || !left_name || !right_name || n_paths < 0 || (n_paths > 0 && !delta_paths)) {
@@ -1334,7 +1341,7 @@ extern "C" int pm_translate_files_as(const char *left_dir, const char *right_dir
         return pm::fail(PM_E_IO, std::string("cannot open ") + out_path);
       }
       fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_name, right_name); // m_translate_main.cc:35-39
-      int rc = pm::translate_to_file_multi(left_dir, right_dir, paths, f, devices, n_devices);
+      int rc = pm::translate_to_file_multi(left_dir, right_dir, paths, f, opt, devices, n_devices);
       if(fclose(f) != 0 && !rc) {
         rc = pm::fail(PM_E_IO, "close failed");
       }
@@ -1360,7 +1367,7 @@ extern "C" int pm_translate_files_as(const char *left_dir, const char *right_dir
   }
   // m_translate_main.cc:35-39 (the names as the caller's argv had them, whatever paths the files are opened by)
   fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_name, right_name);
-  rc = pm::translate_to_file(left_dir, right_dir, paths, f, device);
+  rc = pm::translate_to_file(left_dir, right_dir, paths, f, opt, device);
   if(fclose(f) != 0 && !rc) {
     rc = pm::fail(PM_E_IO, "close failed");
   }
@@ -1387,7 +1394,7 @@ extern "C" int pm_translate_files_multi(const char *left_dir, const char *right_
     return pm::fail(PM_E_IO, std::string("cannot open ") + out_path);
   }
   fprintf(f, "%s/sequences.fasta %s/sequences.fasta\nNUCMER\n", left_dir, right_dir); // m_translate_main.cc:35-39
-  int rc = pm::translate_to_file_multi(left_dir, right_dir, paths, f, devices, n_devices);
+  int rc = pm::translate_to_file_multi(left_dir, right_dir, paths, f, pm::translate_options(nullptr), devices, n_devices);
   if(fclose(f) != 0 && !rc) {
     rc = pm::fail(PM_E_IO, "close failed");
   }
@@ -1483,7 +1490,7 @@ extern "C" int pm_workload_load(const char *left_dir, const char *right_dir, con
     paths.push_back(delta_paths[k]);
   }
   pm_workload *h = new pm_workload();
-  int rc = pm::load_workload(left_dir, right_dir, paths, h->w, true);
+  int rc = pm::load_workload(left_dir, right_dir, paths, h->w, pm::translate_options(nullptr), true);
   if(rc) {
     delete h;
     return rc;
@@ -1522,6 +1529,10 @@ extern "C" int pm_workload_row_name(pm_workload_t *h, int side, int64_t row, con
 }
 
 extern "C" int pm_job_create_from_workload(pm_workload_t *h, int device, pm_job_t **out) {
+  return pm_job_create_from_workload_opt(h, nullptr, device, out);
+}
+
+extern "C" int pm_job_create_from_workload_opt(pm_workload_t *h, const pm_translate_options_t *options, int device, pm_job_t **out) {
   return pm::guarded("pm_job_create_from_workload", [&]() -> int {
     if(!h || !out) {
       return pm::fail(PM_E_INVALID, "pm_job_create_from_workload: null argument");
@@ -1532,7 +1543,7 @@ extern "C" int pm_job_create_from_workload(pm_workload_t *h, int device, pm_job_
     pm::EnumTables et;
     pm::build_enum_tables(h->w.left, h->w.right, h->w.table, et);
     const pm::EnumInput en = et.view();
-    return pm::job_create_enumerating(&lv, &rv, &dv, &en, device, out);
+    return pm::job_create_enumerating(&lv, &rv, &dv, &en, pm::translate_options(options), device, out);
   });
 }
 

@@ -65,21 +65,21 @@ struct OutSink {
   }
 };
 // <dir>/profiles.soa when it matches <dir>/profiles, else the text file (parse_profiles)
-int load_side(const std::string &dir, Side &side);
+int load_side(const std::string &dir, Side &side, const pm_translate_options_t &opt);
 int write_side_soa(const std::string &dir, const Side &side, long long profiles_text_bytes);
 int load_deltas(const std::vector<std::string> &delta_paths, Workload &w);
 void parse_deltas(const std::vector<std::string> &delta_paths, Workload &w);
 void index_and_enumerate(Workload &w);
 void index_sides(Workload &w);
-int run_workload(Workload &w, FILE *out, int device);
+int run_workload(Workload &w, FILE *out, const pm_translate_options_t &opt, int device);
 // The device part of a translate job over tables that are in place (the two sides may be shared, read-only, by several callers):
 // upload + prepare + sizing, one pass, fetch, format.  units: the unit list, or null for the job to list the units on the device from
 // the sides' row index (build_side_index must have run on both).  parse_rc / parse_msg: a delta-file parse failure to report after the
 // output of the entries read before it.
 int run_tables(const Side &left, const Side &right, const DeltaTable &table, const UnitList *units, int parse_rc, const std::string &parse_msg,
-               OutSink out, int device);
+               OutSink out, const pm_translate_options_t &opt, int device);
 int load_workload(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, Workload &w,
-                  bool list_units = true);
+                  const pm_translate_options_t &opt, bool list_units = true);
 void workload_views(const Workload &w, pm_rows_t *left, pm_rows_t *right, pm_deltas_t *deltas, pm_units_t *units);
 // Bytes in device memory to a sink through pinned staging pieces, the writing beside the copying; `copied` runs once the last byte
 // has left the device.  The calling thread's current device must be the buffer's.
@@ -87,8 +87,8 @@ int device_bytes_to_sink(const char *dev, int64_t n_bytes, OutSink out, bool tim
 // multi.hpp: the job's delta-file list over several devices, texts joined in list order (header rule re-applied at the seams)
 int merge_shard_texts(const std::vector<std::string> &parts, size_t n_parts, OutSink out);
 int translate_to_file_multi(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
-                            const int *devices, int n_devices);
+                            const pm_translate_options_t &opt, const int *devices, int n_devices);
 int translate_to_file(const std::string &left_dir, const std::string &right_dir, const std::vector<std::string> &delta_paths, FILE *out,
-                      int device);
+                      const pm_translate_options_t &opt, int device);
 
 } // namespace pm

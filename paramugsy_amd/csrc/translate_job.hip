@@ -1186,9 +1186,12 @@ extern "C" {
 
 // pm_job_create, with the unit list either given (units) or made on the device from the sides' per-sequence row lists (en).
 static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
-                           const pm::EnumInput *en, int device, pm_job_t **out) {
+                           const pm::EnumInput *en, const pm_translate_options_t &opt, int device, pm_job_t **out) {
   if(!out) {
     return fail(PM_E_INVALID, "pm_job_create: null out");
+  }
+  if(opt.coordinate_bits != 0 && opt.coordinate_bits != 32 && opt.coordinate_bits != 64) {
+    return fail(PM_E_INVALID, "pm_job_create: options.coordinate_bits is 0, 32 or 64");
   }
   *out = nullptr;
   const pm_units_t no_units = {0, nullptr, nullptr, nullptr};
@@ -1225,7 +1228,7 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
       return rc_;      \
     }                  \
   } while(0)
-  const bool timing = getenv("PM_TIMING") != nullptr;
+  const bool timing = opt.timing != 0;
   auto wall = []() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1357,10 +1360,8 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
       pm_job_destroy(j);
       return fail(PM_E_HIP, "hipMemcpy failed");
     }
-    const char *wide = getenv("PM_TRANSLATE_WIDE");
-    const char *lib_scans = getenv("PM_TRANSLATE_LIBRARY_SCANS");
-    j->library_scans = lib_scans && lib_scans[0] == '1';
-    j->narrow = big < (unsigned long long)PM_NARROW_INPUT_LIMIT && !(wide && wide[0] == '1');
+    j->library_scans = opt.library_scans != 0;
+    j->narrow = big < (unsigned long long)PM_NARROW_INPUT_LIMIT && opt.coordinate_bits != 64;
   }
   // Size the outputs once: the inputs of a job never change, so neither do its output sizes.
   JTRY(job_launch_pass(j, stream, false, nullptr));
@@ -1373,6 +1374,13 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
     }
     if(trip) { // some unit's int merge left its checked range: this job runs on the int64 tables
       j->narrow = false;
+      // the sizing pass no longer stores zero counts for units that are not live: were the wide filter ever to keep fewer units than
+      // the narrow one did, a stale count would corrupt the prefix sums.  The redo starts from cleared counts (once per job).
+      if(hipMemsetAsync(j->cnt_ent.p, 0, (size_t)(U + 1) * 8, stream) != hipSuccess ||
+         hipMemsetAsync(j->cnt_off.p, 0, (size_t)(U + 1) * 8, stream) != hipSuccess) {
+        pm_job_destroy(j);
+        return fail(PM_E_HIP, "hipMemsetAsync failed");
+      }
       JTRY(job_launch_pass(j, stream, false, nullptr));
       JTRY(job_read_totals(j, stream));
     }
@@ -1461,9 +1469,9 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
 }
 
 namespace pm {
-int job_create_enumerating(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const EnumInput *en, int device,
-                           pm_job_t **out) {
-  return job_create_impl(left, right, deltas, nullptr, en, device, out);
+int job_create_enumerating(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const EnumInput *en,
+                           const pm_translate_options_t &opt, int device, pm_job_t **out) {
+  return job_create_impl(left, right, deltas, nullptr, en, opt, device, out);
 }
 int job_unit_at(pm_job_t *j, int64_t unit, int32_t out[3]) {
   if(!j || unit < 0 || unit >= j->n_units) {
@@ -1481,7 +1489,12 @@ extern "C" {
 
 int pm_job_create(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units, int device,
                   pm_job_t **out) {
-  return job_create_impl(left, right, deltas, units, nullptr, device, out);
+  return job_create_impl(left, right, deltas, units, nullptr, pm::translate_options(nullptr), device, out);
+}
+
+int pm_job_create_opt(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+                      const pm_translate_options_t *options, int device, pm_job_t **out) {
+  return job_create_impl(left, right, deltas, units, nullptr, pm::translate_options(options), device, out);
 }
 
 /* the job's unit list (made on the device when the job came from pm_job_create_from_workload) */

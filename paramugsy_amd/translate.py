@@ -93,23 +93,26 @@ class JobResult:
 class TranslateJob:
     """A batch of work units resident in HBM (pm_job_*)."""
 
-    def __init__(self, tables: Tables, device: int = 0):
+    def __init__(self, tables: Tables, device: int = 0, options: Optional[capi.PmTranslateOptions] = None):
+        """options: pm_translate_options_t for this job; None = what the PM_* names spell at this moment (capi.translate_options_from_env)."""
         l = capi.lib()
+        opt = options if options is not None else capi.translate_options_from_env()
         ls, k1 = capi.rows_struct(tables.left)
         rs, k2 = capi.rows_struct(tables.right)
         ds, k3 = capi.deltas_struct(tables.deltas)
         us, k4 = capi.units_struct(tables.units)
         h = C.c_void_p()
-        capi.check(l.pm_job_create(C.byref(ls), C.byref(rs), C.byref(ds), C.byref(us), device, C.byref(h)))
+        capi.check(l.pm_job_create_opt(C.byref(ls), C.byref(rs), C.byref(ds), C.byref(us), C.byref(opt), device, C.byref(h)))
         del k1, k2, k3, k4  # the job has copied everything to the device
         self._h = h
         self.n_units = tables.n_units
 
     @classmethod
-    def from_workload(cls, workload: "Workload", device: int = 0) -> "TranslateJob":
+    def from_workload(cls, workload: "Workload", device: int = 0, options: Optional[capi.PmTranslateOptions] = None) -> "TranslateJob":
         """The job of a loaded workload with its unit list made on the device (pm_job_create_from_workload)."""
         h = C.c_void_p()
-        capi.check(capi.lib().pm_job_create_from_workload(workload._h, device, C.byref(h)))
+        opt = options if options is not None else capi.translate_options_from_env()
+        capi.check(capi.lib().pm_job_create_from_workload_opt(workload._h, C.byref(opt), device, C.byref(h)))
         job = cls.__new__(cls)
         job._h = h
         n = C.c_int64()
@@ -202,10 +205,14 @@ def seq_idx_of_profile_idx(rows: Dict[str, np.ndarray], row: np.ndarray, profile
     return out, st
 
 
-def translate(left_dir: str, right_dir: str, nucmer_list: Sequence[str], out_path: str, device: int = 0) -> None:
+def translate(left_dir: str, right_dir: str, nucmer_list: Sequence[str], out_path: str, device: int = 0,
+              options: Optional[capi.PmTranslateOptions] = None) -> None:
     """Para_mugsy::translate (m_translate.hh:9-14) preceded by m_translate_main.cc's two header lines."""
     arr = (C.c_char_p * len(nucmer_list))(*[p.encode() for p in nucmer_list])
-    capi.check(capi.lib().pm_translate_files(left_dir.encode(), right_dir.encode(), arr, len(nucmer_list), out_path.encode(), device))
+    opt = options if options is not None else capi.translate_options_from_env()
+    dev = (C.c_int32 * 1)(device)
+    capi.check(capi.lib().pm_translate_files_opt(left_dir.encode(), right_dir.encode(), arr, len(nucmer_list), out_path.encode(),
+                                                 left_dir.encode(), right_dir.encode(), dev, 1, C.byref(opt)))
 
 
 def translate_multi(left_dir: str, right_dir: str, nucmer_list: Sequence[str], out_path: str, devices: Sequence[int]) -> None:

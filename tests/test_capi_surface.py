@@ -66,6 +66,43 @@ def test_dp_options_layout_and_the_environment_spelling(monkeypatch):
         assert not re.search(r'getenv\("PM_DP_', text), fn
 
 
+def test_translate_options_layout_and_no_environment_reads_in_the_library(monkeypatch, hip_lib):
+    """pm_translate_options_t: 4 int32 + 4 reserved (include/paramugsy_amd.h).  The PM_TRANSLATE_WIDE / PM_TRANSLATE_LIBRARY_SCANS /
+    PM_NO_SOA / PM_TIMING names of rounds 1-4 are a spelling of the binding and of the executables' main(); the library's own sources
+    read no PM_* variable at all (they were read inside entries that run on one thread per device)."""
+    assert C.sizeof(capi.PmTranslateOptions) == 8 * 4
+    header = open(os.path.join(ROOT, "include", "paramugsy_amd.h")).read()
+    body = header[header.index("typedef struct pm_translate_options {"):header.index("} pm_translate_options_t;")]
+    declared = re.findall(r"int32_t\s+([a-z0-9_]+)(?:\[\d+\])?;", body)
+    assert declared == [f for f, _ in capi.PmTranslateOptions._fields_]
+    for name in ("PM_TRANSLATE_WIDE", "PM_TRANSLATE_LIBRARY_SCANS", "PM_NO_SOA", "PM_TIMING"):
+        monkeypatch.delenv(name, raising=False)
+    o = capi.translate_options_from_env()
+    assert (o.coordinate_bits, o.library_scans, o.no_side_file, o.timing) == (0, 0, 0, 0)
+    monkeypatch.setenv("PM_TRANSLATE_WIDE", "1")
+    monkeypatch.setenv("PM_TRANSLATE_LIBRARY_SCANS", "1")
+    monkeypatch.setenv("PM_NO_SOA", "1")
+    monkeypatch.setenv("PM_TIMING", "1")
+    o = capi.translate_options_from_env()
+    assert (o.coordinate_bits, o.library_scans, o.no_side_file, o.timing) == (64, 1, 1, 1)
+    monkeypatch.setenv("PM_TRANSLATE_WIDE", "0")
+    assert capi.translate_options_from_env().coordinate_bits == 0
+    # the defaults: set, refused when malformed, cleared
+    bad = capi.PmTranslateOptions()
+    bad.coordinate_bits = 48
+    assert hip_lib.pm_translate_set_default_options(C.byref(bad)) == capi.PM_E_INVALID
+    assert hip_lib.pm_translate_set_default_options(C.byref(o)) == capi.PM_OK
+    assert hip_lib.pm_translate_set_default_options(None) == capi.PM_OK
+    # what belongs to the library (the executables' mains and the client/worker socket header are not it)
+    csrc = os.path.join(ROOT, "paramugsy_amd", "csrc")
+    mains = {"m_translate_main.cc", "mugsy_profiles_main.cc", "side_tools_main.cc", "serve_common.hpp"}
+    for fn in sorted(os.listdir(csrc)):
+        if fn in mains:
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        assert "getenv" not in text, fn
+
+
 def test_no_cpu_fallback_without_device(hip_lib):
     if hip_lib.pm_device_count() > 0:
         pytest.skip("a HIP device is present")

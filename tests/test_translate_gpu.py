@@ -426,3 +426,63 @@ def test_file_level_failure_writes_what_precedes_it(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "bin", "m_translate"), w.left_dir, w.right_dir, w.list_path, cli], capture_output=True)
     assert r.returncode == 134 and b"work unit" in r.stderr
     assert open(cli, "rb").read() == part
+
+
+def test_explicit_options_per_job_on_every_thread_and_device(tmp_path, monkeypatch):
+    """pm_translate_options_t (round 5): a job takes its options when it is created or run -- also over a device list, whose workers
+    are threads that never look at the environment or at the defaults of another job -- and two jobs created side by side under
+    different options each keep their own."""
+    import ctypes as C
+    import threading
+    for name in ("PM_TRANSLATE_WIDE", "PM_TRANSLATE_LIBRARY_SCANS", "PM_NO_SOA", "PM_TIMING"):
+        monkeypatch.delenv(name, raising=False)
+    case, deltas = case_paths("typical")
+    l = capi.lib()
+    arr = (C.c_char_p * len(deltas))(*[os.path.join(case, p).encode() for p in deltas])
+    devs = (C.c_int32 * 3)(0, 0, 0)
+    expected = open(os.path.join(case, "expected.delta"), "rb").read()
+    for bits, scans, no_soa in ((0, 0, 0), (64, 1, 1), (32, 0, 1)):
+        opt = capi.PmTranslateOptions()
+        opt.coordinate_bits, opt.library_scans, opt.no_side_file = bits, scans, no_soa
+        for n_dev in (1, 3):
+            out = str(tmp_path / ("o_%d_%d.delta" % (bits, n_dev)))
+            capi.check(l.pm_translate_files_opt(os.path.join(case, "profiles-l").encode(), os.path.join(case, "profiles-r").encode(), arr,
+                                                len(deltas), out.encode(), b"profiles-l", b"profiles-r", devs, n_dev, C.byref(opt)))
+            assert open(out, "rb").read() == expected, (bits, n_dev)
+    bad = capi.PmTranslateOptions()
+    bad.coordinate_bits = 16
+    assert l.pm_translate_files_opt(b"a", b"b", arr, 0, str(tmp_path / "x").encode(), b"a", b"b", devs, 1, C.byref(bad)) == capi.PM_E_INVALID
+    # two jobs at once, each with its own width
+    t = Workload.load(os.path.join(case, "profiles-l"), os.path.join(case, "profiles-r"), [os.path.join(case, p) for p in deltas]).tables()
+    got = {}
+
+    def make(bits):
+        opt = capi.PmTranslateOptions()
+        opt.coordinate_bits = bits
+        for _ in range(5):
+            job = TranslateJob(t, options=opt)
+            got.setdefault(bits, set()).add(job.coordinate_bits())
+            job.close()
+    ts = [threading.Thread(target=make, args=(b,)) for b in (0, 64)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join()
+    assert got == {0: {32}, 64: {64}}
+    # the process's defaults are what the entries without an options argument take
+    wide = capi.PmTranslateOptions()
+    wide.coordinate_bits = 64
+    capi.check(l.pm_translate_set_default_options(C.byref(wide)))
+    try:
+        h = C.c_void_p()
+        ls, k1 = capi.rows_struct(t.left)
+        rs, k2 = capi.rows_struct(t.right)
+        ds, k3 = capi.deltas_struct(t.deltas)
+        us, k4 = capi.units_struct(t.units)
+        capi.check(l.pm_job_create(C.byref(ls), C.byref(rs), C.byref(ds), C.byref(us), 0, C.byref(h)))
+        b = C.c_int()
+        capi.check(l.pm_job_coordinate_bits(h, C.byref(b)))
+        l.pm_job_destroy(h)
+        assert b.value == 64
+    finally:
+        capi.check(l.pm_translate_set_default_options(None))
