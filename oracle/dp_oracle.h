@@ -18,6 +18,17 @@
  *   ties:   H prefers diagonal, then E, then F;  E and F prefer opening (from H) over extending.
  *   path    ops from (0,0) to (La,Lb): 0 = M (one column of each), 1 = I (column of B against a gap),
  *           2 = D (column of A against a gap).
+ *
+ * The same WITHOUT matrices (round 5; tests/dp_bruteforce.py writes every alignment of tiny pairs out and holds this file to it):
+ *   score   = max over all op strings of  sum of s(i,j) over the M's  -  sum over MAXIMAL runs of I's and of D's of
+ *             (gap_open + (len - 1) * gap_extend);  an I run directly followed by a D run is two runs, two openings.
+ *   path    = label every gap column as opening its run or extending it; read the optimal labelled strings from the END; the one
+ *             reported is the smallest in lexicographic order under  M < I-open < I-extend < D-open < D-extend.
+ *   Two corners, stated so that nobody has to find them again:
+ *   - the boundary rows H[0][j], H[i][0] are ONE run from the origin (labels forced: open, extend, extend, ...);
+ *   - gap_open < gap_extend (allowed by the limits, used by no scoring scheme): inside the matrix a run may re-open instead of
+ *     extending (E takes max(E - ge, H - go) and H may itself have come from E), so a run of n costs go + (n-1) * min(go, ge)
+ *     there, while the boundary keeps go + (n-1) * ge.  For gap_open >= gap_extend the maximum is the textbook affine optimum.
  */
 #ifndef DP_ORACLE_H
 #define DP_ORACLE_H
