@@ -278,7 +278,8 @@ typedef struct pm_dp_options {
   int32_t slots;           /* 2..8 parts of the path workspace that the chunks of a batch that does not fit use in turn (default 3) */
   int32_t split;           /* N >= 1: a batch that fits is cut into N chunks all the same (default: 1 or 2, by the size of its walk) */
   int32_t no_gate;         /* 1: a chunk's fill kernel is not held back until the chunk before has nothing left to dispatch */
-  int32_t reserved;
+  int32_t tile_steps;      /* 1: no launch takes its work from a queue of tiles; a multiple of 64: every checkpoint / score launch does, in
+                            * tiles of that many steps (default: launches of few long pairs, 1 024 steps) */
   int64_t segment_cells;   /* host-fed engine: no more upload segments than leave each this many cells (default 5e9) */
 } pm_dp_options_t;
 /* The defaults batches are created with when no options are given (NULL: all zero again).  Copied under a lock. */

@@ -5,10 +5,20 @@
 #include <hip/hip_runtime.h>
 
 #include <functional>
+#include <memory>
 #include <vector>
 
 #include "dp_internal.hpp"
 #include "pm_internal.hpp"
+
+// A fill launch that takes its work from a queue of tiles (dp_fill_tiles_kernel): the list, made once per layout for the launch of
+// the pairs at positions [first, first + n), and what its wavefronts share while they run
+struct DpTilePlan {
+  pm::i64 first = 0, n = 0;
+  int tile_steps = 0;
+  pm::i64 n_tiles = 0, total_stripes = 0;
+  pm::DevBuf tiles, sync_off, sync_words, state;
+};
 
 struct pm_dp_batch {
   int device = 0;
@@ -33,6 +43,7 @@ struct pm_dp_batch {
   bool ckpt = true;       // paths from checkpoints + block recomputation (dp_walk.hip), or 4 stored decision bits per cell
   bool mode_auto = true;  // ckpt chosen per batch in dp_batch_plan (opt.path_mode fixes it)
   int walk_lanes = 0;     // lanes per pair of the checkpoint walk; 0 = chosen per launch; opt.walk_lanes overrides
+  std::vector<std::unique_ptr<DpTilePlan> > tile_plans; // of this layout's launches (dp_batch_plan_layout forgets them)
   pm::DevBuf pipe_error;
   // progress words of pairs whose stripes run on several workgroups (dp_fill_kernel, NG): an arena sized by dp_run for all the
   // launches of a pass, every launch taking a piece of its own (launches of one pass may overlap on their streams)
@@ -71,6 +82,10 @@ struct pm_dp_batch {
   hipEvent_t ev_begin = nullptr;
   std::vector<hipEvent_t> ev_fill, ev_path;                       // per chunk: fill done / path done
   std::vector<hipEvent_t> tv_fill0, tv_fill1, tv_path0, tv_path1; // timing events of the profiled run
+  // ... and of the tiers' fill kernels (three pairs per chunk, on the tiers' own streams): the launches the step waits for -- without
+  // them the profiled run's fill time, its fill-busy union and bench.py's roofline left the longest pairs' kernels out
+  std::vector<hipEvent_t> tv_tier0, tv_tier1;
+  std::vector<int> tv_tier_chunk; // which chunk each recorded pair of this pass belongs to (size = pairs recorded)
   // dp_stream.hip: the columns arrive in segments of consecutive pairs (seg_first: first pair of each, plus n_pairs); ev_seg[k]
   // fires on the upload stream when segment k is in HBM; dp_batch_plan cuts such a batch into chunks that end where segments end
   // (a small one: one chunk, which dp_run launches segment by segment), dp_run holds a chunk's launch back until its segment is up
@@ -82,7 +97,7 @@ struct pm_dp_batch {
   size_t pinned_bytes = 0;
   int host_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   ~pm_dp_batch() {
-    for(std::vector<hipEvent_t> *v : {&ev_fill, &ev_path, &tv_fill0, &tv_fill1, &tv_path0, &tv_path1, &ev_seg}) {
+    for(std::vector<hipEvent_t> *v : {&ev_fill, &ev_path, &tv_fill0, &tv_fill1, &tv_path0, &tv_path1, &ev_seg, &tv_tier0, &tv_tier1}) {
       for(hipEvent_t e : *v) {
         if(e) {
           (void)hipEventDestroy(e);

@@ -111,25 +111,33 @@ __host__ __device__ inline i64 dp_fill_cost(i64 la, i64 lb, int C, int tail) {
 // Words (4 bytes) of checkpoint storage one pair needs:
 //   col[group][t]     int2 {H~ - gop, E~} of the group's last column after the row its last lane was on at step t
 //   row[stripe][m][j] int2 {H~ - gop, F~} of column j of the stripe after its lane's (m + 1)-th checkpoint step
+// Round 5: every store of a checkpoint is a whole, ALIGNED 128-byte line.  A pair's workspace is a multiple of 128 bytes (so every
+// pair's begins on a line: the chunks' bases are multiples of 256), a group's column checkpoints are dp_ck_stride(la) entries apart
+// -- the steps rounded up to 16, the entries of one 128-byte store -- and the row checkpoints begin on a line and give every lane of
+// the fill kernel a line-aligned run of its own (below).  Until then a 128-byte store of column checkpoints straddled two lines
+// ((la + 63) * 8 is a multiple of 128 for no length anybody uses), and the 64-byte write requests HBM saw were 1.22 x the bytes.
 __host__ __device__ inline i64 dp_ck_steps(i64 la) { return la + 63; }
+__host__ __device__ inline i64 dp_ck_stride(i64 la) { return (la + 63 + 15) & ~(i64)15; }
 __host__ __device__ inline i64 dp_ck_nck(i64 la) { return (la + 63) / DP_CK_R; }
 __host__ __device__ inline i64 dp_ck_groups(i64 lb, int C, int tail) { return dp_padded_cols(lb, C, tail) / (DP_CK_W * C); }
 __host__ __device__ inline i64 dp_ck_words(i64 la, i64 lb, int C, int tail) {
-  return dp_ck_groups(lb, C, tail) * dp_ck_steps(la) * 2 + dp_ck_nck(la) * dp_padded_cols(lb, C, tail) * 2;
+  return (dp_ck_groups(lb, C, tail) * dp_ck_stride(la) * 2 + dp_ck_nck(la) * dp_padded_cols(lb, C, tail) * 2 + 31) & ~(i64)31;
 }
 // column checkpoint of column group g (written by the last lane of the group) at step t.  Layout [group][step]: the steps of one
 // group are contiguous, which is how all three readers go through them (the next stripe's seam: lane 63's group, 64 rows at a
 // time; the walk's left edge: one group, the rows of a block); the writer's 16 lanes hit 16 lines per step, each line completed
 // by 16 consecutive steps while it sits in L2.  ([step][group] made the seam read 8 bytes of every 128-byte line: 20 GB of
 // FETCH_SIZE on the headline batch.)
-__host__ __device__ inline i64 dp_ck_col_word(i64 la, i64 g, i64 t) { return (g * dp_ck_steps(la) + t) * 2; }
-// row checkpoint m of column j, which lies in stripe st: [stripe][m][c][lane] with c = the column's place in its lane.  Lane-minor,
-// so that the fill kernel's store of one c is 64 consecutive 8-byte slots (whole lines); [lane][c] made every lane write a line of
-// its own, 8 bytes at a time -- HBM bytes are the same, L2 write requests four times as many, and those are what the fill kernel
-// runs short of (round 4: 2 048 -> 320 requests per wavefront and 64 steps, with the column checkpoints' staging below)
+__host__ __device__ inline i64 dp_ck_col_word(i64 la, i64 g, i64 t) { return (g * dp_ck_stride(la) + t) * 2; }
+// row checkpoint m of column j, which lies in stripe st: [stripe][m][lane][c] with c = the column's place in its lane -- a lane's cs
+// columns are cs * 8 consecutive bytes: one line with 16 columns a lane, written by that lane alone in ONE step (16-byte stores
+// back to back), so the line is whole when it leaves L2, and the walk's top edge is the consecutive lines of the block's lanes.
+// History: round 3 had this order with 8-byte stores; round 4 turned it lane-minor ([c][lane]: a store of one c then covers 64
+// consecutive slots -- but only every fourth lane stores at a step, the lanes of a group being one step apart, so every line was
+// filled in four steps a few microseconds apart and left L2 in pieces: WRITE_SIZE 1.22 x the checkpoints, profiles/r04_store_ablation.txt).
 __host__ __device__ inline i64 dp_ck_row_word(i64 la, i64 lb, int C, int tail, DpStripe st, i64 m, i64 j) {
-  const int r = (int)(j - st.jb), sh = dp_cs_shift(st.cs);
-  return dp_ck_groups(lb, C, tail) * dp_ck_steps(la) * 2 + ((i64)st.jb * dp_ck_nck(la) + m * 64 * st.cs + (r & (st.cs - 1)) * 64 + (r >> sh)) * 2;
+  const int r = (int)(j - st.jb);
+  return dp_ck_groups(lb, C, tail) * dp_ck_stride(la) * 2 + ((i64)st.jb * dp_ck_nck(la) + m * 64 * st.cs + r) * 2;
 }
 // the first fill lane of column group g (in the stripe it lies in), and the lanes of a group there
 __host__ __device__ inline int dp_group_lane0(int C, DpStripe st, i64 g) { return ((int)g * DP_CK_W * C - st.jb) >> dp_cs_shift(st.cs); }

@@ -71,7 +71,7 @@ __host__ __device__ inline i64 dp_tb_words(i64 la, i64 lb, int C) {
 // What a pair's stripes share (uniform over the wavefront).
 struct DpFillPair {
   const u64 *A, *B;
-  int la, lb, steps, tiles, n_stripes, gop, ge;
+  int la, lb, steps, cstride, tiles, n_stripes, gop, ge; // cstride: entries between two groups' column checkpoints (dp_ck_stride)
   unsigned *tbp;   // the pair's workspace: decision bits, or checkpoints
   int2 *bp;        // bits / score mode: the seam, one {H~ - gop, E~} per row of A
   i64 row_base;    // checkpoint mode: word offset of the row checkpoints in the workspace
@@ -79,6 +79,15 @@ struct DpFillPair {
   int ng, team, tw;
   int *gp;         // ng > 1: the pair's progress words in global memory
   int *pipe_error;
+  // tiles (dp_fill_tiles_kernel): this call runs the 64-step blocks [t_begin, t_end) of the stripe and hands the lanes' state on
+  int t_begin, t_end;
+  unsigned *state; // the stripe's lane state between two tiles: [dword][lane], 2 C + 4 dwords
+  int *tdone;      // steps of the stripe done and saved so far
+};
+
+// One work item of dp_fill_tiles_kernel: the blocks [t_begin, t_end) of stripe s of the pair at position pos of the launch.
+struct DpTile {
+  int pos, s, t_begin, t_end;
 };
 
 // One stripe of a pair: 64 lanes x CS columns of B from column st.jb on, against all rows of A.  C is the batch's columns per lane
@@ -94,11 +103,18 @@ struct DpFillPair {
 //     DPP instructions' `old` operand with the lane's read of its row -- no v_readlane / v_writelane per step;
 //   * a block is always 64 steps (the steps behind the stripe's last have an empty EXEC mask), so the step loop has a constant
 //     trip count and unrolls by four with its LDS and checkpoint addresses as immediate offsets.
-template <int C, int CS, int MODE, bool DOT4, int NW, bool UNI>
+// TILED (dp_fill_tiles_kernel): the call runs only the blocks [pp.t_begin, pp.t_end) of the stripe.  What a lane carries from block to
+// block -- hop[], f[], e, dn_last and the boundary's hl_carry: 2 CS + 3 dwords -- is loaded from pp.state at the start (after the
+// tile before has published it: pp.tdone) and stored there at the end; A's 64 rows before the first block are staged again (the
+// lanes right of lane 0 are still on them).  Everything the wavefront shares with other wavefronts then goes the way it goes between
+// the workgroups of a pair (ng > 1): progress words in global memory, the seam read and written past the XCD's L2.
+template <int C, int CS, int MODE, bool DOT4, int NW, bool UNI, bool TILED = false>
 __device__ __forceinline__ void dp_fill_stripe(const DpFillPair &pp, const DpParamsD &P, const int s, const DpStripe st, int4 *ring, int4 *sbnd,
                                                int2 *cstage, unsigned *tbstage, int *progress, const int wv, const int lane, int &result) {
   constexpr bool TRACE = MODE == DP_MODE_BITS;
   constexpr bool CKPT = MODE == DP_MODE_CKPT;
+  constexpr bool SYNC = NW > 1 || TILED; // the stripe to the left is another wavefront's
+  static_assert(!TILED || (NW == 1 && !TRACE), "tiles: one wavefront per workgroup, no decision bits");
   constexpr int TBW = TRACE ? CS / 8 : 1;
   constexpr int TBS = TRACE ? 64 * TBW : 1;
   constexpr bool PACKED = DOT4 && UNI; // a row of A is one dword: the boundary's three ride in the same 16-byte ring entry
@@ -125,6 +141,46 @@ __device__ __forceinline__ void dp_fill_stripe(const DpFillPair &pp, const DpPar
   int dn_last = 0;    // between steps: the diagonal term of the right neighbour's first cell
   // H~ - gop above-left of lane 0's first cell of the block's first row: H~[0][jb] - gop at the top, then the boundary's last row
   int hl_carry = (jb == 0 ? 0 : -gop) - gop;
+  if constexpr(TILED) {
+    if(pp.t_begin > 0) {
+      // the tile before this one (drawn earlier from the queue, so running or done) has saved the lanes' state
+      int spins = 0;
+      while(__hip_atomic_load(pp.tdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pp.t_begin) {
+        if((spins & 1023) == 0 && __hip_atomic_load(pp.pipe_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          break; // the launch has already failed somewhere: do not wait, let the grid drain
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if(++spins > (1 << 22)) {
+          if(lane == 0) {
+            atomicOr(pp.pipe_error, 1);
+          }
+          break;
+        }
+      }
+      asm volatile("" ::: "memory");
+      const int *sv = reinterpret_cast<const int *>(pp.state) + lane;
+#pragma unroll
+      for(int c = 0; c < CS; ++c) {
+        hop[c] = __hip_atomic_load(sv + c * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f[c] = __hip_atomic_load(sv + (CS + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      e = __hip_atomic_load(sv + 2 * CS * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dn_last = __hip_atomic_load(sv + (2 * CS + 1) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hl_carry = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sv + (2 * CS + 2) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      // rows [t_begin - 64, t_begin) of A: lane l of the first block's step t is on row t - l
+      const int rp = pp.t_begin - 64 + lane;
+      const int4 vp = rp < la ? dp_expand_row<DOT4>(A[rp]) : make_int4(0, 0, 0, 0);
+      if constexpr(PACKED) {
+        const int4 ent = make_int4(vp.x, 0, 0, 0);
+        ring[rp & 127] = ent;
+        ring[(rp & 127) + 128] = ent;
+      }
+      else {
+        ring[rp & 127] = vp;
+        ring[(rp & 127) + 128] = vp;
+      }
+    }
+  }
   if(jb > 0 && ng == 1) { // lane 63's stores of the stripe to the left must be visible to every lane's loads
     if constexpr(CKPT) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (they are inline asm, the fence below does not know of them)
@@ -137,18 +193,18 @@ __device__ __forceinline__ void dp_fill_stripe(const DpFillPair &pp, const DpPar
   // the wavefront writes the 16 steps of every group out, 16 lanes per group: whole 128-byte lines, four groups per store (a store
   // per lane and step was 16 partial-line write requests per step; L2 write requests are what this kernel runs short of)
   constexpr int NGRP = 64 / GW;
-  const int2 *const ck_col = reinterpret_cast<const int2 *>(tbp) + g0 * steps; // group 0 of the stripe, step 0
+  const int2 *const ck_col = reinterpret_cast<const int2 *>(tbp) + g0 * pp.cstride; // group 0 of the stripe, step 0
   const bool closes_group = (lane & (GW - 1)) == GW - 1;
   unsigned cs_put = (unsigned)(size_t)cstage + (unsigned)(lane / GW) * 136u;              // + (step & 15) * 8
   const unsigned cs_get = (unsigned)(size_t)cstage + (unsigned)(lane >> 4) * 136u + (unsigned)(lane & 15) * 8u; // + 4 i groups
-  const unsigned ck_put = ((unsigned)(lane >> 4) * (unsigned)steps + (unsigned)(lane & 15)) * 8u;                // the same in HBM
+  const unsigned ck_put = ((unsigned)(lane >> 4) * (unsigned)pp.cstride + (unsigned)(lane & 15)) * 8u;           // the same in HBM
 
-  for(int t0 = 0; t0 < steps; t0 += 64) {
+  for(int t0 = TILED ? pp.t_begin : 0; t0 < (TILED ? min(pp.t_end, steps) : steps); t0 += 64) {
     {
       // stage rows [t0, t0+63] of A (one coalesced 8-byte load per lane, expanded) and the left boundary of the same rows
       const int r = t0 + lane;
       const int4 v = r < la ? dp_expand_row<DOT4>(A[r]) : make_int4(0, 0, 0, 0);
-      if(NW > 1 && s > 0) {
+      if(SYNC && s > 0) {
         // rows [t0, t0+63] of the left stripe's boundary must have been published by its wave
         const int need = ((s - 1) / team) * la + min(t0 + 64, la);
         int spins = 0;
@@ -316,14 +372,17 @@ __device__ __forceinline__ void dp_fill_stripe(const DpFillPair &pp, const DpPar
           int tc;
           asm volatile("v_sub_u32 %0, %1, %2" : "=v"(tc) : "s"(t + 1), "v"(ln & (GW - 1)));
           if(tc > 0 && (tc & (DP_CK_R - 1)) == 0) {
-            // [c][lane]: the store of one c is consecutive 8-byte slots over the lanes.  One store after the other through inline asm:
-            // left to itself the compiler assembles all of them side by side first, 32 registers that the step loop then does without
+            // [lane][c]: the lane's CS columns are CS * 8 consecutive, line-aligned bytes, written here and now, store after store --
+            // the line is whole when it leaves L2 (dp_internal.hpp).  8-byte stores: a 16-byte one wants its four registers side by
+            // side, and the copies that takes cost the step loop of the 96-register kernels 16 spilled registers (measured at the
+            // compiler).  One store after the other through inline asm: left to itself the compiler assembles all of them side by
+            // side first, 32 registers that the step loop then does without
             const char *rowp = reinterpret_cast<const char *>(tbp + pp.row_base + ((i64)jb * pp.nck + (i64)(tc / DP_CK_R - 1) * 64 * CS) * 2) +
-                               (unsigned)ln * 8u;
+                               (unsigned)ln * (unsigned)(CS * 8);
 #pragma unroll
             for(int c = 0; c < CS; ++c) {
               const unsigned long long hf = (unsigned long long)(unsigned)hop[c] | ((unsigned long long)(unsigned)f[c] << 32);
-              asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(rowp + (c >> 3) * 4096), "v"(hf), "n"((c & 7) * 512) : "memory");
+              asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(rowp), "v"(hf), "n"(c * 8) : "memory");
             }
           }
         }
@@ -365,18 +424,18 @@ __device__ __forceinline__ void dp_fill_stripe(const DpFillPair &pp, const DpPar
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for(int i = 0; i < NGRP / 4; ++i) {
-              if(NW > 1 && i == NGRP / 4 - 1 && ng > 1) { // lane 63's group is the seam for another workgroup: past this XCD's L2
-                asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(ck_put), "v"(he[i]), "s"(base + (i64)i * 4 * steps) : "memory");
+              if(SYNC && i == NGRP / 4 - 1 && ng > 1) { // lane 63's group is the seam for another workgroup: past this XCD's L2
+                asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(ck_put), "v"(he[i]), "s"(base + (i64)i * 4 * pp.cstride) : "memory");
               }
               else {
-                asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(ck_put), "v"(he[i]), "s"(base + (i64)i * 4 * steps) : "memory");
+                asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(ck_put), "v"(he[i]), "s"(base + (i64)i * 4 * pp.cstride) : "memory");
               }
             }
           }
         }
       }
     }
-    if(NW > 1) {
+    if(SYNC) {
       // lane 63 has stored the boundary of rows < t0 + 64 - 63: publish the count (cumulated over this wave's stripes)
       const int done = (s / team) * la + max(0, min(t0 + 1, la));
       if(ng > 1) {
@@ -396,7 +455,24 @@ __device__ __forceinline__ void dp_fill_stripe(const DpFillPair &pp, const DpPar
       }
     }
   }
-  if(s == pp.n_stripes - 1) {
+  if constexpr(TILED) {
+    if(pp.t_end < steps) { // not the stripe's last tile: the lanes' state for the next one, then the word that says it is there
+      int *sv = reinterpret_cast<int *>(pp.state) + lane;
+#pragma unroll
+      for(int c = 0; c < CS; ++c) {
+        __hip_atomic_store(sv + c * 64, hop[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sv + (CS + c) * 64, f[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(sv + 2 * CS * 64, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sv + (2 * CS + 1) * 64, dn_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sv + (2 * CS + 2) * 64, hl_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // those, and the checkpoints' inline-asm stores
+      if(lane == 0) {
+        __hip_atomic_store(pp.tdone, pp.t_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if(s == pp.n_stripes - 1 && (!TILED || pp.t_end >= steps)) {
     const int jj = lb - 1 - jb;
     const int cstar = jj % CS;
     int hv = hop[0];
@@ -488,8 +564,9 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   pp.ge = P.ge;
   pp.n_stripes = (int)dp_ck_stripes(lb, C, tl);
   pp.steps = la + 63;
+  pp.cstride = (int)dp_ck_stride(la);
   pp.tiles = (pp.steps + 3) / 4;
-  pp.row_base = dp_ck_groups(lb, C, tl) * dp_ck_steps(la) * 2;
+  pp.row_base = dp_ck_groups(lb, C, tl) * dp_ck_stride(la) * 2;
   pp.nck = (int)dp_ck_nck(la);
   int result = 0;
   if(la == 0 || lb == 0) { // one profile empty: a single gap run
@@ -521,6 +598,109 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   }
   if(lane == 0 && pp.tw == (pp.n_stripes - 1) % pp.team) {
     scores[pair] = result;
+  }
+}
+
+// Tiles from a queue (round 5).  A wavefront of dp_fill_kernel works through a whole stripe -- La + 63 steps -- so a launch of few long
+// pairs meets the chip's wavefront slots as uneven rounds: 512 pairs of 32 x 10 kbp are 5 120 stripe-long jobs for 4 096 slots, and
+// the second half of the launch ran at one wavefront per SIMD (3 204 GCUPS against 4 153 for 4 096 pairs; a ragged launch's longest
+// pairs needed launches of their own, the tiers).  Here the unit of work is a TILE: the 64-step blocks [t_begin, t_end) of one
+// stripe, the lanes' state handed from tile to tile through memory (dp_fill_stripe, TILED), the stripes of a pair pipelined through
+// the progress words the workgroups of a pair already use.  The grid is persistent -- as many one-wavefront workgroups as the chip
+// holds -- and every wavefront takes the next tile from a queue until the queue is empty.
+// Nobody waits for ever, by construction: the host lists the tiles in an order in which every tile comes after the two it depends
+// on -- the tile before it in its stripe, and the tile of the stripe to its left that covers the same steps of the pair's clock
+// (stripe s lags stripe s - 1 by 64 steps on that clock, so that a tile needs rows of the seam only from the left tile of its own
+// number) -- and a wavefront draws tickets in that order: whatever a tile waits for was drawn earlier, so it is running on a resident
+// wavefront or done, and the tile with the lowest unfinished ticket never waits.  The bounded waits and the error word stay as the
+// last line of defence.  The order the host chooses (dp_tiles_build) is longest remaining chain first.
+template <int C, int MODE, bool DOT4, bool UNI>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DOT4 ? 5 : 4)))
+dp_fill_tiles_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
+                     const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
+                     int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P,
+                     const DpTile *__restrict__ tiles, int n_tiles, const i64 *__restrict__ sync_off, i64 total_stripes, int *__restrict__ sync_words,
+                     unsigned *__restrict__ state, int *__restrict__ started, int tail) {
+  static_assert(MODE != DP_MODE_BITS, "tiles: scores and checkpoints only");
+  if(started && threadIdx.x == 0) {
+    __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  constexpr bool CKPT = MODE == DP_MODE_CKPT;
+  constexpr bool TAILS = C == 16;
+  constexpr bool PACKED = DOT4 && UNI;
+  __shared__ int4 ring[256];
+  __shared__ int4 sbnd[PACKED ? 1 : 64];
+  __shared__ int2 cstage[CKPT ? 16 * 17 : 1];
+  __shared__ unsigned tbstage[1];
+  __shared__ int progress[1];
+  const int lane = threadIdx.x;
+  int *const queue = sync_words + 2 * total_stripes; // the ticket counter, behind the progress words and the tiles-done words
+  for(;;) {
+    int ticket = 0;
+    if(lane == 0) {
+      ticket = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if(ticket >= n_tiles) {
+      break;
+    }
+    const DpTile tile = tiles[ticket];
+    const int pos = tile.pos, s = tile.s;
+    DpFillPair pp;
+    pp.ng = 2;           // the seam and the progress words the way several workgroups of a pair share them
+    pp.team = 1 << 24;   // more than any pair has stripes: the progress words are one per stripe, not cumulated
+    pp.tw = s;
+    const i64 so = sync_off[pos];
+    pp.gp = sync_words + so;
+    pp.tdone = sync_words + total_stripes + so + s;
+    pp.state = state + (so + s) * (i64)(64 * (2 * C + 4));
+    pp.t_begin = tile.t_begin;
+    pp.t_end = tile.t_end;
+    pp.pipe_error = pipe_error;
+    const i64 pair = order[pos];
+    const i64 a0 = off_a[pair], b0 = off_b[pair];
+    const int la = (int)(off_a[pair + 1] - a0), lb = (int)(off_b[pair + 1] - b0);
+    const int tl = TAILS ? tail : 0;
+    pp.A = cols_a + a0;
+    pp.B = cols_b + b0;
+    pp.la = la;
+    pp.lb = lb;
+    pp.tbp = CKPT ? tb + tb_off[pair] : nullptr;
+    pp.bp = bnd + a0;
+    pp.gop = P.go - P.ge;
+    pp.ge = P.ge;
+    pp.n_stripes = (int)dp_ck_stripes(lb, C, tl);
+    pp.steps = la + 63;
+    pp.cstride = (int)dp_ck_stride(la);
+    pp.tiles = (pp.steps + 3) / 4;
+    pp.row_base = dp_ck_groups(lb, C, tl) * dp_ck_stride(la) * 2;
+    pp.nck = (int)dp_ck_nck(la);
+    if(la == 0 || lb == 0) { // one profile empty: a single gap run (the host lists one tile for such a pair)
+      const int n = la + lb;
+      if(lane == 0) {
+        scores[pair] = n == 0 ? 0 : -(P.go + (n - 1) * P.ge);
+      }
+      continue;
+    }
+    int result = 0;
+    const DpStripe st = dp_stripe(lb, C, tl, s);
+    if(!TAILS || st.cs == C) {
+      dp_fill_stripe<C, C, MODE, DOT4, 1, UNI, true>(pp, P, s, st, ring, sbnd, cstage, tbstage, progress, 0, lane, result);
+    }
+    else if constexpr(TAILS) {
+      if(st.cs == 8) {
+        dp_fill_stripe<C, 8, MODE, DOT4, 1, UNI, true>(pp, P, s, st, ring, sbnd, cstage, tbstage, progress, 0, lane, result);
+      }
+      else {
+        dp_fill_stripe<C, 4, MODE, DOT4, 1, UNI, true>(pp, P, s, st, ring, sbnd, cstage, tbstage, progress, 0, lane, result);
+      }
+    }
+    if(lane == 0 && s == pp.n_stripes - 1 && pp.t_end >= pp.steps) {
+      scores[pair] = result;
+    }
+    // the next tile's staging must not overtake this tile's last LDS reads (one wavefront, LDS operations in order: a compiler fence)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -688,7 +868,7 @@ int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budge
      (o.waves_per_pair != 0 && o.waves_per_pair != 1 && o.waves_per_pair != 2 && o.waves_per_pair != 4 && o.waves_per_pair != 8 &&
       o.waves_per_pair != 16) ||
      o.groups_per_pair < 0 || o.band < 0 || o.band > 2 || o.walk_lanes < 0 || (o.slots != 0 && (o.slots < 2 || o.slots > 8)) || o.split < 0 ||
-     o.split > 64 || o.segment_cells < 0 || o.tier_min_pairs < 0) {
+     o.split > 64 || o.segment_cells < 0 || o.tier_min_pairs < 0 || o.tile_steps < 0 || (o.tile_steps > 1 && o.tile_steps % 64 != 0)) {
     return fail(PM_E_INVALID, "pm_dp_options_t: a field is out of range");
   }
   // (a batch may be initialised again for its next use -- the kept batches of dp_maf.hip: every field from the options, every time)
@@ -1001,6 +1181,87 @@ static int dp_walk_lanes_for(const pm_dp_batch *h, i64 first, i64 n) { // positi
   return dp_walk_lanes_rule(h, n, n > 0 ? columns / (double)n : 0.0);
 }
 
+// Does the fill launch of the pairs at positions [first, first + n) take its work from a queue of tiles (dp_fill_tiles_kernel), and in
+// tiles of how many steps?  0: no.  By itself: a launch whose stripe-long jobs are neither few enough to be resident all at once
+// (the waves-per-pair choices of dp_launch_fill) nor so many that the rounds even out -- between half and eight times the chip's
+// 4 096 wavefront slots -- and long enough to be cut (the longest pair two tiles or more).  From the lengths and the options alone,
+// so that the layout (no tiers for such a launch) and the launch agree.
+static int dp_tiles_rule(const pm_dp_batch *h, i64 first, i64 n, bool bits) {
+  if(h->opt.tile_steps == 1 || bits || h->cols_per_lane != 16 || h->waves_override != 0 || n <= 0) {
+    return 0;
+  }
+  if(h->opt.tile_steps >= 64) {
+    return h->opt.tile_steps;
+  }
+  const i64 T = 1024, slots = 4096;
+  i64 jobs = 0, max_steps = 0;
+  for(i64 q = first; q < first + n; ++q) {
+    const i64 k = h->order[(size_t)q];
+    const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+    jobs += la > 0 ? dp_ck_stripes(lb, h->cols_per_lane, h->tail) : 0;
+    max_steps = std::max(max_steps, la > 0 && lb > 0 ? la + 63 : 0);
+  }
+  return max_steps >= 2 * T && jobs >= slots / 2 && jobs <= 8 * slots ? (int)T : 0;
+}
+
+// The tiles of that launch, in the order the wavefronts draw them: longest remaining chain first.  On the pair's clock stripe s lags
+// stripe s - 1 by one 64-step block; tile k of a stripe is what the stripe does during blocks [k Tb, (k + 1) Tb) of that clock, so a
+// tile depends on the tile before it in its stripe and on tile k of the stripe to its left, nothing else.  A tile's rank is the
+// number of clock tiles its pair still has from it on; the list is sorted by falling rank, then by position, then by stripe -- an
+// order in which every tile comes after those it depends on (the tile before it has a higher rank; the left tile the same rank, the
+// same position and a lower stripe number).
+static int dp_tiles_build(pm_dp_batch *h, i64 first, i64 n, int T, DpTilePlan &plan) {
+  struct Ranked {
+    DpTile t;
+    int rank;
+  };
+  std::vector<Ranked> all;
+  std::vector<i64> sync_off((size_t)n);
+  const i64 Tb = T / 64;
+  i64 total_stripes = 0;
+  for(i64 pos = 0; pos < n; ++pos) {
+    const i64 k = h->order[(size_t)(first + pos)];
+    const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
+    sync_off[(size_t)pos] = total_stripes;
+    if(la == 0 || lb == 0) {
+      all.push_back(Ranked{DpTile{(int)pos, 0, 0, 0}, 1}); // the kernel writes the score of the single gap run
+      total_stripes += 1;
+      continue;
+    }
+    const i64 S = dp_ck_stripes(lb, h->cols_per_lane, h->tail), nblk = (la + 63 + 63) / 64;
+    const i64 K = (nblk + S - 1 + Tb - 1) / Tb;
+    for(i64 s = 0; s < S; ++s) {
+      for(i64 kk = 0; kk < K; ++kk) {
+        const i64 b0 = std::max<i64>(kk * Tb - s, 0), b1 = std::min<i64>((kk + 1) * Tb - s, nblk);
+        if(b1 > b0) {
+          all.push_back(Ranked{DpTile{(int)pos, (int)s, (int)(b0 * 64), (int)(b1 * 64)}, (int)(K - kk)});
+        }
+      }
+    }
+    total_stripes += S;
+  }
+  if(all.size() >= ((size_t)1 << 30)) {
+    return fail(PM_E_INVALID, "pm_dp_batch: too many tiles in one launch");
+  }
+  std::stable_sort(all.begin(), all.end(), [](const Ranked &x, const Ranked &y) { return x.rank > y.rank; });
+  std::vector<DpTile> tiles(all.size());
+  for(size_t i = 0; i < all.size(); ++i) {
+    tiles[i] = all[i].t;
+  }
+  plan.first = first;
+  plan.n = n;
+  plan.tile_steps = T;
+  plan.n_tiles = (i64)tiles.size();
+  plan.total_stripes = total_stripes;
+  PM_TRY(plan.tiles.alloc(tiles.size() * sizeof(DpTile)));
+  PM_TRY(plan.sync_off.alloc((size_t)n * 8));
+  PM_TRY(plan.sync_words.alloc((size_t)(2 * total_stripes + 1) * 4));
+  PM_TRY(plan.state.alloc((size_t)total_stripes * 64 * (size_t)(2 * h->cols_per_lane + 4) * 4));
+  PM_HIP(hipMemcpy(plan.tiles.p, tiles.data(), tiles.size() * sizeof(DpTile), hipMemcpyHostToDevice));
+  PM_HIP(hipMemcpy(plan.sync_off.p, sync_off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+  return PM_OK;
+}
+
 int dp_batch_plan_with(pm_dp_batch *h, const int *st, hipStream_t stream) {
   PM_TRY(dp_batch_plan_variant(h, st));
   return dp_batch_plan_layout(h, stream);
@@ -1071,6 +1332,7 @@ int dp_batch_plan_variant(pm_dp_batch *h, const int *st) {
 // order, chunks and their workspace, tiers, the band.
 int dp_batch_plan_layout(pm_dp_batch *h, hipStream_t stream) {
   const i64 n_pairs = h->n_pairs;
+  h->tile_plans.clear(); // (hipFree waits for the device: no launch of the layout before still reads them)
   // Columns of B per lane: 16, or 8 for a batch of a few hundred pairs at most whose profiles fit one 1 024-column stripe --
   // two stripes of 512 then, so twice the wavefronts a pair can keep busy, each with half the work per step (256 pairs of
   // 2 x 1 kbp: 0.60 -> 0.46 ms).  Longer pairs already have stripes to run side by side, and narrower stripes only make the
@@ -1313,6 +1575,9 @@ int dp_batch_plan_layout(pm_dp_batch *h, hipStream_t stream) {
       if(n < W) {
         continue; // dp_launch_fill already gives such a launch several wavefronts per pair
       }
+      if(dp_tiles_rule(h, c_lo, n, !h->ckpt) > 0) {
+        continue; // the launch takes tiles from a queue: its longest pairs' tiles go first, on as many wavefronts as they have stripes
+      }
       auto cost_at = [&](i64 q) {
         const i64 k = h->order[(size_t)q];
         return dp_fill_cost(h->off_a[k + 1] - h->off_a[k], h->off_b[k + 1] - h->off_b[k], h->cols_per_lane, h->tail);
@@ -1530,6 +1795,63 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
                           i64 *groups = nullptr) {
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
+  static const int cus_of_device = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+  }();
+  // tiles from a queue (dp_fill_tiles_kernel)?  The list is made at the launch's first pass and kept with the layout
+  if(const int T = dp_tiles_rule(h, first, n, traceback && !h->ckpt)) {
+    DpTilePlan *plan = nullptr;
+    for(std::unique_ptr<DpTilePlan> &p : h->tile_plans) {
+      if(p->first == first && p->n == n && p->tile_steps == T) {
+        plan = p.get();
+      }
+    }
+    if(!plan) {
+      std::unique_ptr<DpTilePlan> made(new DpTilePlan());
+      PM_TRY(dp_tiles_build(h, first, n, T, *made));
+      plan = made.get();
+      h->tile_plans.push_back(std::move(made));
+    }
+    // progress words, tiles-done words and the ticket counter start from zero every pass (the lanes' states are written before read)
+    PM_HIP(hipMemsetAsync(plan->sync_words.p, 0, (size_t)(2 * plan->total_stripes + 1) * 4, stream));
+    const i64 slots = (i64)std::max(cus_of_device, 1) * 4 * (h->dot4 ? 5 : 4); // what the chip holds of this kernel at once
+    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(plan->n_tiles, slots));
+#define DP_LAUNCH_TILES(TR, D4, UN)                                                                                                          \
+  dp_fill_tiles_kernel<16, TR, D4, UN><<<grid, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p, \
+                                                                (const i64 *)h->d_off_b.p, order, tb_off, tbw, (int2 *)h->bnd.p,             \
+                                                                (int *)h->scores.p, (int *)h->pipe_error.p, h->params,                      \
+                                                                (const DpTile *)plan->tiles.p, (int)plan->n_tiles,                          \
+                                                                (const i64 *)plan->sync_off.p, plan->total_stripes, (int *)plan->sync_words.p, \
+                                                                (unsigned *)plan->state.p, started, h->tail ? 1 : 0)
+#define DP_LAUNCH_TILES_D4(TR)            \
+  if(h->dot4 && h->uni) {                 \
+    DP_LAUNCH_TILES(TR, true, true);      \
+  }                                       \
+  else if(h->dot4) {                      \
+    DP_LAUNCH_TILES(TR, true, false);     \
+  }                                       \
+  else if(h->uni) {                       \
+    DP_LAUNCH_TILES(TR, false, true);     \
+  }                                       \
+  else {                                  \
+    DP_LAUNCH_TILES(TR, false, false);    \
+  }
+    if(traceback) {
+      DP_LAUNCH_TILES_D4(DP_MODE_CKPT)
+    }
+    else {
+      DP_LAUNCH_TILES_D4(DP_MODE_SCORE)
+    }
+#undef DP_LAUNCH_TILES_D4
+#undef DP_LAUNCH_TILES
+    PM_HIP(hipGetLastError());
+    if(groups) {
+      *groups = (i64)grid;
+    }
+    return PM_OK;
+  }
   // waves per pair: one, unless the launch has too few pairs to fill the chip (1 024 SIMDs x 4 waves) and the pairs
   // have several stripes to pipeline
   int nw = 1, ng = 1;
@@ -1555,11 +1877,7 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
     }
     // workgroups per pair: with at most half as many pairs as CUs, as many as give every workgroup a CU of its own and still two
     // stripes; the waves of a workgroup then follow from the stripes it gets (consecutive stripes go to different workgroups)
-    static const int cus = [] {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      return hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
-    }();
+    const int cus = cus_of_device;
     // (also for a launch that runs beside another fill launch of this batch -- dp_run's fill streams, the tiers: every launch has
     // progress words of its own, and the tickets make the order in which workgroups start irrelevant)
     const int groups_env = h->opt.groups_per_pair ? h->opt.groups_per_pair : -1; // 1: never; 2, 4, ..: that many; -1: chosen here
@@ -1729,6 +2047,7 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       }
     }
   }
+  h->tv_tier_chunk.clear();
   unsigned *tb = (unsigned *)h->tb.p;
   // two fill streams (see dp_batch.hpp): the fill kernel of an odd chunk is held back only by the path kernel that frees its half
   // of the workspace, not by the fill kernel of the chunk before it
@@ -1830,7 +2149,22 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
           hipStream_t ts = h->tier_streams[tier];
           PM_HIP(hipStreamWaitEvent(ts, h->tier_events[0], 0));
           i64 groups = 0;
+          const size_t tslot = h->tv_tier_chunk.size();
+          if(timed) {
+            while(h->tv_tier0.size() <= tslot) {
+              hipEvent_t e0 = nullptr, e1 = nullptr;
+              PM_HIP(hipEventCreate(&e0));
+              h->tv_tier0.push_back(e0);
+              PM_HIP(hipEventCreate(&e1));
+              h->tv_tier1.push_back(e1);
+            }
+            PM_HIP(hipEventRecord(h->tv_tier0[tslot], ts));
+          }
           PM_TRY(dp_launch_fill(h, at, cuts[tier] - at, tbw, traceback, ts, tier_started, &groups));
+          if(timed) {
+            PM_HIP(hipEventRecord(h->tv_tier1[tslot], ts));
+            h->tv_tier_chunk.push_back((int)c);
+          }
           tier_groups += groups;
           if(traceback) {
             PM_TRY(dp_launch_path(h, at, cuts[tier] - at, tbw, ts, true));
@@ -1917,6 +2251,14 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       if(c != first_chunk) {
         PM_HIP(hipEventElapsedTime(&at, h->tv_fill0[first_chunk], h->tv_fill0[c]));
       }
+      spans.push_back(std::make_pair(at, at + a));
+    }
+    // the tiers' fill kernels: launches of their own on their own streams, and the ones the step waits for
+    for(size_t k = 0; k < h->tv_tier_chunk.size(); ++k) {
+      float a = 0, at = 0;
+      PM_HIP(hipEventElapsedTime(&a, h->tv_tier0[k], h->tv_tier1[k]));
+      PM_HIP(hipEventElapsedTime(&at, h->tv_fill0[first_chunk], h->tv_tier0[k])); // (may be negative: a tier starts before its chunk's launch)
+      acc_fill += a;
       spans.push_back(std::make_pair(at, at + a));
     }
     std::sort(spans.begin(), spans.end());

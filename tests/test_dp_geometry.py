@@ -66,9 +66,11 @@ def test_stripes_tile_the_columns_and_the_narrow_ones_come_last(geo):
                     assert (jb.value, cs.value) in st and jb.value <= j < jb.value + 64 * cs.value
 
 
-def test_checkpoint_words_of_a_pair_are_disjoint_and_fill_the_workspace(geo):
+def test_checkpoint_words_of_a_pair_are_disjoint_and_every_store_is_a_whole_aligned_line(geo):
     """Every column checkpoint (group, step) and every row checkpoint (m, column) of a pair has a slot of its own inside the words the
-    planner allots the pair: nothing overlaps, nothing is left over."""
+    planner allots the pair; what is left over is alignment (round 5): a pair's workspace is a multiple of 128 bytes, the 16 steps of
+    a group that the fill kernel writes with one store are one aligned 128-byte line, the row checkpoints begin on a line and a
+    lane's columns of one checkpoint are consecutive -- with 16 columns a lane exactly one aligned line."""
     R, W = geo.geo_ck_r(), geo.geo_ck_w()
     rng = np.random.default_rng(4)
     shapes = [(1, 1), (63, 64), (64, 1024), (65, 1025), (200, 300), (130, 700), (100, 1300), (77, 1800), (90, 2048), (150, 2100)]
@@ -76,6 +78,7 @@ def test_checkpoint_words_of_a_pair_are_disjoint_and_fill_the_workspace(geo):
     for Cc, tail in ((16, 0), (16, 1), (8, 0)):
         for la, lb in shapes:
             words = geo.geo_words(la, lb, Cc, tail)
+            assert words % 32 == 0  # 128 bytes: the next pair's workspace begins on a line
             seen = np.zeros(words // 2, dtype=np.uint8)  # int2 slots
             steps, nck, groups, padded = la + 63, geo.geo_nck(la), geo.geo_groups(lb, Cc, tail), geo.geo_padded_cols(lb, Cc, tail)
             assert nck == (la + 63) // R and groups * W * Cc == padded
@@ -84,13 +87,24 @@ def test_checkpoint_words_of_a_pair_are_disjoint_and_fill_the_workspace(geo):
                 assert np.all(w % 2 == 0) and np.all(w + 2 <= words)
                 first = geo.geo_col_word(la, g, 0) // 2
                 assert geo.geo_col_word(la, g, steps - 1) // 2 == first + steps - 1  # a group's steps are contiguous
+                assert first % 16 == 0  # step 0, 16, 32, ... of every group: the start of a line
                 seen[first:first + steps] += 1
+            jb, cs = C.c_int(), C.c_int()
             for m in range(nck):
                 for j in range(padded):
                     w = geo.geo_row_word(la, lb, Cc, tail, m, j)
                     assert w % 2 == 0 and w + 2 <= words
                     seen[w // 2] += 1
-            assert np.all(seen == 1), (Cc, tail, la, lb, int((seen != 1).sum()))
+                    geo.geo_stripe_of_col(lb, Cc, tail, j, C.byref(jb), C.byref(cs))
+                    c = (j - jb.value) % cs.value
+                    if c == 0:
+                        assert (w // 2) % cs.value == 0  # a lane's columns: cs consecutive slots, aligned to their own size
+                    else:
+                        assert w == geo.geo_row_word(la, lb, Cc, tail, m, j - 1) + 2
+            assert np.all(seen <= 1), (Cc, tail, la, lb, int((seen > 1).sum()))
+            used = int(seen.sum())
+            assert used == groups * steps + nck * padded
+            assert words // 2 - used <= groups * 15 + 15  # the padding: less than 16 entries a group, and the end
             assert geo.geo_bytes_written(la, lb, Cc, tail) == (groups * la * 2 + nck * padded * 2) * 4 <= words * 4
 
 

@@ -516,3 +516,51 @@ def test_options_at_creation_and_as_process_defaults_and_the_geometry_of_a_pass(
         assert plain_create() is False
     finally:
         dp.set_default_options(None)
+
+
+@pytest.mark.parametrize("tile", ["64", "128", "320", "1024"])
+@pytest.mark.parametrize("dot4", ["0", "1"])
+@pytest.mark.parametrize("tail", ["0", "1"])
+def test_tiles_from_a_queue_equal_the_stripe_kernel(tile, dot4, tail, oracle_build, monkeypatch):
+    """dp_fill_tiles_kernel (round 5): the stripes of every pair cut into tiles of `tile` steps, taken from a queue by a persistent
+    grid, the lanes' state handed from tile to tile through memory, the stripes of a pair pipelined through progress words -- scores,
+    checkpoints (hence every path) and the scores-only pass equal the oracle's.  Pairs of one to five stripes, rows of A from less
+    than one tile to a dozen, lengths around the tile and block edges, an empty profile on either side."""
+    monkeypatch.setenv("PM_DP_MODE", "ckpt")
+    monkeypatch.setenv("PM_DP_TILE", tile)
+    monkeypatch.setenv("PM_DP_DOT4", dot4)
+    monkeypatch.setenv("PM_DP_TAIL", tail)
+    monkeypatch.setenv("PM_DP_COLS", "16")
+    la = np.array([1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 500, 700, 1000, 0, 300, 257, 640, 705])
+    lb = np.array([2100, 1024, 1025, 3000, 5000, 100, 2049, 4097, 1023, 1500, 2600, 4200, 1300, 50, 0, 3073, 2048, 1100])
+    inputs = dp.synth_batch(77, la, lb, 3, 4)
+    run_and_compare(inputs, dp.make_params(3, 4))
+    # the same tiles under the uniform-depth form and its general twin
+    for uni in ("1", "0"):
+        monkeypatch.setenv("PM_DP_UNI", uni)
+        inputs = dp.synth_pairs(78, 6, 4, 900, vary_length=True)
+        run_and_compare(inputs, dp.make_params(4, 4))
+
+
+def test_tiles_are_what_a_launch_of_few_long_pairs_takes_by_itself_and_tiers_are_not(oracle_build, monkeypatch):
+    """The rule (dp_tiles_rule): stripe-long jobs between half and eight times the chip's 4 096 wavefront slots, the longest pair two
+    tiles or more.  600 pairs of 2 100 x 4 500 columns (five stripes each: 3 000 jobs) qualify; their results are checked through the
+    size-independent properties (every path re-scores to its score and spans its pair) and against the stripe kernel (tile_steps = 1)."""
+    import pyoracle
+    monkeypatch.delenv("PM_DP_TILE", raising=False)
+    inputs = dp.synth_batch(81, np.full(600, 2100), np.full(600, 4500), 2, 2)
+    params = dp.make_params(2, 2)
+    got = []
+    for tile_steps in (0, 1):
+        batch = dp.DpBatch(inputs, params, options=dp.options(path_mode=2, tile_steps=tile_steps))
+        batch.run(traceback=True)
+        scores, ops, n_ops = batch.fetch()
+        got.append((scores, ops, n_ops))
+        if tile_steps == 0:
+            bad_scores, bad_paths = pyoracle.dp_check_batch_exhaustively(inputs, params, scores, ops, n_ops)
+            assert len(bad_scores) == 0 and len(bad_paths) == 0
+            paths = batch.paths(ops, n_ops)
+            for pair, (o_score, o_path) in zip([0, 299, 599], pyoracle.dp_align_pairs(inputs, params, [0, 299, 599])):
+                assert scores[pair] == o_score and np.array_equal(paths[pair], o_path)
+        batch.close()
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][1], got[1][1])

@@ -222,6 +222,42 @@ def test_dp_over_a_device_list_equals_the_resident_batch(devices, oracle_build):
 
 
 @pytest.mark.gpu
+def test_eight_way_rehearsal_of_the_device_list_on_one_gpu(oracle_build):
+    """the first real 8-GPU run must not be the first 8-way run of the code.  pm_dp_align_multi over an
+    EIGHT-entry device list {0, ..., 0} (eight host threads and HIP contexts in one process -- the GPU box allows six PROCESSES on
+    its card, so the eight-rank bench is rehearsed with gloo ranks on the CPU, tests/test_shard_gloo.py, and with six ranks on the
+    card, tests/test_bench_rehearsal_gpu.py): on a reduced stand-in for configs[3] (2 000 ragged pairs) the eight weighted cuts are
+    within 2 % of equal cells, the gathered scores and paths hash-equal to the one-device batch, and a slice that fails fails the call."""
+    import hashlib
+    from paramugsy_amd import dp
+    la, lb = dp.ragged_lengths(20261003, 2000, median=400, lo=50, hi=2000)
+    inputs = dp.synth_batch(7, la, lb, 4, 4)
+    params = dp.make_params(4, 4)
+    cuts = shard.partition_weighted(shard.pair_weights(la, lb).tolist(), 8)
+    cells = [int((la[a:b] * lb[a:b]).sum()) for a, b in zip(cuts, cuts[1:])]
+    assert len(cells) == 8 and max(cells) <= 1.02 * sum(cells) / 8 and min(cells) >= 0.98 * sum(cells) / 8
+    batch = dp.DpBatch(inputs, params)
+    batch.run(True)
+    r_scores, r_ops, r_nops = batch.fetch()
+    batch.close()
+    digest = lambda *arrays: hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in arrays)).hexdigest()
+    want = digest(r_scores, r_nops, *dp.paths_of(inputs, r_ops, r_nops))
+    scores, ops, n_ops = dp.align_multi(inputs, params, [0] * 8)
+    assert digest(scores, n_ops, *dp.paths_of(inputs, ops, n_ops)) == want
+    # a pair the library refuses (a profile of 300 rows with weights that leave int16) in the LAST slice: every slice's work is thrown
+    # away, the call fails, and the error names what failed
+    bad = dp.DpInputs(inputs.cols_a.copy(), inputs.off_a, inputs.cols_b.copy(), inputs.off_b)
+    bad.cols_b[int(inputs.off_b[1990]), 0] = 255
+    bad.cols_b[int(inputs.off_b[1990]), 1] = 255
+    with pytest.raises(capi.PmError):
+        dp.align_multi(bad, dp.make_params(4, 4, match=127, mismatch=-127), [0] * 8)
+    # and the list may name more workers than there are pairs
+    few = shard.slice_pairs(inputs, 0, 5)
+    s3, o3, n3 = dp.align_multi(few, params, [0] * 8)
+    assert np.array_equal(s3, r_scores[:5]) and np.array_equal(n3, r_nops[:5])
+
+
+@pytest.mark.gpu
 def test_maf_blocks_over_a_device_list(oracle_build, tmp_path):
     from paramugsy_amd import dp
     from test_dp_maf import random_blocks

@@ -171,6 +171,12 @@ def test_dp_pair_partition_gathers_in_pair_order(world, oracle_build, tmp_path):
     check_dp_gather(*run_dp_ranks(tmp_path, "cpu", world))
 
 
+def test_dp_eight_gloo_ranks_gather_in_pair_order(oracle_build, tmp_path):
+    """The world size the scaling run has (8), on the CPU: eight gloo ranks, 23 pairs (some ranks get two, some three), gathered in pair
+    order -- the census, the cuts and the point-to-point gather of shard.align_sharded at the width no GPU box of this build can run."""
+    check_dp_gather(*run_dp_ranks(tmp_path, "cpu", 8))
+
+
 @pytest.mark.gpu
 def test_dp_two_ranks_on_the_gpu(oracle_build, tmp_path):
     check_dp_gather(*run_dp_ranks(tmp_path, "gpu"))

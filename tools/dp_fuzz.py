@@ -28,7 +28,9 @@ KNOBS = {"PM_DP_MODE": ["ckpt", "ckpt", "bits", None], "PM_DP_COLS": ["8", "16",
          "PM_DP_SPLIT": ["2", "3", "5", None, None, None],
          # the tiers (a chunk's longest pairs in launches of their own, with their own path kernels) for chunks of 8 or 16 pairs already;
          # full-width last stripes instead of the narrow ones
-         "PM_DP_TIER_MIN_PAIRS": ["8", "8", "16", None], "PM_DP_NO_TIERS": ["1", None, None, None, None], "PM_DP_TAIL": ["0", None, None]}
+         "PM_DP_TIER_MIN_PAIRS": ["8", "8", "16", None], "PM_DP_NO_TIERS": ["1", None, None, None, None], "PM_DP_TAIL": ["0", None, None],
+         # tiles from a queue (round 5): never, tiles of 64 / 128 / 512 steps for every checkpoint or score launch, or the library's own rule
+         "PM_DP_TILE": ["0", "64", "64", "128", "512", None, None]}
 
 
 def random_case(rng):
