@@ -620,10 +620,22 @@ dp_fill_tiles_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off
                      const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
                      int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P,
                      const DpTile *__restrict__ tiles, int n_tiles, const i64 *__restrict__ sync_off, i64 total_stripes, int *__restrict__ sync_words,
-                     unsigned *__restrict__ state, int *__restrict__ started, int tail) {
+                     unsigned *__restrict__ state, int *__restrict__ started, int tail, int n_pos) {
   static_assert(MODE != DP_MODE_BITS, "tiles: scores and checkpoints only");
   if(started && threadIdx.x == 0) {
     __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // pairs with an empty profile have no tiles: their score is a single gap run, written here, a pair per thread of the grid.
+  // (Not as a tile of its own with a `continue` in the loop below: a lane-0 store followed by `continue` inside the persistent loop
+  // came out of the compiler's control-flow structurizer with the other 63 lanes running on into the tile body -- found by the
+  // probe that filled the workspace with a pattern and ran the queue one ticket further at a time, tools/debug/.)
+  for(int p = (int)(blockIdx.x * 64 + threadIdx.x); p < n_pos; p += (int)(gridDim.x * 64)) {
+    const i64 pr = order[p];
+    const int la_p = (int)(off_a[pr + 1] - off_a[pr]), lb_p = (int)(off_b[pr + 1] - off_b[pr]);
+    if(la_p == 0 || lb_p == 0) {
+      const int n = la_p + lb_p;
+      scores[pr] = n == 0 ? 0 : -(P.go + (n - 1) * P.ge);
+    }
   }
   constexpr bool CKPT = MODE == DP_MODE_CKPT;
   constexpr bool TAILS = C == 16;
@@ -675,13 +687,6 @@ dp_fill_tiles_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off
     pp.tiles = (pp.steps + 3) / 4;
     pp.row_base = dp_ck_groups(lb, C, tl) * dp_ck_stride(la) * 2;
     pp.nck = (int)dp_ck_nck(la);
-    if(la == 0 || lb == 0) { // one profile empty: a single gap run (the host lists one tile for such a pair)
-      const int n = la + lb;
-      if(lane == 0) {
-        scores[pair] = n == 0 ? 0 : -(P.go + (n - 1) * P.ge);
-      }
-      continue;
-    }
     int result = 0;
     const DpStripe st = dp_stripe(lb, C, tl, s);
     if(!TAILS || st.cs == C) {
@@ -695,8 +700,10 @@ dp_fill_tiles_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off
         dp_fill_stripe<C, 4, MODE, DOT4, 1, UNI, true>(pp, P, s, st, ring, sbnd, cstage, tbstage, progress, 0, lane, result);
       }
     }
-    if(lane == 0 && s == pp.n_stripes - 1 && pp.t_end >= pp.steps) {
-      scores[pair] = result;
+    if(s == pp.n_stripes - 1 && pp.t_end >= pp.steps) { // (uniform condition outside, the lane inside: see above)
+      if(lane == 0) {
+        scores[pair] = result;
+      }
     }
     // the next tile's staging must not overtake this tile's last LDS reads (one wavefront, LDS operations in order: a compiler fence)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1193,15 +1200,22 @@ static int dp_tiles_rule(const pm_dp_batch *h, i64 first, i64 n, bool bits) {
   if(h->opt.tile_steps >= 64) {
     return h->opt.tile_steps;
   }
-  const i64 T = 1024, slots = 4096;
-  i64 jobs = 0, max_steps = 0;
+  const i64 slots = 4096;
+  i64 jobs = 0, max_steps = 0, min_steps = (i64)1 << 40;
   for(i64 q = first; q < first + n; ++q) {
     const i64 k = h->order[(size_t)q];
     const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
     jobs += la > 0 ? dp_ck_stripes(lb, h->cols_per_lane, h->tail) : 0;
     max_steps = std::max(max_steps, la > 0 && lb > 0 ? la + 63 : 0);
+    min_steps = std::min(min_steps, la + 63);
   }
-  return max_steps >= 2 * T && jobs >= slots / 2 && jobs <= 8 * slots ? (int)T : 0;
+  // ... and a launch of LIKE pairs: in a ragged one the tiers (launches of the longest pairs with their own early walks) are worth
+  // more than the balance (measured: one GPU's eighth of the ragged batch 3 440 GCUPS from the queue, 3 970 with tiers)
+  // Tiles of a quarter of the longest stripe, 1 024 steps at least: a tile costs its hand-over and, more, the waits of wavefronts that
+  // now depend on each other (measured, profiles/r05_dp_tiles.txt: 512 pairs of 32 x 10 kbp 3 295 GCUPS without tiles, 3 217 / 3 418 /
+  // 3 433 / 3 256 in tiles of 512 / 1 024 / 2 048 / 4 096 steps; 1 024 pairs 3 463 without, 3 383 / 3 660 / 3 790 / 3 848)
+  const i64 T = std::max<i64>(1024, ((max_steps / 4 + 63) / 64) * 64);
+  return max_steps >= 2 * T && 2 * min_steps >= max_steps && jobs >= slots / 2 && jobs <= 8 * slots ? (int)T : 0;
 }
 
 // The tiles of that launch, in the order the wavefronts draw them: longest remaining chain first.  On the pair's clock stripe s lags
@@ -1224,9 +1238,7 @@ static int dp_tiles_build(pm_dp_batch *h, i64 first, i64 n, int T, DpTilePlan &p
     const i64 la = h->off_a[k + 1] - h->off_a[k], lb = h->off_b[k + 1] - h->off_b[k];
     sync_off[(size_t)pos] = total_stripes;
     if(la == 0 || lb == 0) {
-      all.push_back(Ranked{DpTile{(int)pos, 0, 0, 0}, 1}); // the kernel writes the score of the single gap run
-      total_stripes += 1;
-      continue;
+      continue; // no tiles: the kernel's first lines write the score of the single gap run
     }
     const i64 S = dp_ck_stripes(lb, h->cols_per_lane, h->tail), nblk = (la + 63 + 63) / 64;
     const i64 K = (nblk + S - 1 + Tb - 1) / Tb;
@@ -1817,14 +1829,14 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
     // progress words, tiles-done words and the ticket counter start from zero every pass (the lanes' states are written before read)
     PM_HIP(hipMemsetAsync(plan->sync_words.p, 0, (size_t)(2 * plan->total_stripes + 1) * 4, stream));
     const i64 slots = (i64)std::max(cus_of_device, 1) * 4 * (h->dot4 ? 5 : 4); // what the chip holds of this kernel at once
-    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(plan->n_tiles, slots));
+    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(std::max<i64>(plan->n_tiles, (n + 63) / 64), slots));
 #define DP_LAUNCH_TILES(TR, D4, UN)                                                                                                          \
   dp_fill_tiles_kernel<16, TR, D4, UN><<<grid, 64, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p, \
                                                                 (const i64 *)h->d_off_b.p, order, tb_off, tbw, (int2 *)h->bnd.p,             \
                                                                 (int *)h->scores.p, (int *)h->pipe_error.p, h->params,                      \
                                                                 (const DpTile *)plan->tiles.p, (int)plan->n_tiles,                          \
                                                                 (const i64 *)plan->sync_off.p, plan->total_stripes, (int *)plan->sync_words.p, \
-                                                                (unsigned *)plan->state.p, started, h->tail ? 1 : 0)
+                                                                (unsigned *)plan->state.p, started, h->tail ? 1 : 0, (int)n)
 #define DP_LAUNCH_TILES_D4(TR)            \
   if(h->dot4 && h->uni) {                 \
     DP_LAUNCH_TILES(TR, true, true);      \
