@@ -73,6 +73,12 @@ struct pm_dp_batch {
   pm::DevBuf fill_started;           // per chunk: workgroups of its fill kernel that have started (the gate of the next chunk's)
   pm::DevBuf tier_started;           // per chunk: workgroups of its tiers' fill kernels that have started (the gate of the launch of the rest)
   hipStream_t path_stream = nullptr;
+  // the walk beside the fill kernel of its own launch (DpEarly, dp_internal.hpp): a stream for the early walkers, per workspace slot
+  // the lists the fill kernel publishes into, and two events (lists zeroed; early walkers done)
+  hipStream_t early_stream = nullptr;
+  pm::DevBuf early_buf;
+  size_t early_slot_ints = 0;
+  std::vector<hipEvent_t> ev_early_ready, ev_early_done;
   // the fill kernels of every slot run on a stream of their own, so that chunk c + 1's first wavefronts take the SIMDs chunk c's
   // last ones leave (a launch ends with the chip draining: its last round of pairs fills only part of it); ev_begin orders that
   // stream behind whatever the caller's stream held when dp_run was called
@@ -106,6 +112,16 @@ struct pm_dp_batch {
     }
     if(path_stream) {
       (void)hipStreamDestroy(path_stream);
+    }
+    if(early_stream) {
+      (void)hipStreamDestroy(early_stream);
+    }
+    for(std::vector<hipEvent_t> *v : {&ev_early_ready, &ev_early_done}) {
+      for(hipEvent_t e : *v) {
+        if(e) {
+          (void)hipEventDestroy(e);
+        }
+      }
     }
     for(hipStream_t st : fill_streams) {
       (void)hipStreamDestroy(st);

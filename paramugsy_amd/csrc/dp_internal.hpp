@@ -345,11 +345,40 @@ __device__ __forceinline__ int4 dp_expand_row(u64 col) {
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------
+// The walk beside the fill of the SAME launch (round 5).  A pair's checkpoints are plain stores: they sit in the L2 of the XCD whose
+// CU wrote them until that L2 writes them back, and the eight L2s are not coherent with each other -- which is why the walk used to
+// be a kernel of its own behind the fill kernel (a kernel's end makes everything visible everywhere).  But a wavefront on the SAME
+// XCD reads that L2.  So the fill wavefront that has finished a pair (one wavefront per pair, all stripes; its stores acknowledged:
+// s_waitcnt vmcnt(0)) appends the pair's position to the list of the XCD it really runs on -- HW_REG_XCC_ID, read, not inferred from
+// blockIdx -- and a persistent walk kernel launched beside the fill kernel (mode 1: a wavefront or two per SIMD, the fill keeps the
+// rest) has every group take the next entry of the list of the XCD IT really runs on, wait until the entry is written, and walk
+// that pair while the fill goes on.  No placement is assumed: a pair lies in exactly one list, whatever the dispatcher did, and an
+// entry is taken exactly once (a ticket per XCD).  When the fill kernel has ended, everything is visible everywhere: a second launch
+// of the walk kernel behind it (mode 2, the whole chip) takes what is left of all eight lists.  The fill never waits for a walker,
+// the early walkers leave the fill most of every SIMD, and every wait ends when the fill has (n_filled), so nothing can hang.
+struct DpEarly {   // device pointers; mode 0: the walk as a kernel of its own (order[0 .. n), one pair per group)
+  int mode;        // 1: beside the fill kernel, the lists of this wavefront's own XCD only; 2: behind it, all lists
+  int n_expected;  // pairs the fill kernel will publish
+  int *taken;      // [8] entries handed out per XCD
+  const int *n_filled; // pairs published so far (incremented AFTER the entry is written)
+  const int *list; // [8][n]: position + 1, 0 = not written yet
+};
+// what the fill kernel needs to publish a finished pair (null pointers: it does not)
+struct DpFilled {
+  int *resv;     // [8] entries reserved per XCD
+  int *n_filled;
+  int *list;     // [8][n]
+  int n;
+};
+// HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wavefront runs on
+#define DP_GETREG_XCC_ID ((3 << 11) | (0 << 6) | 20)
+
 // dp_walk.hip: one launch walks the paths of the pairs order[0 .. n) from their checkpoints (tb_off is indexed by pair).
 // cols_per_lane (of the fill kernel) in {8, 16}; lanes_per_pair a power of two for which dp_walk_lanes_ok() holds.
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
-                   const DpBand &band, int tail, int urgent, hipStream_t stream);
+                   const DpBand &band, int tail, int urgent, hipStream_t stream, const DpEarly *early = nullptr, unsigned early_groups = 0);
 
 bool dp_walk_lanes_ok(int cols_per_lane, int lanes_per_pair);
 

@@ -505,12 +505,26 @@ __device__ __forceinline__ void dp_fill_stripe(const DpFillPair &pp, const DpPar
 // grows.  The bounded waits stay as the last line of defence, and a wave that finds *pipe_error set (by any wave of the grid)
 // stops waiting at once, so a failed launch drains in milliseconds instead of paying the time-out at every block.
 // tail: the narrow last stripes of dp_internal.hpp (kernels with 16 columns per lane that store no decision bits).
+// A finished pair for the walk that runs beside this launch (DpFilled / DpEarly, dp_internal.hpp): the wavefront's stores have been
+// acknowledged, so they are in this XCD's L2, where a walker of the same XCD reads them; the entry goes into that XCD's list, and
+// the count of published pairs goes up only when the entry is written.
+__device__ __forceinline__ void dp_publish_filled(const DpFilled &fl, int pos, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if(lane == 0) {
+    const int x = (int)(__builtin_amdgcn_s_getreg(DP_GETREG_XCC_ID) & 7);
+    const int slot = __hip_atomic_fetch_add(fl.resv + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fl.list + (i64)x * fl.n + slot, pos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(fl.n_filled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int C, int MODE, bool DOT4, int NW, bool UNI>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DOT4 && NW <= 4 ? 5 : 4)))
 dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b,
                const i64 *__restrict__ off_b, const int *__restrict__ order, const i64 *__restrict__ tb_off, unsigned *__restrict__ tb,
                int2 *__restrict__ bnd, int *__restrict__ scores, int *__restrict__ pipe_error, DpParamsD P, int ng, int *__restrict__ gprog,
-               int *__restrict__ started, int tail) {
+               int *__restrict__ started, int tail, DpFilled fl) {
   static_assert(C % 8 == 0, "whole traceback words per lane per step");
   if(NW > 1) { // several wavefronts per pair: a launch of few, long pairs (a tier beside the launch of the rest): ahead of those at issue
     __builtin_amdgcn_s_setprio(2);
@@ -574,6 +588,11 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     if(lane == 0 && pp.tw == 0) {
       scores[pair] = n == 0 ? 0 : -(P.go + (n - 1) * P.ge);
     }
+    if constexpr(NW == 1) {
+      if(fl.list) {
+        dp_publish_filled(fl, pos, lane);
+      }
+    }
     return;
   }
   if(NW > 1) {
@@ -598,6 +617,11 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   }
   if(lane == 0 && pp.tw == (pp.n_stripes - 1) % pp.team) {
     scores[pair] = result;
+  }
+  if constexpr(NW == 1) { // one wavefront has run all the pair's stripes: the pair is filled (the host passes the lists to such launches only)
+    if(fl.list) {
+      dp_publish_filled(fl, pos, lane);
+    }
   }
 }
 
@@ -875,7 +899,7 @@ int dp_batch_init(pm_dp_batch *h, const pm_dp_params_t *params, int64_t tb_budge
      (o.waves_per_pair != 0 && o.waves_per_pair != 1 && o.waves_per_pair != 2 && o.waves_per_pair != 4 && o.waves_per_pair != 8 &&
       o.waves_per_pair != 16) ||
      o.groups_per_pair < 0 || o.band < 0 || o.band > 2 || o.walk_lanes < 0 || (o.slots != 0 && (o.slots < 2 || o.slots > 8)) || o.split < 0 ||
-     o.split > 64 || o.segment_cells < 0 || o.tier_min_pairs < 0 || o.tile_steps < 0 || (o.tile_steps > 1 && o.tile_steps % 64 != 0)) {
+     o.split > 64 || o.segment_cells < 0 || o.tier_min_pairs < 0 || o.tile_steps < 0 || (o.tile_steps > 1 && o.tile_steps % 64 != 0) || o.early_walk < 0 || o.early_walk > 2) {
     return fail(PM_E_INVALID, "pm_dp_options_t: a field is out of range");
   }
   // (a batch may be initialised again for its next use -- the kept batches of dp_maf.hip: every field from the options, every time)
@@ -1803,8 +1827,13 @@ __global__ void dp_gate_kernel(const int *__restrict__ started, int total) {
 
 // The fill kernel of chunk c into workspace `tbw`.  started: the chunk's counter of started workgroups, or null; *groups: the launch's
 // workgroups.
+// filled: where a launch of one wavefront per pair publishes its finished pairs for the walk beside it (null: nobody listens);
+// *filled_used: whether this launch does (it does not when it takes tiles or gives a pair several wavefronts).
 static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int traceback, hipStream_t stream, int *started = nullptr,
-                          i64 *groups = nullptr) {
+                          i64 *groups = nullptr, const DpFilled *filled = nullptr, bool *filled_used = nullptr) {
+  if(filled_used) {
+    *filled_used = false;
+  }
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
   static const int cus_of_device = [] {
@@ -1929,12 +1958,19 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
       PM_HIP(hipMemsetAsync(gprog, 0, words * sizeof(int), stream));
     }
   }
+  DpFilled fl = {nullptr, nullptr, nullptr, 0};
+  if(filled && nw == 1 && ng == 1) {
+    fl = *filled;
+    if(filled_used) {
+      *filled_used = true;
+    }
+  }
 #define DP_LAUNCH_FILL(CC, TR, D4, NWV, UN)                                                                                                  \
   dp_fill_kernel<CC, TR, D4, NWV, UN><<<(unsigned)(n * ng), 64 * NWV, 0, stream>>>((const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p,    \
                                                                                    (const u64 *)h->cols_b.p, (const i64 *)h->d_off_b.p,    \
                                                                                    order, tb_off, tbw, (int2 *)h->bnd.p, (int *)h->scores.p, \
                                                                                    (int *)h->pipe_error.p, h->params, ng, gprog, started, \
-                                                                                   h->tail ? 1 : 0)
+                                                                                   h->tail ? 1 : 0, fl)
 #define DP_LAUNCH_FILL_D4(CC, TR, NWV)         \
   if(h->dot4 && h->uni) {                      \
     DP_LAUNCH_FILL(CC, TR, true, NWV, true);   \
@@ -1995,14 +2031,21 @@ static int dp_launch_fill(pm_dp_batch *h, i64 first, i64 n, unsigned *tbw, int t
 
 // The path kernel of the pairs at positions [first, first + n) (of one chunk) from the chunk's workspace `tbw`: the checkpoint walk,
 // or the walk over stored decision bits.
-static int dp_launch_path(pm_dp_batch *h, i64 first, i64 n, const unsigned *tbw, hipStream_t stream, bool urgent = false) {
+static int dp_launch_path(pm_dp_batch *h, i64 first, i64 n, const unsigned *tbw, hipStream_t stream, bool urgent = false,
+                          const DpEarly *early = nullptr, unsigned early_groups = 0, int lanes = 0) {
   if(n <= 0) {
     return PM_OK;
   }
   const i64 *tb_off = (const i64 *)h->d_tb_off.p;
   const int *order = (const int *)h->d_order.p + first;
   if(h->ckpt) {
-    const int lpp = dp_walk_lanes_for(h, first, n);
+    const int lpp = lanes ? lanes : dp_walk_lanes_for(h, first, n);
+    if(early && early->mode != 0) { // beside / behind the fill kernel of the same launch: no band (such launches are large)
+      const DpBand none = {nullptr, 0, nullptr, nullptr};
+      return dp_launch_walk(h->cols_per_lane, lpp, h->dot4, (const u64 *)h->cols_a.p, (const i64 *)h->d_off_a.p, (const u64 *)h->cols_b.p,
+                            (const i64 *)h->d_off_b.p, order, n, tb_off, tbw, (unsigned char *)h->ops.p, (int *)h->n_ops.p, h->params, none,
+                            h->tail ? 1 : 0, urgent ? 1 : 0, stream, early, early_groups);
+    }
     DpBand band = {nullptr, 0, nullptr, nullptr};
     if(h->band_work_items > 0 && h->band_lanes == lpp) {
       band.work = (const int *)h->d_band_work.p;
@@ -2094,6 +2137,86 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
     }
   }
   const bool gate_on = !h->opt.no_gate;
+  // The walk beside the fill kernel of its own launch (DpEarly, dp_internal.hpp): for the launches whose walk nothing else hides -- a
+  // batch of one chunk, and the last chunk of a batch of several (the chunks before it walk beside the fill kernels that follow them).
+  // prepare: the lists the fill kernel publishes into, zeroed on the fill stream in front of it; begin: the early walkers on their own
+  // stream (a wavefront per SIMD, two where the walk is a large share of the work); finish (in place of the path kernel): the same
+  // kernel behind the fill kernel over the whole chip for what is left, and the chunk is done when the early walkers are, too.
+  struct EarlyWalk {
+    bool used = false;
+    size_t slot = 0;
+    i64 first = 0, n = 0;
+    int *base = nullptr;
+    DpFilled fl = {nullptr, nullptr, nullptr, 0};
+  } ew;
+  auto early_prepare = [&](size_t c, i64 first, i64 n, hipStream_t fill_stream) -> int {
+    ew = EarlyWalk();
+    // NOT taken by default (opt.early_walk = 2 turns it on): measured on one MI355X (profiles/r05_early_walk.txt) the walkers beside
+    // the fill kernel do the walk's work at a worse rate than the walk kernel does behind it -- a wavefront per SIMD of the 32-lane
+    // walk is a chain of blocks with nothing to hide its latency -- and every instruction they issue is one the fill kernel does not:
+    // 10 000 pairs of 2 x 1 000: 2.99 ms a step without, 3.72 with (the fill kernel 1.92 -> 3.11 ms, the walk behind it 1.01 -> 0.23);
+    // one GPU's eighth of the ragged batch 15.7 -> 15.4 ms.  Both kernels are bound by VALU issue: running them side by side moves the
+    // work, it does not remove it.
+    if(!traceback || !h->ckpt || h->opt.early_walk != 2 || h->band_work_items > 0 || !h->seg_first.empty() || n <= 0) {
+      return PM_OK;
+    }
+    (void)c;
+    if(!h->early_stream) {
+      PM_HIP(hipStreamCreateWithFlags(&h->early_stream, hipStreamNonBlocking));
+    }
+    const size_t slots = (size_t)std::max(K, 1);
+    while(h->ev_early_ready.size() < slots) {
+      hipEvent_t a = nullptr, b = nullptr;
+      PM_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      h->ev_early_ready.push_back(a);
+      PM_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      h->ev_early_done.push_back(b);
+    }
+    i64 n_max = 0;
+    for(size_t cc = 0; cc < nc; ++cc) {
+      n_max = std::max(n_max, h->chunk_first[cc + 1] - h->chunk_first[cc]);
+    }
+    const size_t slot_ints = 96 + 8 * (size_t)n_max; // taken[8], resv[8], the count: a 128-byte line each, then the lists
+    if(h->early_slot_ints < slot_ints || h->early_buf.bytes < slots * slot_ints * sizeof(int)) {
+      PM_TRY(h->early_buf.alloc(slots * slot_ints * sizeof(int))); // (hipFree of the old lists waits for the device)
+      h->early_slot_ints = slot_ints;
+    }
+    ew.slot = c % slots;
+    ew.first = first;
+    ew.n = n;
+    ew.base = (int *)h->early_buf.p + ew.slot * h->early_slot_ints;
+    ew.fl = DpFilled{ew.base + 32, ew.base + 64, ew.base + 96, (int)n};
+    PM_HIP(hipMemsetAsync(ew.base, 0, (96 + 8 * (size_t)n) * sizeof(int), fill_stream));
+    PM_HIP(hipEventRecord(h->ev_early_ready[ew.slot], fill_stream));
+    return PM_OK;
+  };
+  auto early_begin = [&](const unsigned *tbw_) -> int { // after the fill launch that publishes (ew.used)
+    PM_HIP(hipStreamWaitEvent(h->early_stream, h->ev_early_ready[ew.slot], 0));
+    const DpEarly e1 = {1, (int)ew.n, ew.base, ew.base + 64, ew.base + 96};
+    // how many pairs are walked at a time: a wavefront per SIMD, two where the walk is more than a seventh of the launch's work
+    double fill_cells = 0, walk_cells = 0;
+    for(i64 q = ew.first; q < ew.first + ew.n; ++q) {
+      const i64 k = h->order[(size_t)q];
+      const double la = (double)(h->off_a[k + 1] - h->off_a[k]), lb = (double)(h->off_b[k + 1] - h->off_b[k]);
+      fill_cells += la * lb;
+      walk_cells += (double)DP_CK_R * (la + lb);
+    }
+    (void)fill_cells;
+    (void)walk_cells;
+    // one wavefront per SIMD, of the walk's smallest footprint (32 lanes per pair: 96 VGPRs and 6 KB of LDS, so that the fill kernel
+    // keeps four of its five wavefronts per SIMD) wherever the fill kernel's blocks allow it
+    const int lpp = h->walk_lanes ? h->walk_lanes : (dp_walk_lanes_ok(h->cols_per_lane, 32) ? 32 : dp_walk_lanes_for(h, ew.first, ew.n));
+    const unsigned groups = (unsigned)std::min<i64>(ew.n, (i64)1024 * (64 / lpp));
+    PM_TRY(dp_launch_path(h, ew.first, ew.n, tbw_, h->early_stream, false, &e1, groups, lpp));
+    PM_HIP(hipEventRecord(h->ev_early_done[ew.slot], h->early_stream));
+    return PM_OK;
+  };
+  auto early_finish = [&](const unsigned *tbw_, hipStream_t ps_) -> int { // on the path stream, behind the fill kernel
+    const DpEarly e2 = {2, (int)ew.n, ew.base, ew.base + 64, ew.base + 96};
+    PM_TRY(dp_launch_path(h, ew.first, ew.n, tbw_, ps_, false, &e2, (unsigned)ew.n));
+    PM_HIP(hipStreamWaitEvent(ps_, h->ev_early_done[ew.slot], 0));
+    return PM_OK;
+  };
   long prev_chunk = -1; // the last chunk that had pairs
   hipStream_t caller_stream = stream;
   i64 tiers_end = 0;       // the current chunk: the position behind its tiers (their path kernels ride on their own streams)
@@ -2122,6 +2245,7 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       i64 at = c_lo;
       tiers_end = c_lo;
       tiers_joined = 0;
+      ew = EarlyWalk();
       size_t spans = 0; // segments the chunk's pairs lie in
       for(size_t sg = 0; sg + 1 < h->seg_first.size(); ++sg) {
         spans += h->seg_first[sg + 1] > c_lo && h->seg_first[sg] < c_hi ? 1 : 0;
@@ -2189,7 +2313,11 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
           dp_gate_kernel<<<1, 64, 0, stream>>>(tier_started, (int)std::min<i64>(tier_groups, 0x7fffffff));
           PM_HIP(hipGetLastError());
         }
-        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream));
+        PM_TRY(early_prepare(c, at, c_hi - at, stream));
+        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, nullptr, nullptr, ew.base ? &ew.fl : nullptr, &ew.used));
+        if(ew.used) {
+          PM_TRY(early_begin(tbw));
+        }
         tiers_joined = cuts.size();
         if(!traceback) { // no path kernel to wait for them: the chunk's fill stream does
           for(size_t tier = 0; tier < cuts.size(); ++tier) {
@@ -2201,7 +2329,14 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       if(at < c_hi) {
         const bool whole = at == c_lo; // one launch for the chunk: the next chunk's gate can count its workgroups
         i64 groups = 0;
-        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, two_fills && whole ? started + c : nullptr, &groups));
+        if(whole) {
+          PM_TRY(early_prepare(c, at, c_hi - at, stream));
+        }
+        PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, two_fills && whole ? started + c : nullptr, &groups,
+                              whole && ew.base ? &ew.fl : nullptr, &ew.used));
+        if(ew.used) {
+          PM_TRY(early_begin(tbw));
+        }
         if(two_fills && whole) {
           h->chunk_groups[c] = groups;
         }
@@ -2219,7 +2354,12 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       if(timed) {
         PM_HIP(hipEventRecord(h->tv_path0[c], ps));
       }
-      PM_TRY(dp_launch_path(h, tiers_end, h->chunk_first[c + 1] - tiers_end, tbw, ps));
+      if(ew.used && ew.first == tiers_end && ew.n == h->chunk_first[c + 1] - tiers_end) {
+        PM_TRY(early_finish(tbw, ps));
+      }
+      else {
+        PM_TRY(dp_launch_path(h, tiers_end, h->chunk_first[c + 1] - tiers_end, tbw, ps));
+      }
       if(timed) {
         PM_HIP(hipEventRecord(h->tv_path1[c], ps));
       }

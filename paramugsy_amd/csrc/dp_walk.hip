@@ -50,7 +50,7 @@ template <int C, int LPP, bool DOT4>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C == 16 && LPP == 32 ? 5 : (C == 16 && LPP == 16 && DOT4 ? 4 : 1))))
 dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, const u64 *__restrict__ cols_b, const i64 *__restrict__ off_b,
                const int *__restrict__ order, i64 n, const i64 *__restrict__ tb_off, const unsigned *__restrict__ ck, unsigned char *__restrict__ ops,
-               int *__restrict__ n_ops, DpParamsD P, DpBand band, int band_mode, int tail, int urgent) {
+               int *__restrict__ n_ops, DpParamsD P, DpBand band, int band_mode, int tail, int urgent, DpEarly early) {
   // band_mode 0: the walk, every block recomputed; 1: no walk, the band's blocks computed and stored (work items = the band's
   // (pair, column group) list); 2: the walk, blocks inside the band read back, the others recomputed
   // A walk is a chain of blocks, each waiting for the one before.  The walk of a tier -- a few hundred long pairs beside the fill
@@ -100,6 +100,13 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     at = la + lb;
     have = true;
   };
+  // beside / behind the fill kernel of the same launch (DpEarly, dp_internal.hpp): a group takes its pairs from the XCDs' lists
+  const int my_xcc = early.mode ? (int)(__builtin_amdgcn_s_getreg(DP_GETREG_XCC_ID) & 7) : 0;
+  int list_x = early.mode == 2 ? (int)((blockIdx.x * G + grp) & 7) : my_xcc; // the list the group draws from (mode 2: all, in turn)
+  int ticket = -1;         // the entry of that list the group has drawn and not yet found written
+  int lists_tried = 0;     // mode 2: lists found exhausted in a row
+  int polls = 0;           // mode 1: looks at an entry that was not there yet
+  bool group_done = early.mode == 0;
   {
     const i64 idx = (i64)blockIdx.x * G + grp;
     if(band_mode == 1) {
@@ -108,7 +115,7 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
         take(band.work[2 * idx]);
       }
     }
-    else if(idx < n) {
+    else if(early.mode == 0 && idx < n) {
       take(order[idx]); // the launch's pairs in processing order
     }
   }
@@ -141,8 +148,69 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
           have = false;
         }
       }
+      if(early.mode != 0 && !have && !group_done) {
+        // the group's next pair.  Draw an entry of the list (one lane draws, the group's first lane hands it round), then see whether
+        // the fill kernel has written it; if not, the group sits this round out -- unless every pair has been published, in which
+        // case an entry still empty will stay empty: the list has ended.
+        // (the count of published pairs is ONE word that every waiting group of the chip would poll: it is looked at when a group is
+        // about to draw, and every sixteenth time an entry is found empty -- polled every round by a thousand wavefronts it became a hot
+        // spot in one memory channel that the fill kernel's checkpoint stores queued behind: the fill took 3.1 ms instead of 1.9)
+        if(ticket < 0 && early.mode == 1 &&
+           __hip_atomic_load(early.n_filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= early.n_expected) {
+          // the fill kernel has ended (or is about to): what is left belongs to the launch behind it, which has the whole chip -- a
+          // wavefront or two per SIMD drawing on would only drag the launch's end out (measured: 10 000 pairs of 2 x 1 000, 4.1 ms
+          // with early walkers that drew until the lists were empty, profiles/r05_early_walk.txt)
+          group_done = true;
+        }
+        else if(ticket < 0) {
+          int t = 0;
+          if(q == 0) {
+            t = __hip_atomic_fetch_add(early.taken + list_x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          ticket = __shfl(t, grp * LPP);
+        }
+        int entry = 0;
+        if(!group_done && ticket < early.n_expected) {
+          entry = __hip_atomic_load(early.list + (i64)list_x * early.n_expected + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if(entry == 0 && (early.mode == 2 || (++polls & 15) == 0) &&
+             __hip_atomic_load(early.n_filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= early.n_expected) {
+            // all published: entries are written before the count goes up, so a second look is final
+            entry = __hip_atomic_load(early.list + (i64)list_x * early.n_expected + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(entry == 0) {
+              ticket = early.n_expected; // this list has ended
+            }
+          }
+        }
+        if(entry != 0) {
+          take(order[entry - 1]);
+          ticket = -1;
+          lists_tried = 0;
+        }
+        else if(!group_done && ticket >= early.n_expected) {
+          ticket = -1;
+          if(early.mode == 2 && ++lists_tried < 8) {
+            list_x = (list_x + 1) & 7; // behind the fill kernel: the next XCD's list
+          }
+          else {
+            group_done = true;
+          }
+        }
+      }
       if(!__any(have)) {
-        break;
+        if(__all(group_done)) {
+          break;
+        }
+        if(early.mode == 1) { // waiting for the fill kernel: leave the SIMD, and the memory system, to it (some 15 us between two looks)
+          __builtin_amdgcn_s_sleep(127);
+          __builtin_amdgcn_s_sleep(127);
+          __builtin_amdgcn_s_sleep(127);
+          __builtin_amdgcn_s_sleep(127);
+        }
+        continue;
+      }
+      if(early.mode == 1 && __any(have && at == la + lb && i == la && j == lb)) {
+        // a pair just taken: this CU's L1 may hold lines of an earlier pass over the same workspace
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       live = have && i > 0 && j > 0;
     }
@@ -398,25 +466,33 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
 
 template <int C, int LPP, bool DOT4>
 static int launch_walk(const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b, const int *order, i64 n, const i64 *tb_off,
-                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, const DpBand &band, int tail, int urgent, hipStream_t stream) {
+                       const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P, const DpBand &band, int tail, int urgent, hipStream_t stream,
+                       const DpEarly *early, unsigned early_groups) {
   constexpr int G = 64 / LPP;
+  const DpEarly none = {0, 0, nullptr, nullptr, nullptr};
+  if(early && early->mode != 0) { // beside (1) or behind (2) the fill kernel of the same launch: groups that take pairs from the XCDs' lists
+    const unsigned eb = std::max(1u, (early_groups + G - 1) / G);
+    dp_walk_kernel<C, LPP, DOT4><<<eb, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, 0, tail, urgent, *early);
+    PM_HIP(hipGetLastError());
+    return PM_OK;
+  }
   const unsigned blocks = (unsigned)((n + G - 1) / G);
   const bool with_band = band.work != nullptr && band.n_work > 0;
   if(with_band) {
     const unsigned bblocks = (unsigned)((band.n_work + G - 1) / G);
     dp_walk_kernel<C, LPP, DOT4><<<bblocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, band.n_work, tb_off, ck, ops, n_ops, P, band, 1,
-                                                             tail, urgent);
+                                                             tail, urgent, none);
     PM_HIP(hipGetLastError());
   }
   dp_walk_kernel<C, LPP, DOT4><<<blocks, 64, 0, stream>>>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, with_band ? 2 : 0,
-                                                          tail, urgent);
+                                                          tail, urgent, none);
   PM_HIP(hipGetLastError());
   return PM_OK;
 }
 
 int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *cols_a, const i64 *off_a, const u64 *cols_b, const i64 *off_b,
                    const int *order, i64 n, const i64 *tb_off, const unsigned *ck, unsigned char *ops, int *n_ops, const DpParamsD &P,
-                   const DpBand &band, int tail, int urgent, hipStream_t stream) {
+                   const DpBand &band, int tail, int urgent, hipStream_t stream, const DpEarly *early, unsigned early_groups) {
   if(n <= 0) {
     return PM_OK;
   }
@@ -424,8 +500,8 @@ int dp_launch_walk(int cols_per_lane, int lanes_per_pair, bool dot4, const u64 *
 #define WALK(CC, LL)                                                                                                        \
   if constexpr((CC * DP_CK_W) % LL == 0 && (CC * DP_CK_W) / LL >= 1 && (CC * DP_CK_W) / LL <= 8 && CC % ((CC * DP_CK_W) / LL) == 0) { \
     if(lanes_per_pair == LL) {                                                                                              \
-      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, urgent, stream) \
-                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, urgent, stream); \
+      return dot4 ? launch_walk<CC, LL, true>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, urgent, stream, early, early_groups) \
+                  : launch_walk<CC, LL, false>(cols_a, off_a, cols_b, off_b, order, n, tb_off, ck, ops, n_ops, P, band, tail, urgent, stream, early, early_groups); \
     }                                                                                                                       \
   }
   if(cols_per_lane == 16) {

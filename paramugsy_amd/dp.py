@@ -29,7 +29,7 @@ class PmDpOptions(C.Structure):
     _fields_ = [("path_mode", C.c_int32), ("cols_per_lane", C.c_int32), ("waves_per_pair", C.c_int32), ("groups_per_pair", C.c_int32),
                 ("band", C.c_int32), ("walk_lanes", C.c_int32), ("int16_weights", C.c_int32), ("no_uniform_depth", C.c_int32),
                 ("keep_order", C.c_int32), ("no_tiers", C.c_int32), ("tier_min_pairs", C.c_int32), ("full_stripes", C.c_int32),
-                ("slots", C.c_int32), ("split", C.c_int32), ("no_gate", C.c_int32), ("tile_steps", C.c_int32), ("segment_cells", C.c_int64)]
+                ("slots", C.c_int32), ("split", C.c_int32), ("no_gate", C.c_int32), ("tile_steps", C.c_int32), ("early_walk", C.c_int32), ("reserved", C.c_int32), ("segment_cells", C.c_int64)]
 
 
 def options(**fields) -> PmDpOptions:
@@ -50,7 +50,8 @@ _ENV_FIELDS = {
     "PM_DP_DOT4": ("int16_weights", {"0": 1, "1": 0}), "PM_DP_UNI": ("no_uniform_depth", {"0": 1, "1": 0}), "PM_DP_KEEP_ORDER": ("keep_order", None),
     "PM_DP_NO_TIERS": ("no_tiers", None), "PM_DP_TIER_MIN_PAIRS": ("tier_min_pairs", None), "PM_DP_TAIL": ("full_stripes", {"0": 1, "1": 0}),
     "PM_DP_SLOTS": ("slots", None), "PM_DP_SPLIT": ("split", None), "PM_DP_NO_GATE": ("no_gate", None),
-    "PM_DP_SEGMENT_CELLS": ("segment_cells", None), "PM_DP_TILE": ("tile_steps", {"0": 1, "*": None}),  # PM_DP_TILE=0: never; =N: tiles of N steps
+    "PM_DP_SEGMENT_CELLS": ("segment_cells", None), "PM_DP_TILE": ("tile_steps", {"0": 1, "*": None}),
+    "PM_DP_EARLY_WALK": ("early_walk", {"0": 1, "1": 2}),  # the walk beside the fill kernel of its own launch: never / wherever possible  # PM_DP_TILE=0: never; =N: tiles of N steps
 }
 
 

@@ -35,10 +35,10 @@ def test_struct_layouts_match_header():
 
 
 def test_dp_options_layout_and_the_environment_spelling(monkeypatch):
-    """pm_dp_options_t: 16 int32 + one int64 (include/paramugsy_amd.h); the PM_DP_* switches are read by the Python binding only and
+    """pm_dp_options_t: 18 int32 + one int64 (include/paramugsy_amd.h); the PM_DP_* switches are read by the Python binding only and
     become explicit fields (the library itself reads no environment variable: no getenv of a PM_DP_ name is left in its sources)."""
     from paramugsy_amd import dp
-    assert C.sizeof(dp.PmDpOptions) == 16 * 4 + 8
+    assert C.sizeof(dp.PmDpOptions) == 18 * 4 + 8
     header = open(os.path.join(ROOT, "include", "paramugsy_amd.h")).read()
     body = header[header.index("typedef struct pm_dp_options {"):header.index("} pm_dp_options_t;")]
     declared = re.findall(r"int(?:32|64)_t\s+([a-z0-9_]+);", body)

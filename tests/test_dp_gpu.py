@@ -564,3 +564,40 @@ def test_tiles_are_what_a_launch_of_few_long_pairs_takes_by_itself_and_tiers_are
                 assert scores[pair] == o_score and np.array_equal(paths[pair], o_path)
         batch.close()
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][1], got[1][1])
+
+
+@pytest.mark.parametrize("lanes", ["0", "16", "32"])
+@pytest.mark.parametrize("dot4", ["0", "1"])
+def test_walk_beside_the_fill_kernel_of_its_own_launch(lanes, dot4, oracle_build, monkeypatch):
+    """The early walk (round 5; DpEarly in dp_internal.hpp): the fill wavefront that has finished a pair puts it on the list of the XCD
+    it runs on, walkers launched BESIDE the fill kernel take the entries of their own XCD's list while the fill goes on, and a second
+    launch of the walk behind the fill kernel takes what is left.  Forced for batches of any size (PM_DP_EARLY_WALK=1), band off: every
+    score and path equal the oracle's -- ragged lengths (pairs finish at very different times), empty profiles, more pairs than early
+    groups and fewer, several passes over the same batch (the lists are zeroed before every pass)."""
+    import pyoracle
+    monkeypatch.setenv("PM_DP_MODE", "ckpt")
+    monkeypatch.setenv("PM_DP_EARLY_WALK", "1")
+    monkeypatch.setenv("PM_DP_BAND", "0")
+    monkeypatch.setenv("PM_DP_WAVES", "1")
+    monkeypatch.setenv("PM_DP_DOT4", dot4)
+    if lanes != "0":
+        monkeypatch.setenv("PM_DP_WALK_LANES", lanes)
+    la, lb = dp.ragged_lengths(91, 300, median=300, lo=1, hi=2400)
+    la[7] = 0
+    lb[100] = 0
+    la[200] = lb[200] = 0
+    inputs = dp.synth_batch(92, la, lb, 3, 3)
+    params = dp.make_params(3, 3)
+    o_scores, o_paths = pyoracle.dp_align(inputs, params)
+    batch = dp.DpBatch(inputs, params)
+    for rep in range(3):
+        batch.run(True)
+        scores, ops, n_ops = batch.fetch()
+        assert np.array_equal(scores, o_scores), rep
+        paths = batch.paths(ops, n_ops)
+        bad = [k for k in range(inputs.n_pairs) if not np.array_equal(paths[k], o_paths[k])]
+        assert not bad, (rep, bad[:5])
+    batch.close()
+    # a handful of pairs (fewer than the early walkers' groups), and the chunked pipeline with the early walk on every chunk
+    run_and_compare(dp.synth_pairs(93, 5, 2, 700, vary_length=True), dp.make_params(2, 2))
+    run_and_compare(dp.synth_batch(94, la[:120], lb[:120], 3, 3), params, tb_budget=6 << 20)
