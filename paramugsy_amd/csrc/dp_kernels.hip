@@ -1224,6 +1224,11 @@ static int dp_tiles_rule(const pm_dp_batch *h, i64 first, i64 n, bool bits) {
   if(h->opt.tile_steps >= 64) {
     return h->opt.tile_steps;
   }
+  if(!h->seg_first.empty()) {
+    // a batch that is arriving from the host (dp_stream.hip): the list would be made, and its buffers allocated, in the middle of the
+    // pipeline of uploads and launches (measured: the headline batch from pinned memory 328 -> 437 ms with a tiled first chunk)
+    return 0;
+  }
   const i64 slots = 4096;
   i64 jobs = 0, max_steps = 0, min_steps = (i64)1 << 40;
   for(i64 q = first; q < first + n; ++q) {
@@ -1825,6 +1830,27 @@ __global__ void dp_gate_kernel(const int *__restrict__ started, int total) {
   }
 }
 
+// The gate itself.  Where the device can make a STREAM wait for a value in memory (hipStreamWaitValue32: the command processor polls, no
+// wavefront does) that is the gate: round 4's kernel trace held 66 gate kernels of 40 ms each, 28 % of all kernel time -- one lane
+// polling, nothing lost but a wavefront slot, yet not a kernel anybody wants in a profile.  Measured first by itself
+// (tools/ubench/wait_value.hip: a stream held back until the 20 000 workgroups of a kernel on another stream had counted themselves
+// in went on 4.6-5.2 ms before that kernel ended).  The wait has no time-out where the kernel's was bounded: it is only ever enqueued
+// behind a launch that has been accepted (hipGetLastError), whose every workgroup counts itself in at entry, so the value is reached
+// whatever else happens.  pm_dp_options_t.no_gate turns the gates off altogether; a device without the attribute keeps the kernel.
+static int dp_gate(hipStream_t stream, int *started, int total) {
+  static const int can_wait = [] {
+    int dev = 0, can = 0;
+    return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess ? can : 0;
+  }();
+  if(can_wait) {
+    PM_HIP(hipStreamWaitValue32(stream, started, (uint32_t)total, hipStreamWaitValueGte, 0xffffffffu));
+    return PM_OK;
+  }
+  dp_gate_kernel<<<1, 64, 0, stream>>>(started, total);
+  PM_HIP(hipGetLastError());
+  return PM_OK;
+}
+
 // The fill kernel of chunk c into workspace `tbw`.  started: the chunk's counter of started workgroups, or null; *groups: the launch's
 // workgroups.
 // filled: where a launch of one wavefront per pair publishes its finished pairs for the walk beside it (null: nobody listens);
@@ -2233,8 +2259,7 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
       PM_HIP(hipStreamWaitEvent(stream, h->ev_path[c - (size_t)K], 0)); // the part is free again
     }
     if(two_fills && gate_on && prev_chunk >= 0 && h->chunk_groups[(size_t)prev_chunk] > 0) {
-      dp_gate_kernel<<<1, 64, 0, stream>>>(started + prev_chunk, (int)std::min<i64>(h->chunk_groups[(size_t)prev_chunk], 0x7fffffff));
-      PM_HIP(hipGetLastError());
+      PM_TRY(dp_gate(stream, started + prev_chunk, (int)std::min<i64>(h->chunk_groups[(size_t)prev_chunk], 0x7fffffff)));
     }
     if(timed) {
       PM_HIP(hipEventRecord(h->tv_fill0[c], stream));
@@ -2310,8 +2335,7 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
         }
         tiers_end = at; // the chunk's own path kernel starts here
         if(gate_on && tier_groups > 0) {
-          dp_gate_kernel<<<1, 64, 0, stream>>>(tier_started, (int)std::min<i64>(tier_groups, 0x7fffffff));
-          PM_HIP(hipGetLastError());
+          PM_TRY(dp_gate(stream, tier_started, (int)std::min<i64>(tier_groups, 0x7fffffff)));
         }
         PM_TRY(early_prepare(c, at, c_hi - at, stream));
         PM_TRY(dp_launch_fill(h, at, c_hi - at, tbw, traceback, stream, nullptr, nullptr, ew.base ? &ew.fl : nullptr, &ew.used));
