@@ -16,11 +16,13 @@ P = os.environ.get("PM_PROFILE_OUT") or os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 tool = os.path.join(ROOT, "tools", "summarize_prof.py")
-if os.path.exists(os.path.join(O, "bench.json")):
-    bench = json.load(open(os.path.join(O, "bench.json")))
+if os.path.exists(os.path.join(O, "bench_long.json")):  # (round 5: the compact line the driver reads, and the long form beside it)
+    bench = json.load(open(os.path.join(O, "bench_long.json")))
     shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "%s_bench_default.json" % TAG))
-else:  # a subset run (PM_REFRESH_ONLY): the line of the last full run names the workloads
-    bench = json.load(open(os.path.join(ROOT, "profiles", "%s_bench_default.json" % TAG)))
+    shutil.copy(os.path.join(O, "bench_long.json"), os.path.join(P, "%s_bench_long.json" % TAG))
+    shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "bench.json"))
+else:  # a subset run (PM_REFRESH_ONLY): the long form of the last full run names the workloads
+    bench = json.load(open(os.path.join(ROOT, "profiles", "%s_bench_long.json" % TAG)))
 table_path = os.path.join(P, "pmc_traffic.json")
 old_table = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 table = json.load(open(old_table)) if os.path.exists(old_table) else {}
