@@ -1830,22 +1830,14 @@ __global__ void dp_gate_kernel(const int *__restrict__ started, int total) {
   }
 }
 
-// The gate itself.  Where the device can make a STREAM wait for a value in memory (hipStreamWaitValue32: the command processor polls, no
-// wavefront does) that is the gate: round 4's kernel trace held 66 gate kernels of 40 ms each, 28 % of all kernel time -- one lane
-// polling, nothing lost but a wavefront slot, yet not a kernel anybody wants in a profile.  Measured first by itself
-// (tools/ubench/wait_value.hip: a stream held back until the 20 000 workgroups of a kernel on another stream had counted themselves
-// in went on 4.6-5.2 ms before that kernel ended).  The wait has no time-out where the kernel's was bounded: it is only ever enqueued
-// behind a launch that has been accepted (hipGetLastError), whose every workgroup counts itself in at entry, so the value is reached
-// whatever else happens.  pm_dp_options_t.no_gate turns the gates off altogether; a device without the attribute keeps the kernel.
+// The gate itself: the polling kernel above, with its bounded wait.  Round 5 tried the runtime's own stream operation instead
+// (hipStreamWaitValue32 on the counter; probed by itself first, tools/ubench/wait_value.hip: it does hold a stream back until a kernel
+// on another stream has counted its workgroups in) hoping to take the gates out of the kernel trace -- and found that the runtime
+// implements it as a polling kernel of its own (`__amd_rocclr_streamOpsWait`: 66 calls x 40.4 ms in the headline's trace, exactly
+// where dp_gate_kernel's 66 x 40.4 ms had been), WITHOUT a time-out: under `rocprofv3 --pmc`, which runs kernels one at a time in
+// whatever order it picks them from the queues, a wait picked before the kernel it waits for never ends, where the bounded kernel
+// gives up after a second and lets the pass go on slowly (the profile refresh hung on its first counter pass).  So: this kernel.
 static int dp_gate(hipStream_t stream, int *started, int total) {
-  static const int can_wait = [] {
-    int dev = 0, can = 0;
-    return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess ? can : 0;
-  }();
-  if(can_wait) {
-    PM_HIP(hipStreamWaitValue32(stream, started, (uint32_t)total, hipStreamWaitValueGte, 0xffffffffu));
-    return PM_OK;
-  }
   dp_gate_kernel<<<1, 64, 0, stream>>>(started, total);
   PM_HIP(hipGetLastError());
   return PM_OK;

@@ -30,7 +30,9 @@ KNOBS = {"PM_DP_MODE": ["ckpt", "ckpt", "bits", None], "PM_DP_COLS": ["8", "16",
          # full-width last stripes instead of the narrow ones
          "PM_DP_TIER_MIN_PAIRS": ["8", "8", "16", None], "PM_DP_NO_TIERS": ["1", None, None, None, None], "PM_DP_TAIL": ["0", None, None],
          # tiles from a queue (round 5): never, tiles of 64 / 128 / 512 steps for every checkpoint or score launch, or the library's own rule
-         "PM_DP_TILE": ["0", "64", "64", "128", "512", None, None]}
+         "PM_DP_TILE": ["0", "64", "64", "128", "512", None, None],
+         # the walk beside the fill kernel of its own launch (off by default): on for a quarter of the cases
+         "PM_DP_EARLY_WALK": ["1", None, None, None]}
 
 
 def random_case(rng):
