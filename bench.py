@@ -799,8 +799,8 @@ def compact_line(result):
 
     def clip(d, limit):
         for k, v in d.items():
-            if isinstance(v, str) and len(v) > limit:
-                d[k] = v[:limit]
+            if isinstance(v, str) and len(v) > (300 if k == "workload" else limit):
+                d[k] = v[:(300 if k == "workload" else limit)]
             elif isinstance(v, dict):
                 clip(v, 160)
     clip(out, 300)
