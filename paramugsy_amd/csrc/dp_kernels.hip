@@ -2182,7 +2182,11 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
     if(!h->early_stream) {
       PM_HIP(hipStreamCreateWithFlags(&h->early_stream, hipStreamNonBlocking));
     }
-    const size_t slots = (size_t)std::max(K, 1);
+    // lists per chunk -- or per part of the workspace where the chunks take those in turn: there the fill stream of chunk c has waited
+    // for chunk c - K to be done with everything (ev_path) before it zeroes the lists chunk c - K used.  (The fuzzer's find of round 5:
+    // a batch that fits, cut into five chunks with parts of their own, shared three sets of lists -- chunk 3 zeroed the lists chunk 0's
+    // walkers were still waiting on, and they waited for a count that never came.)
+    const size_t slots = h->slot_reuse ? (size_t)std::max(K, 1) : std::max<size_t>(nc, 1);
     while(h->ev_early_ready.size() < slots) {
       hipEvent_t a = nullptr, b = nullptr;
       PM_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));

@@ -99,6 +99,7 @@ t_end = time.time() + budget
 cases = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
+    t_case = time.time()
     inputs, p, rows, la, lb = random_case(rng)
     env = {k: str(rng.choice([x for x in v if x is not None] + [""] * sum(x is None for x in v))) for k, v in KNOBS.items()}
     env = {k: v for k, v in env.items() if v}
@@ -115,6 +116,13 @@ while time.time() < t_end:
     n_workers = int(rng.integers(2, 5))
     if engine == "stream_text" and rows > 255:
         engine = "stream"
+    if os.environ.get("PM_FUZZ_DRY"):  # what a seed draws, without running it (no GPU needed)
+        print("seed", seed, "pairs", len(la), "rows", rows, "la", la[:12], "lb", lb[:12], env, "engine", engine, "workers", n_workers, flush=True)
+        seed += 1
+        cases += 1
+        if cases >= int(os.environ["PM_FUZZ_DRY"]):
+            break
+        continue
     streamed = engine != "batch"
     try:
         if engine in ("stream", "stream_text"):
@@ -155,8 +163,11 @@ while time.time() < t_end:
         continue
     if streamed:
         env = dict(env, engine=engine)
+    t_gpu = time.time() - t_case
     o_scores, o_paths = pyoracle.dp_align(inputs, p)
     ok = np.array_equal(scores, o_scores) and all(np.array_equal(x, y) for x, y in zip(paths, o_paths))
+    if t_gpu > 0.5:  # a case that takes the GPU side this long is waiting for something (a bounded wait running out?)
+        env = dict(env, SLOW_s=round(t_gpu, 2))
     print("seed", seed, "pairs", len(la), "rows", rows, "max", max(la + [0]), "x", max(lb + [0]), env, ("ckpt" if v["checkpoints"] else "bits") if v["checkpoints"] != "?" else "-", "cols", v["cols_per_lane"],
           "OK" if ok else "MISMATCH", flush=True)
     if not ok:
