@@ -280,8 +280,9 @@ typedef struct pm_dp_options {
   int32_t no_gate;         /* 1: a chunk's fill kernel is not held back until the chunk before has nothing left to dispatch */
   int32_t tile_steps;      /* 1: no launch takes its work from a queue of tiles; a multiple of 64: every checkpoint / score launch does, in
                             * tiles of that many steps (default: launches of few long pairs, 1 024 steps) */
-  int32_t early_walk;      /* 2: the walk also runs BESIDE the fill kernel of its own launch wherever the launch allows it (one wavefront per pair):
-                            * finished pairs are taken from per-XCD lists while the fill goes on.  Default (0, 1): not -- measured slower */
+  int32_t early_walk;      /* the walk BESIDE the fill kernel of its own launch (finished pairs taken from per-XCD lists while the fill goes on):
+                            * 1: never; 2: wherever a launch allows it (one wavefront per pair); default: launches of long pairs whose walk
+                            * nothing else hides */
   int32_t reserved;
   int64_t segment_cells;   /* host-fed engine: no more upload segments than leave each this many cells (default 5e9) */
 } pm_dp_options_t;

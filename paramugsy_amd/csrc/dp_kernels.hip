@@ -529,6 +529,12 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   if(NW > 1) { // several wavefronts per pair: a launch of few, long pairs (a tier beside the launch of the rest): ahead of those at issue
     __builtin_amdgcn_s_setprio(2);
   }
+  else if(fl.list) {
+    // walkers run beside this launch (DpEarly): the fill goes first at issue, the walkers take the cycles it leaves (a fifth of them:
+    // the fill kernel issues a VALU instruction in four cycles of five) -- side by side at EQUAL priority every instruction of a walker
+    // is one the fill does not issue, and the fill took 1.4 ms longer for a walk that costs 1.0 ms behind it (profiles/r05_early_walk.txt)
+    __builtin_amdgcn_s_setprio(1);
+  }
   if(started && threadIdx.x == 0) { // dp_gate_kernel: once every workgroup of this launch has started, the next chunk's may
     __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -2169,16 +2175,26 @@ int dp_run(pm_dp_batch *h, hipStream_t stream, int traceback, float *ms_fill, fl
   } ew;
   auto early_prepare = [&](size_t c, i64 first, i64 n, hipStream_t fill_stream) -> int {
     ew = EarlyWalk();
-    // NOT taken by default (opt.early_walk = 2 turns it on): measured on one MI355X (profiles/r05_early_walk.txt) the walkers beside
-    // the fill kernel do the walk's work at a worse rate than the walk kernel does behind it -- a wavefront per SIMD of the 32-lane
-    // walk is a chain of blocks with nothing to hide its latency -- and every instruction they issue is one the fill kernel does not:
-    // 10 000 pairs of 2 x 1 000: 2.99 ms a step without, 3.72 with (the fill kernel 1.92 -> 3.11 ms, the walk behind it 1.01 -> 0.23);
-    // one GPU's eighth of the ragged batch 15.7 -> 15.4 ms.  Both kernels are bound by VALU issue: running them side by side moves the
-    // work, it does not remove it.
-    if(!traceback || !h->ckpt || h->opt.early_walk != 2 || h->band_work_items > 0 || !h->seg_first.empty() || n <= 0) {
+    // By itself: for the launches whose walk nothing else hides (a batch of one chunk, the last chunk of a batch of several) when the
+    // pairs are LONG (a mean of 3 000 columns and more in La + Lb).  Measured on one MI355X (profiles/r05_early_walk.txt), with the fill
+    // kernel ahead of the walkers at issue (s_setprio: the walkers take the cycles the fill leaves): one GPU's eighth of the ragged
+    // batch 16.3 -> 14.9 ms a step, of the headline batch 41.3 -> 40.3.  NOT for short pairs: 10 000 pairs of 2 x 1 000 finish in two
+    // bursts, a round of wavefronts each -- there is nothing to walk for the first half of the launch and too much at its end, and the
+    // walkers that are in the middle of a pair when the fill ends hold the launch behind it up (3.03 -> 3.37 ms; at equal priority
+    // 3.72).  opt.early_walk: 1 never, 2 wherever the launch allows it.
+    if(!traceback || !h->ckpt || h->opt.early_walk == 1 || h->band_work_items > 0 || !h->seg_first.empty() || n <= 0) {
       return PM_OK;
     }
-    (void)c;
+    if(h->opt.early_walk != 2) {
+      double columns = 0;
+      for(i64 q = first; q < first + n; ++q) {
+        const i64 k = h->order[(size_t)q];
+        columns += (double)(h->off_a[k + 1] - h->off_a[k] + h->off_b[k + 1] - h->off_b[k]);
+      }
+      if(c + 1 != nc || n < 2048 || columns < 3000.0 * (double)n) {
+        return PM_OK;
+      }
+    }
     if(!h->early_stream) {
       PM_HIP(hipStreamCreateWithFlags(&h->early_stream, hipStreamNonBlocking));
     }
