@@ -166,6 +166,12 @@ int pm_job_kernel_bytes(pm_job_t *job, int64_t *count_bytes, int64_t *emit_bytes
  * wavefronts), else 64 (the reference's `long`, lib/profiles_lib/m_range.hh:8).  pm_translate_options_t.coordinate_bits = 64
  * forces 64. */
 int pm_job_coordinate_bits(pm_job_t *job, int *bits);
+/* Width the job holds SEQUENCE POSITIONS in (round 5).  A job whose positions pass 2^25 -- a chromosome, a concatenated assembly --
+ * while every row's and entry's span, length and gap column stays below it keeps its positions in 64 bits and runs everything else
+ * as the 32-bit job does: a position enters the arithmetic only as its difference from the start of a row or entry that contains it
+ * (lib/profiles_lib/m_profile.cc:93-99), and that difference is bounded by the row's length.  Such a job reports coordinate_bits 32,
+ * position_bits 64; its results are those of the reference's `long` (lib/profiles_lib/m_range.hh:8), checked like the 32-bit job's. */
+int pm_job_position_bits(pm_job_t *job, int *bits);
 void pm_job_destroy(pm_job_t *job);
 
 /* Batched coordinate conversions on one side's rows (a3/a4).  `row` selects the row per query; results and

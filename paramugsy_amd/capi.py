@@ -69,7 +69,7 @@ ENTRY_DTYPE = np.dtype([("ref_start", "<i8"), ("ref_end", "<i8"), ("qry_start", 
 EXPORTS = [
     "pm_last_error", "pm_release_caches", "pm_device_count", "pm_device_info",
     "pm_translate_set_default_options", "pm_job_create_opt", "pm_job_create_from_workload_opt", "pm_translate_files_opt",
-    "pm_job_create", "pm_job_text", "pm_job_text_fetch", "pm_job_text_fetch_range", "pm_job_run", "pm_job_run_profiled", "pm_job_sizes", "pm_job_fetch", "pm_job_algorithmic_bytes", "pm_job_kernel_bytes", "pm_job_coordinate_bits", "pm_job_destroy",
+    "pm_job_create", "pm_job_text", "pm_job_text_fetch", "pm_job_text_fetch_range", "pm_job_run", "pm_job_run_profiled", "pm_job_sizes", "pm_job_fetch", "pm_job_algorithmic_bytes", "pm_job_kernel_bytes", "pm_job_coordinate_bits", "pm_job_position_bits", "pm_job_destroy",
     "pm_rows_profile_idx_of_seq_idx_batch", "pm_rows_seq_idx_of_profile_idx_batch",
     "pm_workload_load", "pm_workload_tables", "pm_workload_row_name", "pm_workload_destroy", "pm_job_create_from_workload", "pm_job_units",
     "pm_translate_files", "pm_translate_files_as", "pm_sort_delta", "pm_maf_analyzer", "pm_profiles_make", "pm_stage_files", "pm_untranslate",
@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
         l.pm_job_algorithmic_bytes.argtypes = [C.c_void_p, _i64p]
         l.pm_job_kernel_bytes.argtypes = [C.c_void_p, _i64p, _i64p, _i64p]
         l.pm_job_coordinate_bits.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        l.pm_job_position_bits.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         l.pm_job_destroy.argtypes = [C.c_void_p]
         l.pm_job_destroy.restype = None
         for name in ("pm_rows_profile_idx_of_seq_idx_batch", "pm_rows_seq_idx_of_profile_idx_batch"):

@@ -32,6 +32,12 @@ typedef long long i64;
 // values, and the merge, which accumulates, checks what it carries after every step (Merge::narrow_overflow) and
 // reports PM_ST_NARROW if anything leaves +-2^26; a job that sees PM_ST_NARROW anywhere is redone with
 // I = long long (pm_job_create).
+// A second type, P, is what SEQUENCE POSITIONS are held in (a row's range, an entry's two ranges, and what is derived from them inside
+// unit_prefix / unit_setup); everything else -- lengths, gap columns, prefix tables, the whole merge and what it writes -- is in
+// profile or entry COLUMNS, type I.  P = I for the two cases above.  I = int with P = long long (round 5) is the job whose
+// positions need the reference's `long` (a chromosome beyond 2^25) while every row, entry and gap list is short: positions enter
+// only as differences from a row's or entry's start, which are bounded by the row's length -- so the set-up subtracts in 64 bits, the
+// difference is an int, and from there on it is the int job (its emit pass IS the int job's emit pass: no position in it).
 #define PM_ST_NARROW 100 /* internal: never leaves the library */
 #define PM_NARROW_INPUT_LIMIT (1 << 25)
 
@@ -43,10 +49,10 @@ struct alignas(2 * sizeof(I)) R2T {
 typedef R2T<i64> R2;
 
 // Rows of one side, device resident.
-template <typename I>
+template <typename I, typename P = I>
 struct RowsT {
   i64 n;
-  const R2T<I> *range; // [n]
+  const R2T<P> *range; // [n]
   const I *length;     // [n]
   const i64 *gap_off;  // [n+1]
   const R2T<I> *gaps;  // [gap_off[n]]
@@ -56,11 +62,11 @@ struct RowsT {
 typedef RowsT<i64> RowsD;
 
 // Delta entries, device resident, in both orientations (o = 0 as read, 1 = M_delta_entry::reverse, m_delta.cc:94-146).
-template <typename I>
+template <typename I, typename P = I>
 struct DeltasT {
   i64 n;
-  const R2T<I> *ref;  // [n] as read
-  const R2T<I> *qry;  // [n]
+  const R2T<P> *ref;  // [n] as read
+  const R2T<P> *qry;  // [n]
   const i64 *ref_off; // [n+1]
   const i64 *qry_off; // [n+1]
   const R2T<I> *ref_gaps[2];
@@ -92,9 +98,9 @@ PM_HD __forceinline__ bool overlap(R2T<I> a, R2T<I> b, R2T<I> &o) {
 }
 
 // A profile as the conversions see it: range, p_length, gap list + prefix table.
-template <typename I>
+template <typename I, typename P = I>
 struct PVT {
-  R2T<I> range;
+  R2T<P> range;
   I len;
   const R2T<I> *g;
   const I *pre; // n+1 entries
@@ -107,14 +113,14 @@ typedef PVT<i64> PV;
 // lower bound.
 // `at` = the lower bound itself: the gaps before index `at` lie wholly before the returned column, gap `at` (if any)
 // starts after it.
-template <typename I>
-PM_HD inline int profile_idx_of_seq_idx(const PVT<I> &p, I si, I &out, int &at) {
-  R2T<I> f = fwd_of(p.range);
+template <typename I, typename P>
+PM_HD inline int profile_idx_of_seq_idx(const PVT<I, P> &p, P si, I &out, int &at) {
+  R2T<P> f = fwd_of(p.range);
   if(!(f.s <= si && si <= f.e)) {
     return PM_ST_SEQ_IDX_OUT_OF_RANGE;
   }
-  I d = p.range.s - si;
-  I offset = (d < 0 ? -d : d) + 1;
+  P d = p.range.s - si;
+  I offset = (I)((d < 0 ? -d : d) + 1); // within the row: at most its length
   int lo = 0, hi = p.n;
   while(lo < hi) {
     int mid = (lo + hi) >> 1;
@@ -130,16 +136,16 @@ PM_HD inline int profile_idx_of_seq_idx(const PVT<I> &p, I si, I &out, int &at) 
   return PM_ST_OK;
 }
 
-template <typename I>
-PM_HD inline int profile_idx_of_seq_idx(const PVT<I> &p, I si, I &out) {
+template <typename I, typename P>
+PM_HD inline int profile_idx_of_seq_idx(const PVT<I, P> &p, P si, I &out) {
   int at;
   return profile_idx_of_seq_idx(p, si, out, at);
 }
 
 // a4, m_profile.cc:114-149.  First gap whose end is >= pi decides: inside it -> none, else the gaps
 // before it are skipped.
-template <typename I>
-PM_HD inline int seq_idx_of_profile_idx(const PVT<I> &p, I pi, I &out, bool &none) {
+template <typename I, typename P>
+PM_HD inline int seq_idx_of_profile_idx(const PVT<I, P> &p, I pi, P &out, bool &none) {
   none = false;
   if(!(pi < p.len + 1)) {
     return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
@@ -159,7 +165,7 @@ PM_HD inline int seq_idx_of_profile_idx(const PVT<I> &p, I pi, I &out, bool &non
     return PM_ST_OK;
   }
   I offset = pi - p.pre[lo] - 1;
-  out = fwd(p.range) ? p.range.s + offset : p.range.s - offset;
+  out = fwd(p.range) ? p.range.s + (P)offset : p.range.s - (P)offset;
   return PM_ST_OK;
 }
 
@@ -188,8 +194,8 @@ PM_HD __forceinline__ R2T<I> view_get(const GapViewT<I> &v, int i) {
 
 // a5, m_profile.cc:160-206.  On an ascending disjoint list the gaps overlapping [s,e] are one index range.
 // Returns status; `none` mirrors the reference's empty option; seq = the sub profile's p_range.
-template <typename I>
-PM_HD inline int subset_profile(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I> &seq, bool &none) {
+template <typename I, typename P>
+PM_HD inline int subset_profile(const PVT<I, P> &p, I s, I e, GapViewT<I> &v, R2T<P> &seq, bool &none) {
   none = false;
   if(s <= 0 || p.len < s || e <= 0 || p.len < e) {
     return PM_ST_PROFILE_IDX_OUT_OF_RANGE;
@@ -242,7 +248,7 @@ PM_HD inline int subset_profile(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I
     }
   }
   bool n1, n2;
-  I ss = 0, se = 0;
+  P ss = 0, se = 0;
   int st = seq_idx_of_profile_idx(p, s, ss, n1);
   if(st) {
     return st;
@@ -254,7 +260,7 @@ PM_HD inline int subset_profile(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I
   if(n1 || n2) {
     return PM_ST_IS_NONE;
   }
-  seq = R2T<I>{ss, se};
+  seq = R2T<P>{ss, se};
   return PM_ST_OK;
 }
 
@@ -270,8 +276,8 @@ PM_HD inline int subset_profile(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I
 //     seq_idx_of_profile_idx of either end finds gap a starting after it and returns range.s +- (offset - 1),
 //     which is the sequence index the column came from.
 // What remains of subset_profile are its range checks.
-template <typename I>
-PM_HD inline int subset_seq(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I> &seq) {
+template <typename I, typename P>
+PM_HD inline int subset_seq(const PVT<I, P> &p, P s, P e, GapViewT<I> &v, R2T<P> &seq) {
   I ps, pe;
   int as, ae;
   int st = profile_idx_of_seq_idx(p, s, ps, as);
@@ -293,7 +299,7 @@ PM_HD inline int subset_seq(const PVT<I> &p, I s, I e, GapViewT<I> &v, R2T<I> &s
   v.we = swap ? ps : pe;
   v.mirror = false;
   v.L = 0;
-  seq = swap ? R2T<I>{e, s} : R2T<I>{s, e};
+  seq = swap ? R2T<P>{e, s} : R2T<P>{s, e};
   return PM_ST_OK;
 }
 
@@ -313,8 +319,8 @@ template <int KIND, typename I>
 PM_HD __forceinline__ bool lb_pred(const R2T<I> &g, I pre, I key) {
   return KIND == 0 ? g.s - pre <= key : (KIND == 1 ? g.e < key : g.s <= key);
 }
-template <typename I>
-PM_HD __forceinline__ LbProbe<I> lb_probe(const PVT<I> &p, bool on, I key) {
+template <typename I, typename P>
+PM_HD __forceinline__ LbProbe<I> lb_probe(const PVT<I, P> &p, bool on, I key) {
   return LbProbe<I>{p.g, p.pre, 0, on ? p.n : 0, key};
 }
 template <int K0, int K1, int K2, int K3, typename I>
@@ -355,11 +361,11 @@ PM_HD __forceinline__ void lower_bounds4(LbProbe<I> &a, LbProbe<I> &b, LbProbe<I
   }
 }
 // profile_idx_of_seq_idx's range test and offset (m_profile.cc:93-99): false = PM_ST_SEQ_IDX_OUT_OF_RANGE
-template <typename I>
-PM_HD __forceinline__ bool seq_idx_offset(const PVT<I> &p, I si, I &offset) {
-  const R2T<I> f = fwd_of(p.range);
-  const I d = p.range.s - si;
-  offset = (d < 0 ? -d : d) + 1;
+template <typename I, typename P>
+PM_HD __forceinline__ bool seq_idx_offset(const PVT<I, P> &p, P si, I &offset) {
+  const R2T<P> f = fwd_of(p.range);
+  const P d = p.range.s - si;
+  offset = (I)((d < 0 ? -d : d) + 1); // inside the row (the only case the value is used in): at most the row's length
   return f.s <= si && si <= f.e;
 }
 
@@ -807,9 +813,9 @@ struct Merge {
   }
 };
 
-template <typename I>
-PM_HD __forceinline__ PVT<I> row_view(const RowsT<I> &rows, int r) {
-  PVT<I> p;
+template <typename I, typename P>
+PM_HD __forceinline__ PVT<I, P> row_view(const RowsT<I, P> &rows, int r) {
+  PVT<I, P> p;
   p.range = rows.range[r];
   p.len = rows.length[r];
   i64 o = rows.gap_off[r];
@@ -822,9 +828,9 @@ PM_HD __forceinline__ PVT<I> row_view(const RowsT<I> &rows, int r) {
 // First part of a unit, up to the test that ends most of them (m_translate.cc:636-639 and :496-513): the
 // overlap of the entry with both rows, the entry's two rows as profiles over its own columns, and the window of
 // columns both rows cover.  `live` = the unit goes on to the subset/merge part.
-template <typename I>
-PM_HD inline int unit_prefix(const RowsT<I> &left, const RowsT<I> &right, const DeltasT<I> &ds, int d, int l, int r, PVT<I> &lp, PVT<I> &rp, PVT<I> &dr,
-                             PVT<I> &dq, R2T<I> &cols, bool &live, int &orientation) {
+template <typename I, typename P>
+PM_HD inline int unit_prefix(const RowsT<I, P> &left, const RowsT<I, P> &right, const DeltasT<I, P> &ds, int d, int l, int r, PVT<I, P> &lp,
+                             PVT<I, P> &rp, PVT<I, P> &dr, PVT<I, P> &dq, R2T<I> &cols, bool &live, int &orientation) {
   live = false;
   orientation = 0;
   if(left.bad[l] | right.bad[r] | ds.bad[d]) {
@@ -832,16 +838,16 @@ PM_HD inline int unit_prefix(const RowsT<I> &left, const RowsT<I> &right, const 
   }
   lp = row_view(left, l);
   rp = row_view(right, r);
-  R2T<I> de_ref = ds.ref[d], de_qry = ds.qry[d];
-  R2T<I> ref_seq, query_seq;
+  R2T<P> de_ref = ds.ref[d], de_qry = ds.qry[d];
+  R2T<P> ref_seq, query_seq;
   if(!overlap(de_ref, lp.range, ref_seq) || !overlap(de_qry, rp.range, query_seq)) {
     return PM_ST_OK; // :636-639
   }
   int o = fwd(de_ref) != fwd(lp.range) ? 1 : 0; // :210-217
   orientation = o;
   if(o) {
-    de_ref = R2T<I>{de_ref.e, de_ref.s};
-    de_qry = R2T<I>{de_qry.e, de_qry.s};
+    de_ref = R2T<P>{de_ref.e, de_ref.s};
+    de_qry = R2T<P>{de_qry.e, de_qry.s};
   }
   // the entry's two rows as profiles over its own columns (:496-506)
   i64 ro = ds.ref_off[d], qo = ds.qry_off[d];
@@ -849,12 +855,12 @@ PM_HD inline int unit_prefix(const RowsT<I> &left, const RowsT<I> &right, const 
   dr.n = (int)(ds.ref_off[d + 1] - ro);
   dr.g = ds.ref_gaps[o] + ro;
   dr.pre = ds.ref_pre[o] + ro + d;
-  dr.len = rlen(de_ref) + dr.pre[dr.n];
+  dr.len = (I)rlen(de_ref) + dr.pre[dr.n];
   dq.range = de_qry;
   dq.n = (int)(ds.qry_off[d + 1] - qo);
   dq.g = ds.qry_gaps[o] + qo;
   dq.pre = ds.qry_pre[o] + qo + d;
-  dq.len = rlen(de_qry) + dq.pre[dq.n];
+  dq.len = (I)rlen(de_qry) + dq.pre[dq.n];
 
   // :508-511: four profile_idx_of_seq_idx; their range tests in the reference's order, their searches together
   I o0, o1, o2, o3;
@@ -883,13 +889,14 @@ struct UnitStateT {
 typedef UnitStateT<i64> UnitState;
 
 // Set-up of a unit that passed unit_prefix (m_translate.cc:527-610): `proceed` = the merge has to run.
-template <bool EMIT, typename I>
-PM_HD inline int unit_setup(const PVT<I> &lp, const PVT<I> &rp, const PVT<I> &dr, const PVT<I> &dq, R2T<I> cols, Merge<EMIT, I> &m, bool &proceed) {
+template <bool EMIT, typename I, typename P>
+PM_HD inline int unit_setup(const PVT<I, P> &lp, const PVT<I, P> &rp, const PVT<I, P> &dr, const PVT<I, P> &dq, R2T<I> cols, Merge<EMIT, I> &m,
+                            bool &proceed) {
   proceed = false;
   // ---- :527-533: subset_profile (m_profile.cc:160-206) of the entry's two rows, side 0 = reference row, 1 = query row, stage by
   // stage for both at once.  Every stage is pure, so a side's status is found whatever the other side's is; the reference's (the
   // first side's first failure) is picked at the end.
-  const PVT<I> *pv[2] = {&dr, &dq};
+  const PVT<I, P> *pv[2] = {&dr, &dq};
   GapViewT<I> *vv[2] = {&m.delta.v0, &m.delta.v1};
   int st_side[2] = {PM_ST_OK, PM_ST_OK};
   bool none_side[2] = {false, false}, on[2];
@@ -951,7 +958,7 @@ PM_HD inline int unit_setup(const PVT<I> &lp, const PVT<I> &rp, const PVT<I> &dr
     }
   }
   // the sequence positions of the window's ends: seq_idx_of_profile_idx (m_profile.cc:114-149) of both, both sides
-  R2T<I> seq_side[2] = {{0, 0}, {0, 0}};
+  R2T<P> seq_side[2] = {{0, 0}, {0, 0}};
   {
 #pragma unroll
     for(int k = 0; k < 2; ++k) {
@@ -982,18 +989,18 @@ PM_HD inline int unit_setup(const PVT<I> &lp, const PVT<I> &rp, const PVT<I> &dr
     for(int k = 0; k < 2; ++k) {
       if(on[k]) {
         const I pi[2] = {cs[k], ce[k]};
-        I out[2];
+        P out[2];
         bool none = false;
 #pragma unroll
         for(int w = 0; w < 2; ++w) {
           none = none || (at[k][w] < pv[k]->n && gs[k][w] <= pi[w]);
           const I offset = pi[w] - pr[k][w] - 1;
-          out[w] = fwd(pv[k]->range) ? pv[k]->range.s + offset : pv[k]->range.s - offset;
+          out[w] = fwd(pv[k]->range) ? pv[k]->range.s + (P)offset : pv[k]->range.s - (P)offset;
         }
         if(none) {
           st_side[k] = PM_ST_IS_NONE;
         }
-        seq_side[k] = R2T<I>{out[0], out[1]};
+        seq_side[k] = R2T<P>{out[0], out[1]};
       }
     }
   }
@@ -1002,13 +1009,13 @@ PM_HD inline int unit_setup(const PVT<I> &lp, const PVT<I> &rp, const PVT<I> &dr
   if(none_side[0] || none_side[1]) {
     return PM_ST_OK; // :535
   }
-  const R2T<I> d_ref_seq = seq_side[0], d_query_seq = seq_side[1];
+  const R2T<P> d_ref_seq = seq_side[0], d_query_seq = seq_side[1];
   // ---- :539-545: subset_seq of the two row profiles (see subset_seq above for why two conversions each are all of it)
-  R2T<I> l_seq, r_seq;
+  R2T<P> l_seq, r_seq;
   {
-    const PVT<I> *rv[2] = {&lp, &rp};
+    const PVT<I, P> *rv[2] = {&lp, &rp};
     GapViewT<I> *rw[2] = {&m.rows.v0, &m.rows.v1};
-    const I si[2][2] = {{d_ref_seq.s, d_ref_seq.e}, {d_query_seq.s, d_query_seq.e}};
+    const P si[2][2] = {{d_ref_seq.s, d_ref_seq.e}, {d_query_seq.s, d_query_seq.e}};
     I off[2][2];
     bool ok[2];
 #pragma unroll
@@ -1053,8 +1060,8 @@ PM_HD inline int unit_setup(const PVT<I> &lp, const PVT<I> &rp, const PVT<I> &dr
     }
     if(st_row[0]) return st_row[0]; // :539-541
     if(st_row[1]) return st_row[1]; // :543-545
-    l_seq = swp[0] ? R2T<I>{d_ref_seq.e, d_ref_seq.s} : d_ref_seq;
-    r_seq = swp[1] ? R2T<I>{d_query_seq.e, d_query_seq.s} : d_query_seq;
+    l_seq = swp[0] ? R2T<P>{d_ref_seq.e, d_ref_seq.s} : d_ref_seq;
+    r_seq = swp[1] ? R2T<P>{d_query_seq.e, d_query_seq.s} : d_query_seq;
   }
   if(rlen(d_ref_seq) != rlen(l_seq) || rlen(d_query_seq) != rlen(r_seq)) {
     return PM_ST_ASSERT_SUB_LENGTHS; // :550-551
@@ -1128,9 +1135,9 @@ PM_HD inline void unit_save(const Merge<EMIT, I> &m, int orientation, UnitStateT
   s.mirrored = m.mirrored ? 1 : 0;
 }
 
-template <bool EMIT, typename I>
-PM_HD inline void unit_restore(const RowsT<I> &left, const RowsT<I> &right, const DeltasT<I> &ds, int d, int l, int r, const UnitStateT<I> &s,
-                               Merge<EMIT, I> &m) {
+template <bool EMIT, typename I, typename P>
+PM_HD inline void unit_restore(const RowsT<I, P> &left, const RowsT<I, P> &right, const DeltasT<I, P> &ds, int d, int l, int r,
+                               const UnitStateT<I> &s, Merge<EMIT, I> &m) {
   const R2T<I> *g[4] = {left.gaps + left.gap_off[l], right.gaps + right.gap_off[r], ds.ref_gaps[s.orientation] + ds.ref_off[d],
                     ds.qry_gaps[s.orientation] + ds.qry_off[d]};
   GapViewT<I> *v[4] = {&m.rows.v0, &m.rows.v1, &m.delta.v0, &m.delta.v1};
@@ -1160,10 +1167,10 @@ PM_HD inline void unit_restore(const RowsT<I> &left, const RowsT<I> &right, cons
 }
 
 // One whole unit: _translate_delta_with_profiles (m_translate.cc:625-647) + _generate_delta (:474-621).
-template <bool EMIT, typename I>
-PM_HD inline int run_unit(const RowsT<I> &left, const RowsT<I> &right, const DeltasT<I> &ds, int d, int l, int r,
+template <bool EMIT, typename I, typename P>
+PM_HD inline int run_unit(const RowsT<I, P> &left, const RowsT<I, P> &right, const DeltasT<I, P> &ds, int d, int l, int r,
                                Sink<EMIT, I> &sink) {
-  PVT<I> lp, rp, dr, dq;
+  PVT<I, P> lp, rp, dr, dq;
   R2T<I> cols;
   bool live;
   int orientation;

@@ -54,7 +54,10 @@ __global__ void prepare_rows_kernel(i64 n, const i64 *start, const i64 *end, con
   I *p = pre + o + r;
   i64 acc = 0, prev_end = 0;
   int flag = 0;
-  unsigned long long big = mag(start[r]) | mag(end[r]) | mag(length[r]);
+  // two ORs of magnitudes (an OR is below 2^k exactly when every one of them is): sequence POSITIONS, and everything counted in
+  // COLUMNS -- with the row's span, which bounds every difference of two positions inside it (translate_device.hpp, type P)
+  const unsigned long long big_pos = mag(start[r]) | mag(end[r]);
+  unsigned long long big = mag(length[r]) | mag(rlen(R2{start[r], end[r]}));
   for(i64 k = 0; k < m; ++k) {
     R2 g{gs[o + k], ge[o + k]};
     if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
@@ -71,8 +74,9 @@ __global__ void prepare_rows_kernel(i64 n, const i64 *start, const i64 *end, con
   if(bad) {
     bad[r] = flag;
   }
-  if(maxabs) { // an OR of magnitudes is below 2^k exactly when every one of them is
-    atomicOr(maxabs, big);
+  if(maxabs) {
+    atomicOr(maxabs, big_pos);
+    atomicOr(maxabs + 1, big);
   }
 }
 
@@ -93,7 +97,8 @@ __global__ void prepare_deltas_kernel(i64 n, const i64 *rs, const i64 *re, const
   I *pr = pre_rev + o + d;
   i64 acc = 0, prev_end = 0;
   int flag = 0;
-  unsigned long long big = mag(rg.s) | mag(rg.e);
+  const unsigned long long big_pos = mag(rg.s) | mag(rg.e);
+  unsigned long long big = mag(rlen(rg));
   for(i64 k = 0; k < m; ++k) {
     R2 g{gs[o + k], ge[o + k]};
     if(g.s > g.e || (k > 0 && g.s <= prev_end)) {
@@ -121,22 +126,23 @@ __global__ void prepare_deltas_kernel(i64 n, const i64 *rs, const i64 *re, const
     atomicOr(bad + d, 1);
   }
   if(maxabs) {
-    atomicOr(maxabs, big);
+    atomicOr(maxabs, big_pos);
+    atomicOr(maxabs + 1, big);
   }
 }
 
 // Filter pass: most (entry, left row, right row) triples the reference's loops visit end at the first overlap test
 // (m_translate.cc:513).  One lane per unit runs just that prefix; the survivors ("live" units) are compacted so that
 // the count and emit passes run on dense wavefronts instead of waiting for the few long lanes of every wavefront.
-template <typename I>
+template <typename I, typename P>
 __global__ void __launch_bounds__(64)
-translate_filter_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
+translate_filter_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                         int *status, i64 *cnt_ent, i64 *cnt_off, int *live_flag) {
   i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if(u >= n_units) {
     return;
   }
-  PVT<I> lp, rp, dr, dq;
+  PVT<I, P> lp, rp, dr, dq;
   R2T<I> cols;
   bool live;
   int orientation;
@@ -403,9 +409,9 @@ __device__ __forceinline__ void state_load(const void *base, i64 n, i64 k, UnitS
 // left its checked range (PM_ST_NARROW): pm_job_create then switches the job to the int64 tables.
 // The int64 emit pass needs 162 VGPRs: held to 128 it spilled 38 of them to scratch, in the merge loop -- three waves per SIMD without
 // spills are the faster (the bench job on the int64 tables 0.470 -> 0.396 ms a step; the count pass, 5 spills, is the same either way).
-template <bool EMIT, typename I>
+template <bool EMIT, typename I, typename P>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(I) == 8 && EMIT ? 3 : 4, 8)))
-translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
+translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                  const int *live_units, const int *live_pos, int *status, i64 *cnt_ent, i64 *cnt_off, const i64 *ent_off,
                  const i64 *off_off, typename EntRecT<I>::type *entries, I *offsets, i64 ent_cap, i64 off_cap, int *overflow, void *states,
                  int *narrow_trip, int *slow_flag, const int *slow_units, i64 n_slow, i64 *scratch, const i64 *slow_scratch_off) {
@@ -481,7 +487,7 @@ translate_kernel(RowsT<I> left, RowsT<I> right, DeltasT<I> ds, i64 n_units, cons
     m.sink.finish();
   }
   else {
-    PVT<I> lp, rp, dr, dq;
+    PVT<I, P> lp, rp, dr, dq;
     R2T<I> cols;
     bool live, proceed = false;
     int orientation;
@@ -927,6 +933,22 @@ struct DeltasStore {
     d.bad = (const int *)bad.p;
     return d;
   }
+  DeltasT<int, i64> view_mixed() const { // positions in 64 bits, the gap tables as int (translate_device.hpp)
+    DeltasT<int, i64> d;
+    d.n = n;
+    d.ref = (const R2 *)ref.p;
+    d.qry = (const R2 *)qry.p;
+    d.ref_off = (const i64 *)ref_off.p;
+    d.qry_off = (const i64 *)qry_off.p;
+    for(int o = 0; o < 2; ++o) {
+      d.ref_gaps[o] = (const R2T<int> *)ref_gaps32[o].p;
+      d.ref_pre[o] = (const int *)ref_pre32[o].p;
+      d.qry_gaps[o] = (const R2T<int> *)qry_gaps32[o].p;
+      d.qry_pre[o] = (const int *)qry_pre32[o].p;
+    }
+    d.bad = (const int *)bad.p;
+    return d;
+  }
   DeltasT<int> view32() const {
     DeltasT<int> d;
     d.n = n;
@@ -1035,6 +1057,10 @@ struct pm_job {
   int64_t off_bytes() const { return narrow ? 4 : 8; }
   bool library_scans = false; // PM_TRANSLATE_LIBRARY_SCANS=1 at pm_job_create: the prefix sums of jobs above SCAN_MAX_TILES tiles, for any job (tests)
   bool narrow = false; // the job runs on the int tables (every table value below PM_NARROW_INPUT_LIMIT, no PM_ST_NARROW seen)
+  // narrow, with the sequence positions -- and only them -- in 64 bits: a job whose positions pass PM_NARROW_INPUT_LIMIT while every
+  // length, span and gap column is below it (translate_device.hpp, type P).  Only the filter and count passes ever see a position;
+  // everything behind them (emit, fix, text, fetch) is the int job's
+  bool wide_positions = false;
   size_t scan_tmp32_bytes = 0;
   size_t scan_tmp_bytes = 0;
   i64 ent_cap = 0, off_cap = 0;
@@ -1057,14 +1083,20 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   }
   // 1. filter + compaction of the live units
   if(U > 0) {
-    if(j->narrow) {
-      translate_filter_kernel<int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), U,
+    if(j->narrow && j->wide_positions) {
+      translate_filter_kernel<int, i64><<<blocks, 64, 0, stream>>>(j->left.view_mixed(), j->right.view_mixed(), j->deltas.view_mixed(), U,
+                                                                   (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p,
+                                                                   (int *)j->status.p, (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p,
+                                                                   (int *)j->live_flag.p);
+    }
+    else if(j->narrow) {
+      translate_filter_kernel<int, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), U,
                                                               (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p,
                                                               (int *)j->status.p, (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p,
                                                               (int *)j->live_flag.p);
     }
     else {
-      translate_filter_kernel<i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U,
+      translate_filter_kernel<i64, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), U,
                                                               (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p,
                                                               (int *)j->status.p, (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p,
                                                               (int *)j->live_flag.p);
@@ -1098,11 +1130,14 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   U, (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,                 \
       (const int *)j->live_pos.p, (int *)j->status.p, (i64 *)j->cnt_ent.p, (i64 *)j->cnt_off.p, nullptr, nullptr, nullptr, nullptr, \
       0, 0, nullptr, j->states.p, (int *)j->narrow_trip.p, (int *)j->slow_flag.p, nullptr, 0, nullptr, nullptr
-    if(j->narrow) {
-      translate_kernel<false, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_COUNT_ARGS);
+    if(j->narrow && j->wide_positions) {
+      translate_kernel<false, int, i64><<<blocks, 64, 0, stream>>>(j->left.view_mixed(), j->right.view_mixed(), j->deltas.view_mixed(), PM_COUNT_ARGS);
+    }
+    else if(j->narrow) {
+      translate_kernel<false, int, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_COUNT_ARGS);
     }
     else {
-      translate_kernel<false, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_COUNT_ARGS);
+      translate_kernel<false, i64, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_COUNT_ARGS);
     }
 #undef PM_COUNT_ARGS
     PM_HIP(hipGetLastError());
@@ -1129,6 +1164,8 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
     PM_HIP(hipEventRecord(ev[3], stream));
   }
   // 4. emit pass over the live units
+  // (a job with wide positions: the int job's kernel on the int tables -- the emit pass restores the merge from the saved state and reads
+  // gap lists; no position enters it, and the int tables' ranges, which would be truncated, are not read)
   if(emit && U > 0) {
 #define PM_EMIT_ARGS_OF(I)                                                                                                        \
   U, (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,                \
@@ -1136,23 +1173,23 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
       (EntRecT<I>::type *)j->entries.p, (I *)j->offsets.p, j->ent_cap, j->off_cap, (int *)j->overflow.p, j->states.p,              \
       (int *)j->narrow_trip.p, nullptr
     if(j->narrow) {
-      translate_kernel<true, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS_OF(int),
+      translate_kernel<true, int, int><<<blocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS_OF(int),
                                                              nullptr, 0, nullptr, nullptr);
     }
     else {
-      translate_kernel<true, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS_OF(i64), nullptr, 0,
+      translate_kernel<true, i64, i64><<<blocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS_OF(i64), nullptr, 0,
                                                              nullptr, nullptr);
     }
     PM_HIP(hipGetLastError());
     if(j->n_slow > 0) { // the FIX pass: the few units whose offsets are not what on-the-fly emission gives
       const unsigned fblocks = (unsigned)((j->n_slow + 63) / 64);
       if(j->narrow) {
-        translate_kernel<true, int><<<fblocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS_OF(int),
+        translate_kernel<true, int, int><<<fblocks, 64, 0, stream>>>(j->left.view32(), j->right.view32(), j->deltas.view32(), PM_EMIT_ARGS_OF(int),
                                                                 (const int *)j->slow_units.p, j->n_slow, (i64 *)j->slow_scratch.p,
                                                                 (const i64 *)j->slow_scratch_off.p);
       }
       else {
-        translate_kernel<true, i64><<<fblocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS_OF(i64),
+        translate_kernel<true, i64, i64><<<fblocks, 64, 0, stream>>>(j->left.view(), j->right.view(), j->deltas.view(), PM_EMIT_ARGS_OF(i64),
                                                                 (const int *)j->slow_units.p, j->n_slow, (i64 *)j->slow_scratch.p,
                                                                 (const i64 *)j->slow_scratch_off.p);
       }
@@ -1243,9 +1280,9 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
       lap_t = t;
     }
   };
-  JTRY(j->maxabs.alloc(8));
+  JTRY(j->maxabs.alloc(16));
   JTRY(j->narrow_trip.alloc(4));
-  if(hipMemsetAsync(j->maxabs.p, 0, 8, stream) != hipSuccess || hipMemsetAsync(j->narrow_trip.p, 0, 4, stream) != hipSuccess) {
+  if(hipMemsetAsync(j->maxabs.p, 0, 16, stream) != hipSuccess || hipMemsetAsync(j->narrow_trip.p, 0, 4, stream) != hipSuccess) {
     pm_job_destroy(j);
     return fail(PM_E_HIP, "hipMemsetAsync failed");
   }
@@ -1355,13 +1392,19 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
   lap("units up, per-unit arrays");
   // int or int64 tables?  int when every magnitude in the tables is below the limit (PM_TRANSLATE_WIDE=1 forces int64)
   {
-    unsigned long long big = 0;
-    if(hipMemcpyAsync(&big, j->maxabs.p, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+    unsigned long long big[2] = {0, 0}; // [0] positions, [1] everything in columns
+    if(hipMemcpyAsync(big, j->maxabs.p, 16, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
       pm_job_destroy(j);
       return fail(PM_E_HIP, "hipMemcpy failed");
     }
     j->library_scans = opt.library_scans != 0;
-    j->narrow = big < (unsigned long long)PM_NARROW_INPUT_LIMIT && opt.coordinate_bits != 64;
+    j->narrow = big[1] < (unsigned long long)PM_NARROW_INPUT_LIMIT && opt.coordinate_bits != 64;
+    // positions beyond the limit (a chromosome, a concatenated assembly): they stay in 64 bits, and only they.  coordinate_bits = 32
+    // asks for the int tables outright where they are valid at all, so it keeps the positions narrow when they fit
+    j->wide_positions = j->narrow && big[0] >= (unsigned long long)PM_NARROW_INPUT_LIMIT;
+    if(big[0] >= (1ull << 62)) { // (positions whose differences could wrap in 64 bits: the spans in big[1] mean nothing then)
+      j->narrow = j->wide_positions = false;
+    }
   }
   // Size the outputs once: the inputs of a job never change, so neither do its output sizes.
   JTRY(job_launch_pass(j, stream, false, nullptr));
@@ -1374,6 +1417,7 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
     }
     if(trip) { // some unit's int merge left its checked range: this job runs on the int64 tables
       j->narrow = false;
+      j->wide_positions = false;
       // the sizing pass no longer stores zero counts for units that are not live: were the wide filter ever to keep fewer units than
       // the narrow one did, a stale count would corrupt the prefix sums.  The redo starts from cleared counts (once per job).
       if(hipMemsetAsync(j->cnt_ent.p, 0, (size_t)(U + 1) * 8, stream) != hipSuccess ||
@@ -1827,6 +1871,14 @@ int pm_job_coordinate_bits(pm_job_t *j, int *bits) {
     return fail(PM_E_INVALID, "pm_job_coordinate_bits: null argument");
   }
   *bits = j->narrow ? 32 : 64;
+  return PM_OK;
+}
+
+int pm_job_position_bits(pm_job_t *j, int *bits) {
+  if(!j || !bits) {
+    return fail(PM_E_INVALID, "pm_job_position_bits: null argument");
+  }
+  *bits = j->narrow && !j->wide_positions ? 32 : 64;
   return PM_OK;
 }
 

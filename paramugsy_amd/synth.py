@@ -258,3 +258,18 @@ def make_workload(root: str, seed: int, n_left: int = 3, n_right: int = 3, genom
     with open(list_path, "w") as f:
         f.write("".join(p + "\n" for p in paths))
     return Workload(left_dir, right_dir, list_path, paths)
+
+
+def shift_positions(tables, left_shift: int, right_shift: int):
+    """The same job further along its sequences: every left row and every entry's reference range moved by left_shift bases, every
+    right row and query range by right_shift.  What translate writes is in profile COLUMNS, so the result does not change -- which
+    makes this both a test property and the way to build a job whose positions need 64 bits (a chromosome beyond 2^25) out of a
+    bacterial-sized one.  Returns a new Tables; the input is left alone."""
+    import copy
+    t = copy.deepcopy(tables)
+    for side, shift in ((t.left, left_shift), (t.right, right_shift)):
+        side["start"] = side["start"] + np.int64(shift)
+        side["end"] = side["end"] + np.int64(shift)
+    for k, shift in (("ref_start", left_shift), ("ref_end", left_shift), ("qry_start", right_shift), ("qry_end", right_shift)):
+        t.deltas[k] = t.deltas[k] + np.int64(shift)
+    return t

@@ -159,6 +159,13 @@ class TranslateJob:
         capi.check(capi.lib().pm_job_coordinate_bits(self._h, C.byref(b)))
         return b.value
 
+    def position_bits(self) -> int:
+        """Width the job holds sequence positions in: 64 with coordinate_bits() == 32 is the job whose positions pass 2^25 while its rows
+        are short (pm_job_position_bits)."""
+        b = C.c_int()
+        capi.check(capi.lib().pm_job_position_bits(self._h, C.byref(b)))
+        return b.value
+
     def fetch(self) -> JobResult:
         ne, no = self.sizes()
         status = np.zeros(self.n_units, dtype=np.int32)

@@ -28,7 +28,7 @@ def harness(tmp_path_factory):
         cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     subprocess.run(cmd, check=True, capture_output=True)
     h = C.CDLL(out)
-    for fn in (h.unit_host_run, h.unit_host_run_narrow):
+    for fn in (h.unit_host_run, h.unit_host_run_narrow, h.unit_host_run_wide_positions):
         fn.argtypes = [C.c_void_p] * 4 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_int64,
                        C.c_void_p, C.c_int64]
     return h
@@ -37,8 +37,26 @@ def harness(tmp_path_factory):
 PM_ST_NARROW = 100  # internal status of the int instantiation: "redo this job in int64"
 
 
+WIDTHS = [False, True, "positions"]  # int64; int; int columns with 64-bit sequence positions (round 5)
+LIMIT = 1 << 25  # PM_NARROW_INPUT_LIMIT
+
+
+def columns_fit_int(t):
+    """What pm_job_create checks before it takes the wide-positions job: every length, span and gap column below the limit."""
+    big = 0
+    for side in (t.left, t.right):
+        for k in ("length", "gap_start", "gap_end"):
+            big = max(big, int(np.abs(side[k]).max(initial=0)))
+        big = max(big, int((np.abs(side["end"] - side["start"]) + 1).max(initial=0)), int(side["length"].sum()))
+    for a, b in (("ref_start", "ref_end"), ("qry_start", "qry_end")):
+        big = max(big, int((np.abs(t.deltas[b] - t.deltas[a]) + 1).max(initial=0)))
+    for k in ("ref_gap_start", "ref_gap_end", "qry_gap_start", "qry_gap_end"):
+        big = max(big, int(np.abs(t.deltas[k]).max(initial=0)))
+    return big < LIMIT // 4  # (with room for the prefix sums, which the library checks one by one)
+
+
 def host_run(h, t, narrow=False):
-    run = h.unit_host_run_narrow if narrow else h.unit_host_run
+    run = {False: h.unit_host_run, True: h.unit_host_run_narrow, "positions": h.unit_host_run_wide_positions}[narrow]
     ls, k1 = capi.rows_struct(t.left)
     rs, k2 = capi.rows_struct(t.right)
     ds, k3 = capi.deltas_struct(t.deltas)
@@ -62,10 +80,21 @@ def check_against_oracle(h, t, narrow=False):
     """narrow: the int instantiation of the same code (the fast path for tables below 2^25).  It must either give the
     oracle's answer on every unit, or report PM_ST_NARROW somewhere (the library then redoes the job in int64)."""
     import pyoracle
+    ora0 = None
+    if narrow == "positions":
+        # the same job 2^40 bases along its left sequences and 2^33 along its right ones: the positions need the `long`, the columns do
+        # not -- and what the job writes (columns) is what the unmoved job writes
+        if not columns_fit_int(t):
+            return None  # the library would not take this instantiation for such tables
+        ora0 = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
+        t = synth.shift_positions(t, (1 << 40) + 12345, (1 << 33) + 777)
     st, eo, ent, off = host_run(h, t, narrow)
     if narrow and (st == PM_ST_NARROW).any():
         return None
     ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
+    if ora0 is not None:
+        assert np.array_equal(ora0["status"], ora["status"]) and np.array_equal(ora0["offsets"], ora["offsets"])
+        assert ora0["entries"].tobytes() == ora["entries"].tobytes()
     assert np.array_equal(st, ora["status"])
     assert np.array_equal(eo, ora["unit_entry_off"])
     assert np.array_equal(off, ora["offsets"])
@@ -74,7 +103,7 @@ def check_against_oracle(h, t, narrow=False):
     return st
 
 
-@pytest.mark.parametrize("narrow", [False, True])
+@pytest.mark.parametrize("narrow", WIDTHS)
 @pytest.mark.parametrize("name", ["typical", "gappy", "reverse", "tiny_blocks", "empty"])
 def test_device_code_equals_oracle_on_golden_inputs(name, narrow, harness, oracle_build):
     case = os.path.join(GOLDEN, "translate_" + name)
@@ -85,7 +114,7 @@ def test_device_code_equals_oracle_on_golden_inputs(name, narrow, harness, oracl
     assert st is not None and (st == 0).all()  # sane tables never trip the int path's range check
 
 
-@pytest.mark.parametrize("narrow", [False, True])
+@pytest.mark.parametrize("narrow", WIDTHS)
 @pytest.mark.parametrize("seed", range(4242, 4250))
 def test_device_code_equals_oracle_on_inconsistent_tables(seed, narrow, harness, oracle_build, tmp_path):
     from test_translate_gpu import MODES, corrupt_tables
@@ -96,7 +125,7 @@ def test_device_code_equals_oracle_on_inconsistent_tables(seed, narrow, harness,
     assert st is None or (st != 0).any()
 
 
-@pytest.mark.parametrize("narrow", [False, True])
+@pytest.mark.parametrize("narrow", WIDTHS)
 @pytest.mark.parametrize("seed,mode", [(33, "typical"), (188, "reverse"), (208, "typical"), (219, "gappy"), (298, "reverse")])
 def test_gaps_out_of_the_writers_order_are_merged_as_the_writer_does(seed, mode, narrow, harness, oracle_build, tmp_path):
     """Tables that contradict themselves can hand the builder gaps in another order than the writer's two-list merge
@@ -121,7 +150,7 @@ def test_gaps_out_of_the_writers_order_are_merged_as_the_writer_does(seed, mode,
     check_against_oracle(harness, t, narrow)
 
 
-@pytest.mark.parametrize("narrow", [False, True])
+@pytest.mark.parametrize("narrow", WIDTHS)
 def test_column_gapped_in_both_rows_prints_what_the_reference_prints(narrow, harness, oracle_build):
     """A delta entry with the same column gapped in its reference row AND its query row cannot come out of a delta file
     (m_delta.cc:50-68 hands out columns once); given one, the reference's writer takes the query gap first (ties go to the query
@@ -155,12 +184,12 @@ def test_int_path_near_its_entry_limit(harness, oracle_build, tmp_path):
         t.deltas[k] += shift
     biggest = max(int(np.abs(a).max()) for a in (t.left["start"], t.left["end"], t.right["start"], t.right["end"]))
     assert (1 << 24) < biggest < (1 << 25)
-    for narrow in (False, True):
+    for narrow in WIDTHS:
         st = check_against_oracle(harness, t, narrow)
         assert st is not None and (st == 0).all()
 
 
-@pytest.mark.parametrize("narrow", [False, True])
+@pytest.mark.parametrize("narrow", WIDTHS)
 def test_dropped_segment_with_more_gaps_than_the_unit_has_offsets(narrow, harness, oracle_build):
     """The FIX pass's scratch list holds (offsets of the unit + 1) gaps: enough for every segment that commits, because a gap
     owns at least one of its segment's offsets.  A segment that is dropped (b_finish does not commit) can hold more: twenty

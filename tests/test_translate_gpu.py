@@ -370,27 +370,64 @@ def test_full_size_job_bytes_equal_cpu_side(oracle_build, tmp_path):
 
 
 def test_coordinate_width_is_chosen_from_the_tables(coordinate_width, oracle_build, tmp_path):
-    """Numbers below 2^25 -> int kernels (unless PM_TRANSLATE_WIDE=1); one sequence coordinate at 2^25 or above ->
-    int64 kernels.  Either way the oracle's answer, also with coordinates just below the limit."""
+    """Numbers below 2^25 -> int kernels (unless PM_TRANSLATE_WIDE=1).  Sequence POSITIONS at 2^25 or above, with every row, entry and
+    gap list still short -> the int kernels with 64-bit positions (round 5: a position enters the arithmetic only as its distance
+    from the start of the row that contains it).  A length, span or gap column at 2^25 or above -> int64 kernels.  Either way the
+    oracle's answer -- and, translate's output being columns, the same answer wherever along its sequences the job lies."""
     import pyoracle
     w = synth.make_workload(str(tmp_path / "job"), 5, **MODES["typical"])
-    for shift, bits_if_free in (((1 << 25) - 70000, 32), ((1 << 25) + 5, 64), ((1 << 40), 64)):
-        t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
-        for side in (t.left, t.right):
-            side["start"] += shift
-            side["end"] += shift
-        for k in ("ref_start", "ref_end", "qry_start", "qry_end"):
-            t.deltas[k] += shift
+    t0 = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+    first = None
+    for lshift, rshift, long_row, bits_if_free, pos_bits_if_free in (
+            ((1 << 25) - 70000, (1 << 25) - 70000, False, 32, 32), ((1 << 25) + 5, (1 << 25) + 5, False, 32, 64),
+            (1 << 40, 0, False, 32, 64), (0, (1 << 33) + 9, False, 32, 64), ((1 << 61) + 3, 1 << 47, False, 32, 64),
+            (1 << 62, 0, False, 64, 64),  # differences of such positions could wrap: nothing is assumed about them
+            (1 << 40, 1 << 40, True, 64, 64)):
+        t = synth.shift_positions(t0, lshift, rshift)
+        if long_row:  # one row (no unit uses it) that spans 2^25 bases: the columns no longer fit, the job is the int64 job
+            for k, v in (("start", 1), ("end", (1 << 25) + 10), ("length", (1 << 25) + 10)):
+                t.left[k] = np.append(t.left[k], np.int64(v))
+            t.left["gap_off"] = np.append(t.left["gap_off"], t.left["gap_off"][-1])
         job = TranslateJob(t)
         try:
-            assert job.coordinate_bits() == (64 if coordinate_width == "int64" else bits_if_free)
+            forced = coordinate_width == "int64"
+            assert job.coordinate_bits() == (64 if forced else bits_if_free)
+            assert job.position_bits() == (64 if forced else pos_bits_if_free)
+            job.run()
+            res = job.fetch()
+            job.run()  # (and again: the emit pass of the job with wide positions is the int job's, from the saved states)
+            res2 = job.fetch()
+        finally:
+            job.close()
+        ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
+        assert_same_result(res, ora)
+        assert_same_result(res2, ora)
+        assert (res.status == 0).all() and len(res.entries) > 10
+        if first is None:
+            first = res
+        assert res.entries.tobytes() == first.entries.tobytes() and np.array_equal(res.offsets, first.offsets)
+
+
+def test_wide_positions_through_the_files_and_the_failure_classes(coordinate_width, oracle_build, tmp_path):
+    """The job with 64-bit positions (int columns) on tables that contradict themselves: the same failure classes as the oracle, unit by
+    unit, as for the other two widths (test_failure_classes_equal_oracle); and on every mode of the generator."""
+    import pyoracle
+    for seed, mode in ((4242, "reverse"), (4243, "tiny_blocks"), (77, "gappy")):
+        w = synth.make_workload(str(tmp_path / ("job%d" % seed)), seed, **MODES[mode])
+        t = Workload.load(w.left_dir, w.right_dir, w.delta_paths).tables()
+        if seed != 77:
+            corrupt_tables(t, np.random.default_rng(seed))
+        t = synth.shift_positions(t, (1 << 36) + 11, (1 << 52) + 5)
+        job = TranslateJob(t)
+        try:
+            assert job.position_bits() == 64 and job.coordinate_bits() == (64 if coordinate_width == "int64" else 32)
             job.run()
             res = job.fetch()
         finally:
             job.close()
         ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
         assert_same_result(res, ora)
-        assert (res.status == 0).all() and len(res.entries) > 10
+        assert (res.status != 0).any() == (seed != 77)
 
 
 def test_file_level_failure_writes_what_precedes_it(tmp_path):

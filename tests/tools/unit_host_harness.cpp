@@ -15,14 +15,15 @@ using namespace pm;
 
 namespace {
 
-template <typename I>
+template <typename I, typename P>
 struct HostRows {
-  std::vector<R2T<I>> range, gaps;
+  std::vector<R2T<P>> range;
+  std::vector<R2T<I>> gaps;
   std::vector<I> length, pre;
   std::vector<i64> gap_off;
   std::vector<int> bad;
-  RowsT<I> view() const {
-    RowsT<I> d;
+  RowsT<I, P> view() const {
+    RowsT<I, P> d;
     d.n = (i64)range.size();
     d.range = range.data();
     d.length = length.data();
@@ -35,8 +36,8 @@ struct HostRows {
 };
 
 // the same construction as prepare_rows_kernel
-template <typename I>
-void prepare_rows(const pm_rows_t *h, HostRows<I> &s) {
+template <typename I, typename P>
+void prepare_rows(const pm_rows_t *h, HostRows<I, P> &s) {
   i64 n = h->n, G = h->gap_off[n];
   s.range.resize(n);
   s.length.resize(n);
@@ -48,7 +49,7 @@ void prepare_rows(const pm_rows_t *h, HostRows<I> &s) {
   s.pre.resize(G + n + 1);
   s.bad.resize(n + 1);
   for(i64 r = 0; r < n; ++r) {
-    s.range[r] = R2T<I>{(I)h->start[r], (I)h->end[r]};
+    s.range[r] = R2T<P>{(P)h->start[r], (P)h->end[r]};
     i64 o = h->gap_off[r], m = h->gap_off[r + 1] - o;
     I *p = s.pre.data() + o + r;
     I acc = 0, prev_end = 0;
@@ -68,18 +69,19 @@ void prepare_rows(const pm_rows_t *h, HostRows<I> &s) {
   }
 }
 
-template <typename I>
+template <typename I, typename P>
 struct HostDeltas {
-  std::vector<R2T<I>> ref, qry, rg[2], qg[2];
+  std::vector<R2T<P>> ref, qry;
+  std::vector<R2T<I>> rg[2], qg[2];
   std::vector<i64> ref_off, qry_off;
   std::vector<I> rp[2], qp[2];
   std::vector<int> bad;
 };
 
 // the same construction as prepare_deltas_kernel
-template <typename I>
+template <typename I, typename P>
 void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *off, const int64_t *gs, const int64_t *ge,
-                    std::vector<R2T<I>> &range, std::vector<R2T<I>> &gf, std::vector<I> &pf, std::vector<R2T<I>> &gr, std::vector<I> &pr,
+                    std::vector<R2T<P>> &range, std::vector<R2T<I>> &gf, std::vector<I> &pf, std::vector<R2T<I>> &gr, std::vector<I> &pr,
                     std::vector<int> &bad) {
   i64 G = off[n];
   range.resize(n);
@@ -88,7 +90,7 @@ void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *
   pf.resize(G + n + 1);
   pr.resize(G + n + 1);
   for(i64 d = 0; d < n; ++d) {
-    R2T<I> rg{(I)rs[d], (I)re[d]};
+    R2T<P> rg{(P)rs[d], (P)re[d]};
     range[d] = rg;
     i64 o = off[d], m = off[d + 1] - o;
     I acc = 0, prev_end = 0;
@@ -103,7 +105,7 @@ void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *
       acc += rlen(g);
     }
     pf[o + d + m] = acc;
-    I columns = rlen(rg) + acc, racc = 0;
+    I columns = (I)rlen(rg) + acc, racc = 0;
     for(i64 k = 0; k < m; ++k) {
       R2T<I> g{(I)gs[o + (m - 1 - k)], (I)ge[o + (m - 1 - k)]};
       R2T<I> mg{columns - g.e + 1, columns - g.s + 1};
@@ -115,14 +117,14 @@ void prepare_strand(i64 n, const int64_t *rs, const int64_t *re, const int64_t *
   }
 }
 
-template <typename I>
+template <typename I, typename P>
 int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
                              int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets, pm_entry_t *entries,
                              int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
-  HostRows<I> L, R;
+  HostRows<I, P> L, R;
   prepare_rows(left, L);
   prepare_rows(right, R);
-  HostDeltas<I> D;
+  HostDeltas<I, P> D;
   i64 n = deltas->n;
   D.bad.assign(n + 1, 0);
   D.ref_off.assign(deltas->ref_gap_off, deltas->ref_gap_off + n + 1);
@@ -131,7 +133,7 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
                  D.rp[0], D.rg[1], D.rp[1], D.bad);
   prepare_strand(n, deltas->qry_start, deltas->qry_end, deltas->qry_gap_off, deltas->qry_gap_start, deltas->qry_gap_end, D.qry, D.qg[0],
                  D.qp[0], D.qg[1], D.qp[1], D.bad);
-  DeltasT<I> dv;
+  DeltasT<I, P> dv;
   dv.n = n;
   dv.ref = D.ref.data();
   dv.qry = D.qry.data();
@@ -144,7 +146,7 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
     dv.qry_pre[o] = D.qp[o].data();
   }
   dv.bad = D.bad.data();
-  RowsT<I> lv = L.view(), rv = R.view();
+  RowsT<I, P> lv = L.view(), rv = R.view();
   i64 U = units->n;
   std::vector<i64> cnt_e(U + 1, 0), cnt_o(U + 1, 0);
   std::vector<char> disorder(U + 1, 0);
@@ -225,7 +227,7 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
 extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
                              int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets, pm_entry_t *entries,
                              int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
-  return run_all<i64>(left, right, deltas, units, status, unit_entry_off, n_entries, n_offsets, entries, entries_cap, offsets, offsets_cap);
+  return run_all<i64, i64>(left, right, deltas, units, status, unit_entry_off, n_entries, n_offsets, entries, entries_cap, offsets, offsets_cap);
 }
 
 // The int instantiation (the fast path of jobs whose tables are all below 2^25): same tables narrowed, same outputs.
@@ -233,5 +235,12 @@ extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, cons
 extern "C" int unit_host_run_narrow(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
                                     int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets,
                                     pm_entry_t *entries, int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
-  return run_all<int>(left, right, deltas, units, status, unit_entry_off, n_entries, n_offsets, entries, entries_cap, offsets, offsets_cap);
+  return run_all<int, int>(left, right, deltas, units, status, unit_entry_off, n_entries, n_offsets, entries, entries_cap, offsets, offsets_cap);
+}
+
+// int columns, 64-bit sequence positions (round 5: a job whose positions need the `long` while its rows are short).
+extern "C" int unit_host_run_wide_positions(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
+                                            int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets,
+                                            pm_entry_t *entries, int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
+  return run_all<int, i64>(left, right, deltas, units, status, unit_entry_off, n_entries, n_offsets, entries, entries_cap, offsets, offsets_cap);
 }
