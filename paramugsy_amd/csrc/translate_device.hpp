@@ -509,44 +509,31 @@ struct Sink {
   I fix_cap;     // FIX pass: gaps the scratch list holds (the unit's offset count + 1).  A gap owns at least one offset of
                  // its segment, so a segment that commits never holds more; one that is later dropped may, and the
                  // gaps past the cap are then simply not recorded (nothing ever reads them)
-  // EMIT: offsets wait in a stage of the lane's own (T = two sectors' worth of slots, `stage_stride` elements apart: LDS, slot-major
-  // across the wavefront) and leave as whole 32-byte sectors: a lone 4- or 8-byte store costs a sector write of its own, since the
-  // lines of some 400 k resident lanes do not wait in the L2 for their neighbours.  Slot = the offset's global index mod T.
-  // [stage_lo, n_off + pend) is what is staged and not yet written, at most T of them.  When the stage is full, everything up to
-  // the last complete sector leaves (its head, if the unit starts inside a sector, as single stores); the rest at the unit's end.
-  static constexpr int T = 2 * S;
-  I *stage;
-  int stage_stride;
-  I stage_lo;
+  // EMIT: where a unit's offsets go.  The 64 lanes of a wavefront hold consecutive live units, so their offsets are ONE contiguous run
+  // of the job's offsets array, [win_lo, win_lo + what the wavefront's units hold): the lanes write into a window of the wavefront's
+  // own in LDS (`win`, win_cap slots from global index win_lo on) and the wavefront stores the run, whole lines at a time, when all its
+  // lanes are done (the kernel does: translate_kernel).  An offset beyond the window (a wavefront with more offsets than win_cap) goes
+  // to memory directly.  Until round 5 every lane staged two sectors of its own and wrote whole sectors -- but a unit holds six offsets
+  // on average, a quarter of a sector, and the first and last sector of every unit left the L2 as partial writes twice (the
+  // request counters: 109 MB written for 80 MB of output).  Every slot of a unit's exact range is written with its final value before
+  // the unit ends (the range is the COUNT pass's count of the same run), a dropped segment's slots by the segment that replaces it.
+  I *win;
+  i64 win_lo;
+  int win_cap;
 
-  PM_HD __forceinline__ void stage_write(i64 g_first, i64 g_end) { // the staged offsets with global indices [g_first, g_end)
-    // one store per offset, back to back: the stores of a sector reach the L2 together and leave it as one write (a 16-byte
-    // vector path for whole sectors cost the kernel 40 registers -- a third of its resident wavefronts -- and bought nothing)
-    for(i64 g = g_first; g < g_end; ++g) {
-      off[g] = stage[(int)(g & (T - 1)) * stage_stride];
-    }
-  }
   PM_HD __forceinline__ void stash(I at, I v) {
     if(at < off_cap) { // offsets of a segment that is later dropped may run past the exact slot
       const i64 g = off_base + at;
-      stage[(int)(g & (T - 1)) * stage_stride] = v;
-      if(at - stage_lo + 1 == T) { // full: T >= 2 S - 1 staged offsets hold at least one complete sector
-        const i64 g_end = (g + 1) & ~(i64)(S - 1);
-        stage_write(off_base + stage_lo, g_end);
-        stage_lo = (I)(g_end - off_base);
+      const unsigned long long d = (unsigned long long)(g - win_lo);
+      if(d < (unsigned long long)win_cap) {
+        win[d] = v;
+      }
+      else {
+        off[g] = v;
       }
     }
   }
-  // after the unit's last commit (or its failure): the committed offsets still staged
-  PM_HD __forceinline__ void finish() {
-    if(EMIT && !fix) {
-      const I end = n_off < off_cap ? n_off : off_cap;
-      if(stage_lo < end) {
-        stage_write(off_base + stage_lo, off_base + end);
-        stage_lo = end;
-      }
-    }
-  }
+  PM_HD __forceinline__ void finish() {} // (the window is stored by the wavefront, after its last lane's last commit)
 
   PM_HD __forceinline__ void put(I v) {
     if(EMIT && !fix) {
@@ -586,9 +573,6 @@ struct Sink {
     pend = 0;
     wpos = 0;
     fix_n = 0;
-    if(EMIT && stage_lo > n_off) { // a segment that was dropped after it had filled sectors: the next one is staged from n_off again
-      stage_lo = n_off;
-    }
   }
   // FIX pass: deltas_of_gaps over the recorded gaps (m_delta_stream_writer.hh:14-53): two cursors, one per row, each taking
   // its row's gaps in arrival order; the smaller start goes first, ties to the query row

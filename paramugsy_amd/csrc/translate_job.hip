@@ -131,6 +131,19 @@ __global__ void prepare_deltas_kernel(i64 n, const i64 *rs, const i64 *re, const
   }
 }
 
+// Which 64 units a workgroup takes.  Workgroups go to the eight XCDs in turn (workgroup b to XCD b mod 8) and every XCD has an L2 of its
+// own: with workgroup b on units [64 b, 64 b + 64) every XCD walks the whole unit list -- and fetches every delta entry's gap lists and
+// prefix tables into its own L2 (the unit list is ordered by entry; round 5's request counters: the emit pass read 145 MB from the
+// memory side, all in 128-byte lines, for 69 MB of algorithmic reads).  Here XCD x takes the x-th eighth of the `nb` chunks of 64, so an
+// entry's tables are fetched by one L2 (two at a seam).  A bijection of [0, nb); workgroups b >= nb have no chunk (returns nb or more).
+__device__ __forceinline__ unsigned xcd_chunk(unsigned b, unsigned nb) {
+  if(b >= nb) {
+    return b;
+  }
+  const unsigned q = nb / 8, r = nb % 8, x = b % 8;
+  return x * q + (x < r ? x : r) + b / 8;
+}
+
 // Filter pass: most (entry, left row, right row) triples the reference's loops visit end at the first overlap test
 // (m_translate.cc:513).  One lane per unit runs just that prefix; the survivors ("live" units) are compacted so that
 // the count and emit passes run on dense wavefronts instead of waiting for the few long lanes of every wavefront.
@@ -138,7 +151,7 @@ template <typename I, typename P>
 __global__ void __launch_bounds__(64)
 translate_filter_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_units, const int *u_delta, const int *u_left, const int *u_right,
                         int *status, i64 *cnt_ent, i64 *cnt_off, int *live_flag) {
-  i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  i64 u = (i64)xcd_chunk(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if(u >= n_units) {
     return;
   }
@@ -418,19 +431,31 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
   // slow_flag (COUNT): set for a unit whose gaps arrive out of the writer's merge order (Sink, translate_device.hpp).
   // slow_units (EMIT only; the FIX pass): the launch covers just those units, one lane each, with a scratch list for the open
   // segment's gaps at scratch + slow_scratch_off[lane]; it rewrites the offsets the EMIT pass wrote for them.
-  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 n_live = live_pos[n_units];
+  // (the launch covers all units; the live ones fill its first ceil(n_live / 64) workgroups, an eighth of them per XCD: xcd_chunk)
+  i64 k = (EMIT && slow_units ? (i64)blockIdx.x : (i64)xcd_chunk(blockIdx.x, (unsigned)((n_live + 63) / 64))) * blockDim.x + threadIdx.x;
   if(EMIT) {
     if(ent_off[n_units] > ent_cap || off_off[n_units] > off_cap) { // uniform: buffers sized by an older run
-      if(k == 0) {
+      if(blockIdx.x == 0 && threadIdx.x == 0) {
         *overflow = 1;
       }
       return;
     }
   }
-  const i64 n_live = live_pos[n_units];
   i64 *fix = nullptr;
-  i64 u;
-  if(EMIT && slow_units) {
+  i64 u = 0;
+  bool active = true; // EMIT: false for a lane that only helps to store the wavefront's window
+  // EMIT: the window of the wavefront's offsets (Sink::win).  8 KB: with it a CU holds 20 workgroups, five per SIMD -- more than the
+  // kernel's registers allow anyway; the mean wavefront of the bench job holds 370 offsets
+  constexpr int WIN = 8192 / (int)sizeof(I);
+  I *win = nullptr;
+  if constexpr(EMIT) {
+    __shared__ I win_slots[WIN];
+    win = win_slots;
+  }
+  i64 win_lo = 0, win_hi = 0;
+  const bool fixing = EMIT && slow_units != nullptr;
+  if(fixing) {
     if(k >= n_slow) {
       return;
     }
@@ -438,16 +463,26 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
     u = slow_units[k];
     k = live_pos[u]; // the unit's place among the live ones: where the count pass left its merge start
   }
+  else if(EMIT) {
+    const i64 k0 = k - threadIdx.x;
+    if(k0 >= n_live) { // the grid covers all units; only the live ones (compacted by the filter pass) have a lane
+      return;
+    }
+    active = k < n_live;
+    u = active ? live_units[k] : 0;
+    // consecutive live units: what lies between two of them holds nothing, so the wavefront's offsets are one run
+    const i64 ob = active ? off_off[u] : 0, oe = active ? off_off[u + 1] : 0;
+    win_lo = __shfl(ob, 0);
+    win_hi = __shfl(oe, (int)(n_live - k0 < 64 ? n_live - k0 - 1 : 63));
+    if(active && oe == ob && ent_off[u + 1] == ent_off[u]) {
+      active = false; // the count pass found nothing to write for this unit (most left x right pairs of an entry)
+    }
+  }
   else {
-    if(k >= n_live) { // the grid covers all units; only the live ones (compacted by the filter pass) have a lane
+    if(k >= n_live) {
       return;
     }
     u = live_units[k];
-  }
-  if(EMIT) {
-    if(ent_off[u + 1] == ent_off[u] && off_off[u + 1] == off_off[u]) {
-      return; // the count pass found nothing to write for this unit (most left x right pairs of an entry)
-    }
   }
   Sink<EMIT, I> sink;
   sink.n_ent = sink.n_off = sink.pend = sink.wpos = sink.last_start = 0;
@@ -459,15 +494,10 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
   sink.fix = fix;
   sink.fix_n = 0;
   sink.fix_cap = 0;
-  sink.stage = nullptr;
-  sink.stage_stride = 64;
-  sink.stage_lo = 0;
-  if constexpr(EMIT) {
-    // two sectors of offsets per lane, slot-major: lanes that fill the same slot hit 64 different banks
-    __shared__ I stage[Sink<EMIT, I>::T * 64];
-    sink.stage = stage + threadIdx.x;
-  }
-  if(EMIT) {
+  sink.win = win;
+  sink.win_lo = win_lo;
+  sink.win_cap = fixing ? 0 : WIN;
+  if(EMIT && active) {
     sink.ent = entries + ent_off[u];
     sink.ent_cap = (I)(ent_off[u + 1] - ent_off[u]);
     sink.off = offsets;
@@ -475,18 +505,27 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
     sink.off_cap = (I)(off_off[u + 1] - off_off[u]);
     sink.fix_cap = sink.off_cap + 1; // the scratch list is 2 * (offsets of the unit) + 2 words (pm_job_create)
   }
-  const int d = u_delta[u], l = u_left[u], r = u_right[u];
   if constexpr(EMIT) {
-    // the count pass left this unit's merge start in states[k]: no set-up to redo
-    Merge<EMIT, I> m;
-    m.sink = sink;
-    UnitStateT<I> s;
-    state_load<I>(states, n_live, k, s);
-    unit_restore<EMIT>(left, right, ds, d, l, r, s, m);
-    (void)unit_merge<EMIT>(m);
-    m.sink.finish();
+    if(active) {
+      const int d = u_delta[u], l = u_left[u], r = u_right[u];
+      // the count pass left this unit's merge start in states[k]: no set-up to redo
+      Merge<EMIT, I> m;
+      m.sink = sink;
+      UnitStateT<I> s;
+      state_load<I>(states, n_live, k, s);
+      unit_restore<EMIT>(left, right, ds, d, l, r, s, m);
+      (void)unit_merge<EMIT>(m);
+    }
+    if(!fixing) { // the wavefront's run of offsets, from its window: whole lines, 64 consecutive offsets a store
+      __syncthreads();
+      const i64 n = win_hi - win_lo < (i64)WIN ? win_hi - win_lo : (i64)WIN;
+      for(i64 q = threadIdx.x; q < n; q += 64) {
+        offsets[win_lo + q] = win[q];
+      }
+    }
   }
   else {
+    const int d = u_delta[u], l = u_left[u], r = u_right[u];
     PVT<I, P> lp, rp, dr, dq;
     R2T<I> cols;
     bool live, proceed = false;

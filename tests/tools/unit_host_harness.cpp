@@ -173,7 +173,10 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
   typedef typename EntRecT<I>::type Rec;
   std::vector<Rec> rec((size_t)eo[U] + 1);
   std::vector<I> off((size_t)oo[U] + 8);
-  I stage[Sink<true, I>::T]; // the lane's sector of staged offsets (LDS on the device)
+  // the wavefront's window of offsets (LDS on the device): here a "wavefront" of one unit and a window of five slots, so that units
+  // are written through the window, past it, and both
+  constexpr int WIN = 5;
+  I win[WIN];
   for(i64 u = 0; u < U; ++u) { // EMIT pass
     Sink<true, I> sink;
     memset(&sink, 0, sizeof sink);
@@ -182,14 +185,18 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
     sink.off = off.data();
     sink.off_base = oo[u];
     sink.off_cap = (I)(oo[u + 1] - oo[u]);
-    sink.stage = stage;
-    sink.stage_stride = 1;
-    for(int k = 0; k < Sink<true, I>::T; ++k) {
-      stage[k] = (I)0x5a5a5a5a; // whatever the previous unit left must not matter
+    sink.win = win;
+    sink.win_lo = oo[u];
+    sink.win_cap = WIN;
+    for(int k = 0; k < WIN; ++k) {
+      win[k] = (I)0x5a5a5a5a; // whatever the previous unit left must not matter
     }
     int st = run_unit<true>(lv, rv, dv, units->delta[u], units->left[u], units->right[u], sink);
     if(st != status[u]) {
       return 2; // the two passes must agree
+    }
+    for(i64 q = 0; q < WIN && q < oo[u + 1] - oo[u]; ++q) { // what the wavefront does when its lanes are done
+      off[(size_t)(oo[u] + q)] = win[q];
     }
     if(disorder[u]) { // the FIX pass of the library: the same unit again, its segments' gaps recorded and merged at commit
       std::vector<i64> scratch((size_t)(2 * (oo[u + 1] - oo[u]) + 2), 0);
