@@ -869,6 +869,7 @@ struct UnitStateT {
   I ref_start, query_start, column, last_column, query_columns;
   int orientation;   // 1: the entry is used reversed (m_translate.cc:210-217)
   int mirrored;      // the right row is walked backwards (:557)
+  int delta, left, right; // which entry and rows the unit is (set by the count pass: the emit pass reads them with the state, as runs)
 };
 typedef UnitStateT<i64> UnitState;
 

@@ -5,7 +5,8 @@
 //   deltas : ref[R2 n], qry[R2 n], ref_off[n+1], qry_off[n+1],
 //            {ref,qry}_gaps[2][R2 G], {ref,qry}_pre[2][G+n]   (orientation 0 as read, 1 reversed), bad[int n]
 //   units  : delta[int U], left[int U], right[int U]
-//   out    : status[int U], cnt_ent[U+1], cnt_off[U+1] -> exclusive scans ent_off[U+1], off_off[U+1],
+//   out    : status[int U]; per LIVE unit (the filter pass's survivors, in unit order: live index k) cnt_ent[k], cnt_off[k] -> exclusive
+//            scans ent_off_l[n_live+1], off_off[n_live+1]; per unit again ent_off[U+1] (what pm_job_fetch hands out), expanded from those;
 //            entries[E] + offsets[O]: 32-byte Entry32 records + int offsets for a job on the int tables (pm_job_fetch widens them),
 //            pm_entry_t + int64 else (translate_device.hpp, EntRecT)
 // Kernels: prepare_rows / prepare_deltas (once per job), translate_filter + the live list, translate_count, the prefix sums of
@@ -371,11 +372,31 @@ count_scan_kernel(i64 n, const i64 *__restrict__ cnt_ent, const i64 *__restrict_
   }
 }
 
+// The counts and their sums are held per LIVE unit (round 5): the count pass stores a wavefront's 64 counts as one run instead of 64
+// 8-byte stores scattered over the unit list (a third of the units are live: nearly every sector of the per-unit arrays was written for
+// a quarter of its bytes), the sums are over a third of the elements, and the emit pass reads its lanes' offsets as runs.  What leaves
+// the library per UNIT -- pm_job_fetch's unit_entry_off, the text pass's unit boundaries -- is this: the live units before unit u are
+// live_pos[u] (the filter pass's exclusive sum; live_pos[U] = all of them), and units that are not live hold nothing, so
+// ent_off[u] = ent_off_l[live_pos[u]].  totals = {entries, offsets} of the job.
+__global__ void expand_offsets_kernel(i64 n_units, const int *__restrict__ live_pos, const i64 *__restrict__ ent_off_l, const i64 *__restrict__ off_off_l,
+                                      i64 *__restrict__ ent_off, i64 *__restrict__ totals) {
+  const i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if(u <= n_units) {
+    const int k = live_pos[u];
+    const i64 e = ent_off_l[k];
+    ent_off[u] = e;
+    if(u == n_units) {
+      totals[0] = e;
+      totals[1] = off_off_l[k];
+    }
+  }
+}
+
 // The saved merge states live in HBM field by field (13 coordinate arrays, then 10 int arrays, each n_live long), so
 // that the 64 lanes of a wavefront, which hold consecutive live units, store and load every field as one contiguous run
 // instead of 64 separate records.
-static_assert(sizeof(UnitStateT<i64>) == 13 * 8 + 10 * 4 && sizeof(UnitStateT<int>) == 23 * 4,
-              "state_store/state_load lay UnitState out as 13 coordinate + 10 int fields");
+static_assert(sizeof(UnitStateT<i64>) == 13 * 8 + 14 * 4 && sizeof(UnitStateT<int>) == 26 * 4,
+              "state_store/state_load lay UnitState out as 13 coordinate + 13 int fields (the int64 struct ends in 4 bytes of padding)");
 template <typename I>
 __device__ __forceinline__ void state_store(void *base, i64 n, i64 k, const UnitStateT<I> &s) {
   I *w = reinterpret_cast<I *>(base);
@@ -394,6 +415,9 @@ __device__ __forceinline__ void state_store(void *base, i64 n, i64 k, const Unit
   w[12 * n + k] = s.query_columns;
   iw[8 * n + k] = s.orientation;
   iw[9 * n + k] = s.mirrored;
+  iw[10 * n + k] = s.delta;
+  iw[11 * n + k] = s.left;
+  iw[12 * n + k] = s.right;
 }
 
 template <typename I>
@@ -414,6 +438,9 @@ __device__ __forceinline__ void state_load(const void *base, i64 n, i64 k, UnitS
   s.query_columns = w[12 * n + k];
   s.orientation = iw[8 * n + k];
   s.mirrored = iw[9 * n + k];
+  s.delta = iw[10 * n + k];
+  s.left = iw[11 * n + k];
+  s.right = iw[12 * n + k];
 }
 
 // amdgpu_waves_per_eu(4): keep the register allocation at <= 128 VGPRs (4 waves per SIMD); the kernel is bound by the
@@ -435,7 +462,8 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
   // (the launch covers all units; the live ones fill its first ceil(n_live / 64) workgroups, an eighth of them per XCD: xcd_chunk)
   i64 k = (EMIT && slow_units ? (i64)blockIdx.x : (i64)xcd_chunk(blockIdx.x, (unsigned)((n_live + 63) / 64))) * blockDim.x + threadIdx.x;
   if(EMIT) {
-    if(ent_off[n_units] > ent_cap || off_off[n_units] > off_cap) { // uniform: buffers sized by an older run
+    // (EMIT: ent_off and off_off are the sums over the LIVE units, indexed by k -- expand_offsets_kernel above)
+    if(ent_off[n_live] > ent_cap || off_off[n_live] > off_cap) { // uniform: buffers sized by an older run
       if(blockIdx.x == 0 && threadIdx.x == 0) {
         *overflow = 1;
       }
@@ -469,12 +497,11 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
       return;
     }
     active = k < n_live;
-    u = active ? live_units[k] : 0;
     // consecutive live units: what lies between two of them holds nothing, so the wavefront's offsets are one run
-    const i64 ob = active ? off_off[u] : 0, oe = active ? off_off[u + 1] : 0;
+    const i64 ob = active ? off_off[k] : 0, oe = active ? off_off[k + 1] : 0;
     win_lo = __shfl(ob, 0);
     win_hi = __shfl(oe, (int)(n_live - k0 < 64 ? n_live - k0 - 1 : 63));
-    if(active && oe == ob && ent_off[u + 1] == ent_off[u]) {
+    if(active && oe == ob && ent_off[k + 1] == ent_off[k]) {
       active = false; // the count pass found nothing to write for this unit (most left x right pairs of an entry)
     }
   }
@@ -498,22 +525,21 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
   sink.win_lo = win_lo;
   sink.win_cap = fixing ? 0 : WIN;
   if(EMIT && active) {
-    sink.ent = entries + ent_off[u];
-    sink.ent_cap = (I)(ent_off[u + 1] - ent_off[u]);
+    sink.ent = entries + ent_off[k];
+    sink.ent_cap = (I)(ent_off[k + 1] - ent_off[k]);
     sink.off = offsets;
-    sink.off_base = off_off[u];
-    sink.off_cap = (I)(off_off[u + 1] - off_off[u]);
+    sink.off_base = off_off[k];
+    sink.off_cap = (I)(off_off[k + 1] - off_off[k]);
     sink.fix_cap = sink.off_cap + 1; // the scratch list is 2 * (offsets of the unit) + 2 words (pm_job_create)
   }
   if constexpr(EMIT) {
     if(active) {
-      const int d = u_delta[u], l = u_left[u], r = u_right[u];
-      // the count pass left this unit's merge start in states[k]: no set-up to redo
+      // the count pass left this unit's merge start in states[k], with which entry and rows it is: no set-up to redo
       Merge<EMIT, I> m;
       m.sink = sink;
       UnitStateT<I> s;
       state_load<I>(states, n_live, k, s);
-      unit_restore<EMIT>(left, right, ds, d, l, r, s, m);
+      unit_restore<EMIT>(left, right, ds, s.delta, s.left, s.right, s, m);
       (void)unit_merge<EMIT>(m);
     }
     if(!fixing) { // the wavefront's run of offsets, from its window: whole lines, 64 consecutive offsets a store
@@ -539,6 +565,9 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
         if(states) { // null only in the sizing pass of pm_job_create
           UnitStateT<I> s;
           unit_save<EMIT>(m, orientation, s);
+          s.delta = d;
+          s.left = l;
+          s.right = r;
           state_store<I>(states, n_live, k, s);
         }
         st = unit_merge<EMIT>(m);
@@ -549,8 +578,8 @@ translate_kernel(RowsT<I, P> left, RowsT<I, P> right, DeltasT<I, P> ds, i64 n_un
       atomicOr(narrow_trip, 1);
     }
     status[u] = st;
-    cnt_ent[u] = sink.n_ent;
-    cnt_off[u] = sink.n_off;
+    cnt_ent[k] = sink.n_ent; // per live unit: a run per wavefront
+    cnt_off[k] = sink.n_off;
     if(sink.disorder && slow_flag) {
       slow_flag[u] = 1;
       slow_flag[n_units] = 1; // "the job has such units"
@@ -1084,7 +1113,9 @@ struct pm_job {
   DeltasStore deltas;
   DevBuf u_delta, u_left, u_right;
   i64 n_units = 0;
-  DevBuf status, cnt_ent, cnt_off, ent_off, off_off, entries, offsets, overflow, scan_tmp;
+  // cnt_ent, cnt_off, ent_off_l, off_off: per LIVE unit (index k); ent_off: per unit (expand_offsets_kernel); totals: {entries, offsets}
+  DevBuf status, cnt_ent, cnt_off, ent_off, ent_off_l, off_off, totals, entries, offsets, overflow, scan_tmp;
+  i64 n_live = -1; // live units of the job (its tables never change, so neither does this); -1 until the sizing pass has run
   DevBuf live_flag, live_pos, live_units, scan_tmp32, scan_partial;
   DevBuf states; // UnitState per live unit (null during the sizing pass of pm_job_create)
   DevBuf maxabs, narrow_trip;
@@ -1184,20 +1215,28 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   if(ev) {
     PM_HIP(hipEventRecord(ev[2], stream));
   }
-  // 3. output offsets
-  if(own_scans) {
-    count_tile_sums_kernel<<<tiles, SCAN_THREADS, 0, stream>>>(n_scan, (const i64 *)j->cnt_ent.p, (const i64 *)j->cnt_off.p, (Sum2 *)j->scan_partial.p);
-    count_scan_kernel<<<tiles, SCAN_THREADS, 0, stream>>>(n_scan, (const i64 *)j->cnt_ent.p, (const i64 *)j->cnt_off.p,
-                                                        (const Sum2 *)j->scan_partial.p, (i64 *)j->ent_off.p, (i64 *)j->off_off.p);
+  // 3. output offsets: sums over the live units' counts (n_live + 1 elements; in the sizing pass of pm_job_create, which does not know
+  // n_live yet, over U + 1 -- the counts behind the live units' are zero), then the per-unit index and the totals
+  {
+    const i64 n_cscan = (j->n_live >= 0 ? j->n_live : U) + 1;
+    const unsigned ctiles = (unsigned)((n_cscan + SCAN_TILE - 1) / SCAN_TILE);
+    if(ctiles <= (unsigned)SCAN_MAX_TILES && !j->library_scans) {
+      count_tile_sums_kernel<<<ctiles, SCAN_THREADS, 0, stream>>>(n_cscan, (const i64 *)j->cnt_ent.p, (const i64 *)j->cnt_off.p, (Sum2 *)j->scan_partial.p);
+      count_scan_kernel<<<ctiles, SCAN_THREADS, 0, stream>>>(n_cscan, (const i64 *)j->cnt_ent.p, (const i64 *)j->cnt_off.p,
+                                                           (const Sum2 *)j->scan_partial.p, (i64 *)j->ent_off_l.p, (i64 *)j->off_off.p);
+      PM_HIP(hipGetLastError());
+    }
+    else {
+      size_t tmp = j->scan_tmp_bytes;
+      PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off_l.p, (i64)0, (size_t)n_cscan,
+                                     rocprim::plus<i64>(), stream));
+      tmp = j->scan_tmp_bytes;
+      PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_off.p, (i64 *)j->off_off.p, (i64)0, (size_t)n_cscan,
+                                     rocprim::plus<i64>(), stream));
+    }
+    expand_offsets_kernel<<<(unsigned)((U + 256) / 256), 256, 0, stream>>>(U, (const int *)j->live_pos.p, (const i64 *)j->ent_off_l.p,
+                                                                          (const i64 *)j->off_off.p, (i64 *)j->ent_off.p, (i64 *)j->totals.p);
     PM_HIP(hipGetLastError());
-  }
-  else {
-    size_t tmp = j->scan_tmp_bytes;
-    PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_ent.p, (i64 *)j->ent_off.p, (i64)0, (size_t)(U + 1),
-                                   rocprim::plus<i64>(), stream));
-    tmp = j->scan_tmp_bytes;
-    PM_HIP(rocprim::exclusive_scan(j->scan_tmp.p, tmp, (i64 *)j->cnt_off.p, (i64 *)j->off_off.p, (i64)0, (size_t)(U + 1),
-                                   rocprim::plus<i64>(), stream));
   }
   if(ev) {
     PM_HIP(hipEventRecord(ev[3], stream));
@@ -1208,7 +1247,7 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
   if(emit && U > 0) {
 #define PM_EMIT_ARGS_OF(I)                                                                                                        \
   U, (const int *)j->u_delta.p, (const int *)j->u_left.p, (const int *)j->u_right.p, (const int *)j->live_units.p,                \
-      (const int *)j->live_pos.p, nullptr, nullptr, nullptr, (const i64 *)j->ent_off.p, (const i64 *)j->off_off.p,                 \
+      (const int *)j->live_pos.p, nullptr, nullptr, nullptr, (const i64 *)j->ent_off_l.p, (const i64 *)j->off_off.p,               \
       (EntRecT<I>::type *)j->entries.p, (I *)j->offsets.p, j->ent_cap, j->off_cap, (int *)j->overflow.p, j->states.p,              \
       (int *)j->narrow_trip.p, nullptr
     if(j->narrow) {
@@ -1244,8 +1283,7 @@ static int job_launch_pass(pm_job *j, hipStream_t stream, bool emit, hipEvent_t 
 
 static int job_read_totals(pm_job *j, hipStream_t stream) {
   i64 tot[2] = {0, 0};
-  PM_HIP(hipMemcpyAsync(&tot[0], (i64 *)j->ent_off.p + j->n_units, 8, hipMemcpyDeviceToHost, stream));
-  PM_HIP(hipMemcpyAsync(&tot[1], (i64 *)j->off_off.p + j->n_units, 8, hipMemcpyDeviceToHost, stream));
+  PM_HIP(hipMemcpyAsync(tot, j->totals.p, 16, hipMemcpyDeviceToHost, stream));
   PM_HIP(hipStreamSynchronize(stream));
   j->n_entries = tot[0];
   j->n_offsets = tot[1];
@@ -1389,7 +1427,9 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
   JTRY(j->cnt_ent.alloc((size_t)(U + 1) * 8));
   JTRY(j->cnt_off.alloc((size_t)(U + 1) * 8));
   JTRY(j->ent_off.alloc((size_t)(U + 1) * 8));
+  JTRY(j->ent_off_l.alloc((size_t)(U + 1) * 8));
   JTRY(j->off_off.alloc((size_t)(U + 1) * 8));
+  JTRY(j->totals.alloc(16));
   JTRY(j->overflow.alloc(4));
   JTRY(j->live_flag.alloc((size_t)(U + 1) * 4));
   JTRY(j->live_pos.alloc((size_t)(U + 1) * 4));
@@ -1484,9 +1524,10 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
       return fail(PM_E_HIP, "hipMemcpy failed");
     }
     if(any) {
-      std::vector<int> flag((size_t)U);
-      std::vector<i64> cnt((size_t)U);
+      std::vector<int> flag((size_t)U), pos((size_t)U);
+      std::vector<i64> cnt((size_t)U); // (the counts are per live unit: a flagged unit's is cnt[pos[u]])
       if(hipMemcpy(flag.data(), j->slow_flag.p, (size_t)U * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+         hipMemcpy(pos.data(), j->live_pos.p, (size_t)U * 4, hipMemcpyDeviceToHost) != hipSuccess ||
          hipMemcpy(cnt.data(), j->cnt_off.p, (size_t)U * 8, hipMemcpyDeviceToHost) != hipSuccess) {
         pm_job_destroy(j);
         return fail(PM_E_HIP, "hipMemcpy failed");
@@ -1498,7 +1539,7 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
         if(flag[(size_t)u]) {
           list.push_back((int)u);
           at.push_back(words);
-          words += 2 * cnt[(size_t)u] + 2;
+          words += 2 * cnt[(size_t)pos[(size_t)u]] + 2;
         }
       }
       if(words > ((i64)1 << 28)) { // 2 GiB of scratch: not a job anyone means
@@ -1521,6 +1562,7 @@ static int job_create_impl(const pm_rows_t *left, const pm_rows_t *right, const 
       pm_job_destroy(j);
       return fail(PM_E_HIP, "hipMemcpy failed");
     }
+    j->n_live = n_live;
     JTRY(j->states.alloc((size_t)(n_live > 0 ? n_live : 1) * sizeof(UnitState))); // the int layout needs less
   }
   // (+ 32: a whole-sector store of staged offsets never starts inside the array and ends outside it, but keep a sector of slack)
