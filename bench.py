@@ -288,7 +288,8 @@ def bench_translate(args, rank, world, local, torch, dist):
     # pass also writes the entries and offsets
     dom_ms = max(ms_count, ms_emit)
     bits = job.coordinate_bits()
-    dom_name = "translate_kernel<%s, %s>" % ("true" if ms_emit >= ms_count else "false", "int" if bits == 32 else "long long")
+    # (translate_kernel<EMIT, I, P>: column type, position type -- the headline job's are the same)
+    dom_name = "translate_kernel<%s, %s>" % ("true" if ms_emit >= ms_count else "false", "int, int" if bits == 32 else "long long, long long")
     alg_bytes = emit_bytes if ms_emit >= ms_count else count_bytes  # algorithmic bytes of the dominant kernel's launch
     tr_key = "translate:%d:%d:%d:%d:%d" % (args.tr_genomes, args.tr_genome_len, args.tr_blocks, args.tr_deltas, args.tr_entries)
     out = {
