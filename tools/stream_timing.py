@@ -26,7 +26,7 @@ for text, ro, br in (side_a, side_b):
     pins.append(pt)  # the array lives as long as its PinnedArray
     sides.append((pt.a, ro, br))
 st = dp.DpStream(params, int(os.environ.get("SEGMENTS", "4")))
-for what in ("columns", "texts"):
+for what in (("columns",) if os.environ.get("ONLY_COLUMNS") else ("columns", "texts")):
     for rep in range(4):
         sys.stderr.write("-- %s, pass %d\n" % (what, rep))
         t = time.perf_counter()
