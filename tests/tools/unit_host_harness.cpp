@@ -231,6 +231,57 @@ int run_all(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *de
 
 } // namespace
 
+// How much merge every unit has in front of it (the kept gaps of its four lists: what unit_merge's step budget is made of), -1 for a
+// unit the filter pass drops or whose set-up ends it: for sizing what a wavefront of 64 consecutive live units waits for.
+extern "C" int unit_host_work(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units, int32_t *work) {
+  typedef i64 I;
+  HostRows<I, I> L, R;
+  prepare_rows(left, L);
+  prepare_rows(right, R);
+  HostDeltas<I, I> D;
+  i64 n = deltas->n;
+  D.bad.assign(n + 1, 0);
+  D.ref_off.assign(deltas->ref_gap_off, deltas->ref_gap_off + n + 1);
+  D.qry_off.assign(deltas->qry_gap_off, deltas->qry_gap_off + n + 1);
+  prepare_strand(n, deltas->ref_start, deltas->ref_end, deltas->ref_gap_off, deltas->ref_gap_start, deltas->ref_gap_end, D.ref, D.rg[0],
+                 D.rp[0], D.rg[1], D.rp[1], D.bad);
+  prepare_strand(n, deltas->qry_start, deltas->qry_end, deltas->qry_gap_off, deltas->qry_gap_start, deltas->qry_gap_end, D.qry, D.qg[0],
+                 D.qp[0], D.qg[1], D.qp[1], D.bad);
+  DeltasT<I, I> dv;
+  dv.n = n;
+  dv.ref = D.ref.data();
+  dv.qry = D.qry.data();
+  dv.ref_off = D.ref_off.data();
+  dv.qry_off = D.qry_off.data();
+  for(int o = 0; o < 2; ++o) {
+    dv.ref_gaps[o] = D.rg[o].data();
+    dv.ref_pre[o] = D.rp[o].data();
+    dv.qry_gaps[o] = D.qg[o].data();
+    dv.qry_pre[o] = D.qp[o].data();
+  }
+  dv.bad = D.bad.data();
+  RowsT<I, I> lv = L.view(), rv = R.view();
+  for(i64 u = 0; u < units->n; ++u) {
+    PVT<I, I> lp, rp, dr, dq;
+    R2T<I> cols;
+    bool live, proceed = false;
+    int orientation;
+    work[u] = -1;
+    int st = unit_prefix(lv, rv, dv, units->delta[u], units->left[u], units->right[u], lp, rp, dr, dq, cols, live, orientation);
+    if(st || !live) {
+      continue;
+    }
+    work[u] = 0; // live: a lane of the count and emit passes
+    Merge<false, I> m;
+    memset(&m, 0, sizeof m);
+    st = unit_setup<false>(lp, rp, dr, dq, cols, m, proceed);
+    if(!st && proceed) {
+      work[u] = 1 + m.rows.v0.n + m.rows.v1.n + m.delta.v0.n + m.delta.v1.n;
+    }
+  }
+  return 0;
+}
+
 extern "C" int unit_host_run(const pm_rows_t *left, const pm_rows_t *right, const pm_deltas_t *deltas, const pm_units_t *units,
                              int32_t *status, int64_t *unit_entry_off, int64_t *n_entries, int64_t *n_offsets, pm_entry_t *entries,
                              int64_t entries_cap, int64_t *offsets, int64_t offsets_cap) {
