@@ -356,12 +356,15 @@ __device__ __forceinline__ int4 dp_expand_row(u64 col) {
 // that pair while the fill goes on.  No placement is assumed: a pair lies in exactly one list, whatever the dispatcher did, and an
 // entry is taken exactly once (a ticket per XCD).  When the fill kernel has ended, everything is visible everywhere: a second launch
 // of the walk kernel behind it (mode 2, the whole chip) takes what is left of all eight lists.  The fill never waits for a walker,
-// the early walkers leave the fill most of every SIMD, and every wait ends when the fill has (n_filled), so nothing can hang.
+// the early walkers leave the fill most of every SIMD, and every wait ends when the fill has (n_filled) -- PROVIDED the fill kernel runs
+// beside them.  Where kernels are run one at a time (rocprofv3 --pmc serialises the dispatches of all streams, and took the walkers
+// first: the profile refresh of round 5 hung there) it never starts while they wait; so a walker first waits, for 30 ms at most, for the
+// fill kernel's sign that it is running (n_filled[1]) and leaves if it does not come -- the launch behind the fill walks everything then.
 struct DpEarly {   // device pointers; mode 0: the walk as a kernel of its own (order[0 .. n), one pair per group)
   int mode;        // 1: beside the fill kernel, the lists of this wavefront's own XCD only; 2: behind it, all lists
   int n_expected;  // pairs the fill kernel will publish
   int *taken;      // [8] entries handed out per XCD
-  const int *n_filled; // pairs published so far (incremented AFTER the entry is written)
+  const int *n_filled; // pairs published so far (incremented AFTER the entry is written); n_filled[1]: the fill kernel has started
   const int *list; // [8][n]: position + 1, 0 = not written yet
 };
 // what the fill kernel needs to publish a finished pair (null pointers: it does not)

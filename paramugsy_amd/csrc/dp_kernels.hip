@@ -535,6 +535,9 @@ dp_fill_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
     // is one the fill does not issue, and the fill took 1.4 ms longer for a walk that costs 1.0 ms behind it (profiles/r05_early_walk.txt).
     // (The fill ahead of the walk kernels of EARLIER chunks too, always: measured, no difference -- 146.4 / 146.1 ms on 50 000 pairs.)
     __builtin_amdgcn_s_setprio(1);
+    if(blockIdx.x == 0 && threadIdx.x == 0) { // "this launch is running": what the walkers beside it wait for before they wait for anything else
+      __hip_atomic_store(fl.n_filled + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if(started && threadIdx.x == 0) { // dp_gate_kernel: once every workgroup of this launch has started, the next chunk's may
     __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

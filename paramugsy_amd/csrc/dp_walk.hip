@@ -107,6 +107,25 @@ dp_walk_kernel(const u64 *__restrict__ cols_a, const i64 *__restrict__ off_a, co
   int lists_tried = 0;     // mode 2: lists found exhausted in a row
   int polls = 0;           // mode 1: looks at an entry that was not there yet
   bool group_done = early.mode == 0;
+  if(early.mode == 1) { // is the fill kernel running beside this launch (DpEarly)?  Bounded: 2 048 looks, some 15 us apart
+    int running = 0;
+    for(int tries = 0; tries < 2048 && !running; ++tries) {
+      if(threadIdx.x == 0) {
+        running = __hip_atomic_load(early.n_filled + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                  __hip_atomic_load(early.n_filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= early.n_expected;
+      }
+      running = __shfl(running, 0);
+      if(!running) {
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+      }
+    }
+    if(!running) {
+      group_done = true; // no fill kernel beside us: nothing to wait for here
+    }
+  }
   {
     const i64 idx = (i64)blockIdx.x * G + grp;
     if(band_mode == 1) {
