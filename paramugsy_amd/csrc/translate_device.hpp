@@ -181,15 +181,15 @@ struct GapViewT {
 };
 typedef GapViewT<i64> GapView;
 
+// (One load whichever way the view runs, the rest by selects: with a branch per direction the merge's pops -- executed for the few
+// lanes that are at that point of that case -- were two loads each where the lanes of a wavefront differ, and what the merge costs is
+// what its divergent lanes issue between them: profiles/r05_translate_merge.txt.)
 template <typename I>
 PM_HD __forceinline__ R2T<I> view_get(const GapViewT<I> &v, int i) {
-  if(!v.mirror) {
-    R2T<I> r = v.g[v.lo + i];
-    return R2T<I>{imax(r.s, v.ws), imin(r.e, v.we)};
-  }
-  R2T<I> r = v.g[v.lo + (v.n - 1 - i)];
+  R2T<I> r = v.g[v.lo + (v.mirror ? v.n - 1 - i : i)];
   r = R2T<I>{imax(r.s, v.ws), imin(r.e, v.we)};
-  return R2T<I>{v.L - r.e + 1, v.L - r.s + 1};
+  const R2T<I> m{v.L - r.e + 1, v.L - r.s + 1};
+  return v.mirror ? m : r;
 }
 
 // a5, m_profile.cc:160-206.  On an ascending disjoint list the gaps overlapping [s,e] are one index range.
