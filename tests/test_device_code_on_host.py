@@ -207,3 +207,24 @@ def test_dropped_segment_with_more_gaps_than_the_unit_has_offsets(narrow, harnes
     z = np.zeros(1, dtype=np.int32)
     t = Tables(left, right, deltas, {"delta": z, "left": z, "right": z})
     check_against_oracle(harness, t, narrow)
+
+
+def test_merge_work_of_every_unit(harness, oracle_build):
+    """unit_host_work (the kept gaps of a unit's four lists: what its merge walks through; -1 = dropped by the filter pass or ended by its
+    set-up) on a golden job: a unit with entries in the oracle's answer has a merge in front of it, and the numbers are what
+    profiles/r05_translate_merge.txt was sized with (a wavefront's longest lane against its mean lane)."""
+    import pyoracle
+    case = os.path.join(GOLDEN, "translate_typical")
+    with open(os.path.join(case, "nucmer.list")) as f:
+        deltas = [os.path.join(case, ln.strip()) for ln in f if ln.strip()]
+    t = Workload.load(os.path.join(case, "profiles-l"), os.path.join(case, "profiles-r"), deltas).tables()
+    ls, k1 = capi.rows_struct(t.left)
+    rs, k2 = capi.rows_struct(t.right)
+    ds, k3 = capi.deltas_struct(t.deltas)
+    us, k4 = capi.units_struct(t.units)
+    work = np.full(t.n_units, -7, np.int32)
+    harness.unit_host_work.argtypes = [C.c_void_p] * 5
+    assert harness.unit_host_work(C.byref(ls), C.byref(rs), C.byref(ds), C.byref(us), work.ctypes.data) == 0
+    ora = pyoracle.translate_units(t.left, t.right, t.deltas, t.units)
+    has_entries = np.diff(ora["unit_entry_off"]) > 0
+    assert (work >= -1).all() and (work[has_entries] >= 1).all() and (work > 0).sum() >= has_entries.sum() > 0
